@@ -1,0 +1,79 @@
+"""ctypes binding of libalignsdf_hip.so (the C ABI declared in include/alignsdf_hip.h).
+
+There is no fallback: if the library is missing, or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libalignsdf_hip.so")
+
+MAX_HEADS = 2
+MAX_POINT_FEATS = 64
+GRID_REFERENCE = 0
+GRID_INTEGER = 1
+
+ERANGE = -6
+ENOSURF = -7
+
+# every symbol include/alignsdf_hip.h declares
+EXPORTS = (
+    "asdf_version", "asdf_strerror", "asdf_last_hip_error", "asdf_device_count", "asdf_decoder_create",
+    "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_points",
+    "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_debug_pack_host",
+)
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(what)
+
+
+class DecoderSpec(ctypes.Structure):
+    _fields_ = [("latent_size", ctypes.c_int32), ("hidden", ctypes.c_int32), ("num_heads", ctypes.c_int32),
+                ("point_feats", ctypes.c_int32 * MAX_HEADS)]
+
+
+class HeadParams(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p * 5), ("b", ctypes.c_void_p * 5)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(-100, "libalignsdf_hip.so not found at %s - run `python -m alignsdf_amd.build_native` "
+                                "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    L.asdf_version.restype = ctypes.c_int
+    L.asdf_strerror.restype = ctypes.c_char_p
+    L.asdf_strerror.argtypes = [ctypes.c_int]
+    L.asdf_last_hip_error.restype = ctypes.c_int
+    L.asdf_device_count.restype = ctypes.c_int
+    L.asdf_decoder_create.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams), ctypes.POINTER(vp)]
+    L.asdf_decoder_destroy.argtypes = [vp]
+    L.asdf_decoder_destroy.restype = None
+    L.asdf_decoder_set_sample.argtypes = [vp, vp, vp, vp]
+    L.asdf_decode_grid.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, vp, vp, vp, vp]
+    L.asdf_decode_points.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.asdf_mc_workspace_bytes.argtypes = [i32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.asdf_mc_count.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32),
+                                ctypes.POINTER(ctypes.c_uint32), vp]
+    L.asdf_mc_emit.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_size_t, vp, vp, vp]
+    L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        L = lib()
+        raise NativeError(code, "%s failed: %s (code %d, hip error %d)" % (
+            what, L.asdf_strerror(code).decode(), code, L.asdf_last_hip_error()))

@@ -1,0 +1,48 @@
+"""Build libalignsdf_hip.so (gfx950 only) in-tree with hipcc.
+
+The shared library is the product: HIP kernels + the C ABI of include/alignsdf_hip.h.  It is
+built next to its sources (alignsdf_amd/csrc/) so that it travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libalignsdf_hip.so")
+SOURCES = ["decoder.hip", "mc33.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit and link the shared library. Returns its path."""
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(HERE, "..", "include", "alignsdf_hip.h"))
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, deps):
+            cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,248 @@
+// Host side of the decoder C ABI (include/alignsdf_hip.h): weight packing, the per-sample fold
+// kernel (K0) and the launches of the fused MLP kernel (K1, sdf_mlp_kernel.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/alignsdf_hip.h"
+#include "common.h"
+#include "pack.h"
+#include "sdf_mlp_kernel.h"
+
+namespace asdf {
+
+thread_local int g_last_hip_error = 0;
+
+// ---------------------------------------------------------------------------------------------
+// K0: fold the per-sample constants.  One wave per (head, layer in {0, 2}, output row):
+//   c[o]    = b[o] + W_lat[o,:] . latent + W_pt[o,:] . E[:,3]
+//   A[o][d] = W_pt[o,:] . E[:,d]            d = 0..2   (column 3 of the K = 4 operand is zero)
+// and scatter them into the LDS constants image (sdf_layout.h).
+// Reference arithmetic being folded: utils/utils.py:568-569 (latent expand + cat),
+// networks/model.py:311-312 (layer-2 skip concat) and utils/utils.py:376-430 (kinematic embedding).
+// ---------------------------------------------------------------------------------------------
+struct FoldParams {
+  const float* wlat;     // [heads][2][512][256]
+  const float* wpt;      // [heads][2][512][ASDF_MAX_POINT_FEATS]
+  const float* bias02;   // [heads][2][512]
+  const float* embed;    // [heads][ASDF_MAX_POINT_FEATS][4]
+  const float* latent;   // [256]
+  float* cst;            // [heads][kCstFloats]
+  int pf[ASDF_MAX_HEADS];
+};
+
+__global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
+  const int lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);   // (head, layer, row)
+  const int row = job & (kHidden - 1);
+  const int layer = (job >> 9) & 1;
+  const int head = job >> 10;
+  if (head >= kHeads) return;
+
+  const float* wl = p.wlat + ((size_t)(head * 2 + layer) * kHidden + row) * kLatent;
+  float dot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kLatent / 64; ++k) dot = fmaf(wl[lane + 64 * k], p.latent[lane + 64 * k], dot);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m);
+
+  const float* wp = p.wpt + ((size_t)(head * 2 + layer) * kHidden + row) * ASDF_MAX_POINT_FEATS;
+  const float* E = p.embed + (size_t)head * ASDF_MAX_POINT_FEATS * 4;
+  float a = 0.0f;
+  if (lane < 4)
+    for (int f = 0; f < p.pf[head]; ++f) a = fmaf(wp[f], E[f * 4 + lane], a);
+  const float a3 = __shfl(a, 3);
+
+  float* cst = p.cst + (size_t)head * kCstFloats;
+  const int t = row >> 5, rr = row & 31;
+  if (lane == 0) {
+    const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + a3;
+    const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
+    cst[(layer ? kCstC2 : kCstC0) + (t * 2 + hh) * 16 + r] = c;
+  }
+  if (lane < 4) {
+    const int step = lane >> 1, hh = lane & 1;
+    cst[(layer ? kCstA2 : kCstA0) + (t * 2 + step) * 64 + hh * 32 + rr] = (lane < 3) ? a : 0.0f;
+  }
+}
+
+__global__ void bbox_init_kernel(int* bbox) {
+  const int i = threadIdx.x;
+  if (i < 16) {
+    const int j = i & 7;
+    bbox[i] = j < 3 ? 0x7fffffff : (j < 6 ? -1 : 0);
+  }
+}
+
+}  // namespace asdf
+
+using namespace asdf;
+
+struct asdf_decoder {
+  asdf_decoder_spec_t spec;
+  int n1[ASDF_MAX_HEADS];
+  int device;
+  int num_cus;
+  float* stream;    // [kStagesAll][kStageFloats]
+  float* wlat;      // [heads][2][512][256]
+  float* wpt;       // [heads][2][512][MAXPF]
+  float* bias02;    // [heads][2][512]
+  float* cst;       // [heads][kCstFloats]  (static parts written at create time)
+  float* embed;     // [heads][MAXPF][4]
+  float* latent;    // last bound latent (device pointer owned by the caller)
+  bool sample_bound;
+};
+
+extern "C" {
+
+int asdf_version(void) { return 100; }
+
+const char* asdf_strerror(int code) {
+  switch (code) {
+    case ASDF_OK: return "ok";
+    case ASDF_EINVAL: return "invalid argument or unsupported decoder shape";
+    case ASDF_ENOMEM: return "out of memory";
+    case ASDF_EHIP: return "HIP runtime error";
+    case ASDF_ENODEV: return "no gfx950 device";
+    case ASDF_ENOSPC: return "buffer or workspace too small";
+    case ASDF_ERANGE: return "Surface level must be within volume data range.";
+    case ASDF_ENOSURF: return "No surface found at the given iso value.";
+    default: return "unknown error";
+  }
+}
+
+int asdf_last_hip_error(void) { return g_last_hip_error; }
+
+int asdf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int good = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++good;
+  }
+  return good;
+}
+
+void asdf_decoder_destroy(asdf_decoder_t* d) {
+  if (!d) return;
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed};
+  for (float* b : bufs) (void)hipFree(b);
+  delete d;
+}
+
+int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, asdf_decoder_t** out) {
+  if (!spec || !heads || !out) return ASDF_EINVAL;
+  *out = nullptr;
+  if (spec->latent_size != kLatent || spec->hidden != kHidden || spec->num_heads != kHeads) return ASDF_EINVAL;
+  for (int h = 0; h < kHeads; ++h) {
+    if (spec->point_feats[h] < 1 || spec->point_feats[h] > ASDF_MAX_POINT_FEATS) return ASDF_EINVAL;
+    if (kHidden - kLatent - spec->point_feats[h] < 1) return ASDF_EINVAL;
+    for (int l = 0; l < 5; ++l)
+      if (!heads[h].w[l] || !heads[h].b[l]) return ASDF_EINVAL;
+  }
+  int dev = 0;
+  ASDF_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  ASDF_HIP(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ASDF_ENODEV;
+
+  asdf_decoder* d = new (std::nothrow) asdf_decoder();
+  if (!d) return ASDF_ENOMEM;
+  std::memset(d, 0, sizeof(*d));
+  d->spec = *spec;
+  d->device = dev;
+  d->num_cus = prop.multiProcessorCount;
+
+  HostPack hp;
+  if (!pack_decoder(*spec, heads, hp)) { delete d; return ASDF_ENOMEM; }
+  for (int h = 0; h < kHeads; ++h) d->n1[h] = kHidden - kLatent - spec->point_feats[h];
+  std::vector<float>&stream = hp.stream, &wlat = hp.wlat, &wpt = hp.wpt, &b02 = hp.b02, &cst = hp.cst, &emb = hp.emb;
+
+  hipError_t e = hipSuccess;
+  auto up = [&](float** dst, const std::vector<float>& src) {
+    if (e != hipSuccess) return;
+    e = hipMalloc((void**)dst, src.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+  };
+  up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    asdf_decoder_destroy(d);
+    return e == hipErrorOutOfMemory ? ASDF_ENOMEM : ASDF_EHIP;
+  }
+  *out = d;
+  return ASDF_OK;
+}
+
+int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
+                         float* wlat, float* wpt, float* bias02, float* cst, float* embed) {
+  if (!spec || !heads) return ASDF_EINVAL;
+  if (spec->latent_size != kLatent || spec->hidden != kHidden || spec->num_heads != kHeads) return ASDF_EINVAL;
+  HostPack hp;
+  if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
+  auto cp = [](float* dst, const std::vector<float>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(float)); };
+  cp(stream, hp.stream); cp(wlat, hp.wlat); cp(wpt, hp.wpt); cp(bias02, hp.b02); cp(cst, hp.cst); cp(embed, hp.emb);
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const float* embed_host, void* stream) {
+  if (!d || !latent_dev) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (embed_host) {
+    ASDF_HIP(hipMemcpyAsync(d->embed, embed_host, sizeof(float) * kHeads * ASDF_MAX_POINT_FEATS * 4,
+                            hipMemcpyHostToDevice, st));
+  }
+  FoldParams fp;
+  fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
+  for (int h = 0; h < kHeads; ++h) fp.pf[h] = d->spec.point_feats[h];
+  hipLaunchKernelGGL(fold_sample_kernel, dim3(kHeads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+  ASDF_HIP(hipGetLastError());
+  d->sample_bound = true;
+  return ASDF_OK;
+}
+
+static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
+  if (!d->sample_bound) return ASDF_EINVAL;
+  p.stream = d->stream;
+  p.cst = d->cst;
+  p.heads_mask = 3;
+  if (p.bbox) {
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+    ASDF_HIP(hipGetLastError());
+  }
+  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  if (ntiles == 0) return ASDF_OK;
+  const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
+  hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
+}
+
+int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
+                     float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream) {
+  if (!d || !origin || N < 2 || N > 1024) return ASDF_EINVAL;
+  if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
+  DecodeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = bbox_dev;
+  p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
+  p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
+  return launch_decode(d, p, (hipStream_t)stream);
+}
+
+int asdf_decode_points(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float* sdf_hand_dev, float* sdf_obj_dev,
+                       void* stream) {
+  if (!d || M < 0 || (M > 0 && !xyz_dev)) return ASDF_EINVAL;
+  DecodeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.xyz = xyz_dev; p.P = M; p.N = 1; p.mode = kPointList;
+  return launch_decode(d, p, (hipStream_t)stream);
+}
+
+}  // extern "C"

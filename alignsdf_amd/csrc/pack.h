@@ -1,0 +1,83 @@
+// Host-only packing of decoder weights into the layouts of sdf_layout.h (no device calls).
+#pragma once
+#include <vector>
+
+#include "../../include/alignsdf_hip.h"
+#include "sdf_layout.h"
+
+namespace asdf {
+
+struct HostPack {
+  std::vector<float> stream;   // [kStagesAll][kStageFloats]
+  std::vector<float> wlat;     // [heads][2][512][256]   latent columns of layers 0 and 2
+  std::vector<float> wpt;      // [heads][2][512][ASDF_MAX_POINT_FEATS]  point columns of layers 0 and 2
+  std::vector<float> b02;      // [heads][2][512]
+  std::vector<float> cst;      // [heads][kCstFloats]    static parts filled, per-sample parts zero
+  std::vector<float> emb;      // [heads][ASDF_MAX_POINT_FEATS][4]  identity-on-xyz default
+};
+
+inline bool pack_decoder(const asdf_decoder_spec_t& spec, const asdf_head_params_t* heads, HostPack& hp) {
+  try {
+    hp.stream.assign((size_t)kStagesAll * kStageFloats, 0.f);
+    hp.wlat.assign((size_t)kHeads * 2 * kHidden * kLatent, 0.f);
+    hp.wpt.assign((size_t)kHeads * 2 * kHidden * ASDF_MAX_POINT_FEATS, 0.f);
+    hp.b02.assign((size_t)kHeads * 2 * kHidden, 0.f);
+    hp.cst.assign((size_t)kHeads * kCstFloats, 0.f);
+    hp.emb.assign((size_t)kHeads * ASDF_MAX_POINT_FEATS * 4, 0.f);
+  } catch (...) {
+    return false;
+  }
+  for (int h = 0; h < kHeads; ++h) {
+    const int pf = spec.point_feats[h];
+    const int in = kLatent + pf;
+    const int n1 = kHidden - in;       // layer-1 width: dims[1] - dims[0] (networks/model.py:244-245)
+    const float* W0 = heads[h].w[0]; const float* W1 = heads[h].w[1]; const float* W2 = heads[h].w[2];
+    const float* W3 = heads[h].w[3]; const float* W4 = heads[h].w[4];
+    // latent / point columns of layer 0 ([latent | pts]) and layer 2 ([x1 (n1) | latent | pts])
+    for (int o = 0; o < kHidden; ++o) {
+      float* l0 = &hp.wlat[((size_t)(h * 2 + 0) * kHidden + o) * kLatent];
+      float* l2 = &hp.wlat[((size_t)(h * 2 + 1) * kHidden + o) * kLatent];
+      for (int k = 0; k < kLatent; ++k) { l0[k] = W0[(size_t)o * in + k]; l2[k] = W2[(size_t)o * kHidden + n1 + k]; }
+      float* p0 = &hp.wpt[((size_t)(h * 2 + 0) * kHidden + o) * ASDF_MAX_POINT_FEATS];
+      float* p2 = &hp.wpt[((size_t)(h * 2 + 1) * kHidden + o) * ASDF_MAX_POINT_FEATS];
+      for (int f = 0; f < pf; ++f) { p0[f] = W0[(size_t)o * in + kLatent + f]; p2[f] = W2[(size_t)o * kHidden + n1 + kLatent + f]; }
+      hp.b02[(h * 2 + 0) * kHidden + o] = heads[h].b[0][o];
+      hp.b02[(h * 2 + 1) * kHidden + o] = heads[h].b[2][o];
+    }
+    // weight stream: L1 (8 tiles x 4 stages), L2 (16 x 2), L3 (16 x 4)
+    float* sp = &hp.stream[(size_t)h * kStagesHead * kStageFloats];
+    auto pack = [&](int ntiles, int stages_per_tile, auto weight_at) {
+      for (int t = 0; t < ntiles; ++t)
+        for (int q = 0; q < stages_per_tile; ++q) {
+          for (int g = 0; g < 16; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int s = q * kStageKSteps + g * 4 + j;
+                const int row = 32 * t + (lane & 31);
+                const int feat = kstep_feature(s, lane >> 5);
+                sp[(g * 64 + lane) * 4 + j] = weight_at(row, feat);
+              }
+          sp += kStageFloats;
+        }
+    };
+    pack(kTilesL1, 4, [&](int row, int feat) { return row < n1 ? W1[(size_t)row * kHidden + feat] : 0.0f; });
+    pack(kTilesHidden, 2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
+    pack(kTilesHidden, 4, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
+    // static constants in D-layout order
+    float* c = &hp.cst[(size_t)h * kCstFloats];
+    for (int t = 0; t < kTilesHidden; ++t)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * t + tile_row(r, hh);
+          if (t < kTilesL1) c[kCstB1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] : 0.0f;
+          c[kCstB3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row];
+          c[kCstW4 + (t * 2 + hh) * 16 + r] = W4[row];
+        }
+    c[kCstB4] = heads[h].b[4][0];
+    // default embedding: identity on xyz (PointFeatSize 3)
+    for (int f = 0; f < 3 && f < pf; ++f) hp.emb[((size_t)h * ASDF_MAX_POINT_FEATS + f) * 4 + f] = 1.0f;
+  }
+  return true;
+}
+
+}  // namespace asdf

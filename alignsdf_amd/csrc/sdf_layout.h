@@ -1,0 +1,65 @@
+// Data layout shared by the host-side weight packer and the gfx950 decoder kernel.
+//
+// The SDF heads of AlignSDF (reference: networks/model.py:191-350, SeparateDecoder) are
+// 5-layer, 512-wide MLPs.  The per-sample-constant latent columns of layer 0 and layer 2 are
+// folded into per-sample biases (reference cat order: networks/model.py:311,330 and
+// utils/utils.py:568-569), and the (affine) point embedding is folded into the 3 xyz columns,
+// so one head, per query point, is
+//
+//   h0 = relu(A0 [512x4]   . (x,y,z,0)        + c0)      K =   4   (per-sample A0, c0)
+//   h1 = relu(W1 [256x512] . h0               + b1)      K = 512   (rows >= n1 are zero)
+//   h2 = relu(W2a[512x256] . h1 + A2[512x4].p + c2)      K = 256+4 (per-sample A2, c2)
+//   h3 = relu(W3 [512x512] . h2               + b3)      K = 512
+//   s  = tanh(w4 . h3 + b4)
+//
+// Everything is laid out for v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand
+// (M = output features) and the POINTS as the B operand (N = 32 points per wave):
+//   A: lane l holds A[i = l & 31][k = l >> 5]      (one f32 VGPR)
+//   B: lane l holds B[k = l >> 5][j = l & 31]      (one f32 VGPR)
+//   D: lane l, reg r holds D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+// Register r of an output tile is therefore directly a valid B operand of the next layer for
+// the K pair {row(r, 0), row(r, 1)}: activations never leave the register file.
+#pragma once
+#include <stdint.h>
+
+namespace asdf {
+
+constexpr int kHidden = 512;            // width of every hidden layer
+constexpr int kLatent = 256;            // latent code size (specs["LatentSize"])
+constexpr int kTilesHidden = 16;        // 512 / 32 output tiles
+constexpr int kTilesL1 = 8;             // layer-1 output padded to 256 rows
+constexpr int kWavePts = 32;            // query points per wave (one 32-wide MFMA column block)
+constexpr int kWaves = 4;               // one wave per SIMD
+constexpr int kWgPts = kWavePts * kWaves;
+
+// Weight stream: fixed-size stages of 64 K-steps (K = 128) of ONE 32-row output tile.
+// stage image = [g = 0..15][lane = 0..63][j = 0..3] floats; K-step s = 4 g + j.
+constexpr int kStageKSteps = 64;
+constexpr int kStageFloats = kStageKSteps * 64;     // 4096 floats
+constexpr int kStageBytes = kStageFloats * 4;       // 16 KiB
+constexpr int kStagesL1 = kTilesL1 * 4;             // K = 512 -> 4 stages per tile
+constexpr int kStagesL2 = kTilesHidden * 2;         // K = 256 -> 2 stages per tile
+constexpr int kStagesL3 = kTilesHidden * 4;
+constexpr int kStagesHead = kStagesL1 + kStagesL2 + kStagesL3;   // 128
+constexpr int kHeads = 2;
+constexpr int kStagesAll = kStagesHead * kHeads;                  // 256 stages = 4 MiB
+
+// Per-head constants block (floats), loaded into LDS once per workgroup.
+//   frag arrays: [tile][kstep = 0..1][lane]  (A operand images)
+//   bias arrays: [tile][half = 0..1][r = 0..15]  (D-layout order)
+constexpr int kCstA0 = 0;                                   // 16 * 2 * 64 = 2048
+constexpr int kCstA2 = kCstA0 + kTilesHidden * 2 * 64;      // 2048
+constexpr int kCstC0 = kCstA2 + kTilesHidden * 2 * 64;      // 512
+constexpr int kCstB1 = kCstC0 + kHidden;                    // 256
+constexpr int kCstC2 = kCstB1 + kTilesL1 * 32;              // 512
+constexpr int kCstB3 = kCstC2 + kHidden;                    // 512
+constexpr int kCstW4 = kCstB3 + kHidden;                    // 512
+constexpr int kCstB4 = kCstW4 + kHidden;                    // 1 (+3 pad)
+constexpr int kCstFloats = kCstB4 + 4;                      // 6404 floats = 25 616 B
+
+// feature row held by (register r, lane half h) of a 32x32 D tile
+__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// input feature consumed by K-step s (s = 16 * in_tile + r) on lane half h
+__host__ __device__ constexpr int kstep_feature(int s, int h) { return 32 * (s >> 4) + tile_row(s & 15, h); }
+
+}  // namespace asdf

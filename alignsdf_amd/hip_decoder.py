@@ -1,0 +1,188 @@
+"""Host-side handle of the HIP SDF decoder: turns a reference-shaped decoder module into the packed
+MFMA weight stream (once) and exposes the grid / point-list sweeps.
+
+The module is recognised by its parameters (`lin{h,o}{0..4}.weight_g|weight_v|weight|bias`, the
+state-dict layout of networks/model.py:191-282) and attributes (`latent_size`, `point_feat_size`,
+`encode_style`).  PyTorch is used for device memory and streams only; all arithmetic runs in
+libalignsdf_hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def _effective(module_sd, name):
+    """Effective [out, in] weight of layer `name`: g * v / ||v|| for weight-normed layers, computed
+    with the same torch primitive the module's forward hook uses (networks/model.py:249-250)."""
+    if name + ".weight_v" in module_sd:
+        v = module_sd[name + ".weight_v"].detach().float().cpu()
+        g = module_sd[name + ".weight_g"].detach().float().cpu()
+        return torch._weight_norm(v, g, 0).contiguous()
+    return module_sd[name + ".weight"].detach().float().cpu().contiguous()
+
+
+def head_point_feats(point_feat_size, encode_style):
+    """(hand, obj) point-feature counts per encode style (networks/model.py:212-223, :288-299)."""
+    return {
+        "nerf": (point_feat_size, point_feat_size),
+        "hand": (point_feat_size, 3),
+        "obj": (3, point_feat_size),
+        "both": (point_feat_size - 3, 6),
+    }[encode_style]
+
+
+def kinematic_affine(point_feat_size, encode_style, scale_factor, mano_results, obj_results):
+    """Affine form of utils.utils.kinematic_embedding (utils/utils.py:376-430): returns, per head,
+    E [pf_head, 4] with  feat = E[:, :3] @ xyz + E[:, 3].  Computed in float64 from the same inputs.
+
+    wrist = xyz * 2 / sf;  mano = wrist + rot_center;  q_j = (G_j^-1 [mano; 1])[:3] / w;
+    o = (T_obj^-1 [wrist; 1])[:3] / w;  all scaled back by sf / 2.  (The homogeneous divisor w is the
+    constant 1 for rigid transforms; it is folded in as computed.)"""
+    sf = float(scale_factor)
+    a = 2.0 / sf
+    rows_hand, rows_obj_tail = [], []
+    if encode_style in ("hand", "both"):
+        rc = mano_results["rot_center"].detach().double().cpu().reshape(3).numpy()
+        # mano_xyz * sf/2 = xyz + rc * sf/2
+        m = np.concatenate([np.eye(3), (rc * sf / 2.0)[:, None]], 1)
+        rows_hand.append(m)
+        G = mano_results["global_trans"].detach().double().cpu().reshape(16, 4, 4).numpy()
+        joints = 1 if ((point_feat_size == 6 and encode_style == "hand") or
+                       (point_feat_size == 9 and encode_style == "both")) else 16
+        for j in range(joints):
+            Gi = np.linalg.inv(G[j])
+            # [mano;1] = [a*xyz + rc; 1];  q = Gi[:3,:3] (a xyz + rc) + Gi[:3,3], divided by w
+            w = Gi[3, :3] @ rc + Gi[3, 3]          # xyz-dependent part of w is 0 for rigid transforms
+            lin = Gi[:3, :3] * a / w
+            off = (Gi[:3, :3] @ rc + Gi[:3, 3]) / w
+            rows_hand.append(np.concatenate([lin * sf / 2.0, (off * sf / 2.0)[:, None]], 1))
+    if encode_style in ("obj", "both"):
+        T = obj_results["obj_trans"].detach().double().cpu().reshape(4, 4).numpy()
+        Ti = np.linalg.inv(T)
+        w = Ti[3, 3]
+        lin = Ti[:3, :3] * a / w
+        off = Ti[:3, 3] / w
+        rows_obj_tail.append(np.concatenate([lin * sf / 2.0, (off * sf / 2.0)[:, None]], 1))
+    ident = np.concatenate([np.eye(3), np.zeros((3, 1))], 1)
+    if encode_style == "hand":
+        return np.concatenate(rows_hand, 0), rows_hand[0]            # obj head sees input[:, :L+3] = mano_xyz*sf/2
+    if encode_style == "obj":
+        return ident, np.concatenate([ident] + rows_obj_tail, 0)     # hand head sees input[:, :L+3] = xyz
+    hand = np.concatenate(rows_hand, 0)
+    return hand, np.concatenate([rows_hand[0]] + rows_obj_tail, 0)   # networks/model.py:297-299
+
+
+class HipSdfDecoder:
+    """Device-resident packed decoder.  One instance per (module, device)."""
+
+    def __init__(self, module_or_state_dict, latent_size=None, point_feat_size=None, encode_style=None, device=None):
+        if isinstance(module_or_state_dict, torch.nn.Module):
+            m = module_or_state_dict
+            sd = m.state_dict()
+            latent_size = latent_size if latent_size is not None else getattr(m, "latent_size", 256)
+            point_feat_size = point_feat_size if point_feat_size is not None else m.point_feat_size
+            encode_style = encode_style if encode_style is not None else m.encode_style
+            if getattr(m, "use_classifier", False):
+                raise NotImplementedError("classifier head is not part of the HIP path yet")
+        else:
+            sd = {k: torch.as_tensor(v) for k, v in module_or_state_dict.items()}
+        sd = {k[len("module.decoder."):] if k.startswith("module.decoder.") else k: v for k, v in sd.items()}
+        if "linh0.bias" not in sd or "lino4.bias" not in sd:
+            raise NotImplementedError("HIP path supports SeparateDecoder-shaped modules (linh*/lino* parameters)")
+        self.latent_size = int(latent_size)
+        self.point_feat_size = int(point_feat_size)
+        self.encode_style = encode_style
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        L = _native.lib()
+        if L.asdf_device_count() < 1:
+            raise _native.NativeError(-4, "no gfx950 (MI355X) device visible - the HIP path has no CPU fallback")
+        pf = head_point_feats(self.point_feat_size, encode_style)
+        spec = _native.DecoderSpec(self.latent_size, 512, 2, (ctypes.c_int32 * 2)(*pf))
+        heads = (_native.HeadParams * 2)()
+        keep = []
+        for hi, head in enumerate("ho"):
+            n_in = self.latent_size + pf[hi]
+            shapes = [(512, n_in), (512 - n_in, 512), (512, 512), (512, 512), (1, 512)]
+            for layer in range(5):
+                name = "lin%s%d" % (head, layer)
+                w = _effective(sd, name)
+                b = sd[name + ".bias"].detach().float().cpu().contiguous()
+                if tuple(w.shape) != shapes[layer] or b.numel() != shapes[layer][0]:
+                    raise NotImplementedError("unsupported layer shape %s %s (expected %s)" % (
+                        name, tuple(w.shape), shapes[layer]))
+                keep += [w, b]
+                heads[hi].w[layer] = w.data_ptr()
+                heads[hi].b[layer] = b.data_ptr()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _native.check(L.asdf_decoder_create(ctypes.byref(spec), heads, ctypes.byref(handle)), "asdf_decoder_create")
+        self._h = handle
+        self._L = L
+        self._pf = pf
+        self._latent = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.asdf_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_sample(self, latent_vec, embed=None):
+        """Bind a latent code [1, L] (any device) and optional per-head affine embeddings (hand_E, obj_E)."""
+        lat = latent_vec.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+        if lat.numel() != self.latent_size:
+            raise ValueError("latent has %d elements, expected %d" % (lat.numel(), self.latent_size))
+        emb_ptr = None
+        if embed is not None:
+            buf = np.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=np.float32)
+            for h in range(2):
+                e = np.asarray(embed[h], dtype=np.float64)
+                if e.shape != (self._pf[h], 4):
+                    raise ValueError("embedding of head %d has shape %s, expected %s" % (h, e.shape, (self._pf[h], 4)))
+                buf[h, :self._pf[h]] = e.astype(np.float32)
+            emb_ptr = buf.ctypes.data_as(ctypes.c_void_p)
+            self._emb_keep = buf
+        elif self._pf != (3, 3):
+            raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
+        self._latent = lat   # keep the device buffer alive until the next set_sample
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
+                          "asdf_decoder_set_sample")
+            if emb_ptr is not None:
+                torch.cuda.current_stream(self.device).synchronize()   # host staging buffer is pageable
+
+    def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True):
+        """Both heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None),
+        all device tensors."""
+        hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device)
+        obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device)
+        bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
+        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
+                                                   int(grid_mode), hand.data_ptr(), obj.data_ptr(),
+                                                   bbox.data_ptr() if want_bbox else None, self._stream()),
+                          "asdf_decode_grid")
+        return hand, obj, bbox
+
+    def decode_points(self, xyz):
+        """Both heads on explicit normalised points [M,3]. Returns (hand [M], obj [M]) device tensors."""
+        xyz = xyz.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        M = xyz.shape[0]
+        hand = torch.empty(M, dtype=torch.float32, device=self.device)
+        obj = torch.empty(M, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decode_points(self._h, xyz.data_ptr(), M, hand.data_ptr(), obj.data_ptr(),
+                                                     self._stream()), "asdf_decode_points")
+        return hand, obj

@@ -1,0 +1,119 @@
+/* alignsdf_hip.h - C ABI of libalignsdf_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary for AlignSDF's reconstruction hot path.  The reference has no native
+ * interface of its own (it is pure PyTorch + skimage); each entry point below names the reference
+ * code it replaces (paths relative to the zerchen/AlignSDF tree).  Plain pointers and sizes only:
+ * device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()), `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  All functions return 0 on success or a
+ * negative ASDF_E* code, never throw, and never fall back to a CPU implementation.
+ */
+#ifndef ALIGNSDF_HIP_H_
+#define ALIGNSDF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASDF_OK 0
+#define ASDF_EINVAL (-1)     /* bad argument / unsupported decoder shape */
+#define ASDF_ENOMEM (-2)     /* device or host allocation failed */
+#define ASDF_EHIP (-3)       /* a HIP runtime call failed (see asdf_last_hip_error) */
+#define ASDF_ENODEV (-4)     /* no gfx950 device visible */
+#define ASDF_ENOSPC (-5)     /* caller-provided buffer / workspace too small */
+#define ASDF_ERANGE (-6)     /* iso level outside the volume's data range (skimage ValueError) */
+#define ASDF_ENOSURF (-7)    /* no surface found (skimage RuntimeError) */
+
+#define ASDF_MAX_HEADS 2
+#define ASDF_MAX_POINT_FEATS 64
+
+/* Grid index modes of asdf_decode_grid. */
+#define ASDF_GRID_REFERENCE 0 /* true-division indices exactly as utils/mesh.py:32-34 computes them */
+#define ASDF_GRID_INTEGER 1   /* floor-division indices (an axis-aligned lattice) */
+
+typedef struct asdf_decoder asdf_decoder_t;
+
+/* Shape of the SDF MLP heads: networks/model.py:191-282 (SeparateDecoder.__init__) with
+ * dims = [512,512,512,512], latent_in = [2], weight_norm on layers 0-3 (already folded by the
+ * caller: W = g * v / ||v||, networks/model.py:249-250).
+ * Head h consumes [latent (latent_size) | point features (point_feats[h])]. */
+typedef struct asdf_decoder_spec {
+  int32_t latent_size;                    /* 256 */
+  int32_t hidden;                         /* 512 */
+  int32_t num_heads;                      /* 2: hand, object */
+  int32_t point_feats[ASDF_MAX_HEADS];    /* 3 ("nerf", PointFeatSize 3) or 6 ("both", PointFeatSize 9) ... */
+} asdf_decoder_spec_t;
+
+/* Host-side effective parameters of one head, row-major [out][in] like nn.Linear.weight:
+ *   w[0] [hidden][latent+pf]   b[0] [hidden]        lin{h,o}0   (networks/model.py:249)
+ *   w[1] [hidden-latent-pf][hidden]  b[1]           lin{h,o}1   (out = dims[1] - dims[0], :244-245)
+ *   w[2] [hidden][hidden]      b[2] [hidden]        lin{h,o}2   (input = cat(x1, head_input), :311)
+ *   w[3] [hidden][hidden]      b[3] [hidden]        lin{h,o}3
+ *   w[4] [1][hidden]           b[4] [1]             lin{h,o}4   (plain Linear, then tanh :324-325) */
+typedef struct asdf_head_params {
+  const float* w[5];
+  const float* b[5];
+} asdf_head_params_t;
+
+int asdf_version(void);
+const char* asdf_strerror(int code);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int asdf_last_hip_error(void);
+/* Number of visible gfx950 devices (0 if none); does not initialise a context. */
+int asdf_device_count(void);
+
+/* Build a decoder on the current HIP device: packs the weights into the MFMA streaming layout and
+ * uploads them.  Replaces module construction + per-forward weight-norm recomputation
+ * (networks/model.py:249-250 forward pre-hook). */
+int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads /*[num_heads]*/,
+                        asdf_decoder_t** out);
+void asdf_decoder_destroy(asdf_decoder_t* dec);
+
+/* Bind the per-sample inputs: the latent code (device, [latent_size]) and, per head, the affine map
+ * from a normalised query point to that head's point features,
+ *     feat[f] = embed[h][f][0..2] . xyz + embed[h][f][3]
+ * (host, [num_heads][ASDF_MAX_POINT_FEATS][4]; NULL = identity, i.e. PointFeatSize 3).
+ * Replaces latent.expand + cat (utils/utils.py:568-569) and utils.utils.kinematic_embedding
+ * (utils/utils.py:376-430), which is affine in xyz. */
+int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const float* embed_host, void* stream);
+
+/* Evaluate both heads on the N^3 lattice
+ *     coord[a] = idx[a] * voxel_size + origin[a]     (fp32 mul then add, a = 0,1,2; axis 2 fastest)
+ * writing sdf_hand[N^3], sdf_obj[N^3] (device; either may be NULL) and, if bbox_dev != NULL, the
+ * per-head bounding box of negative voxels as int32[16]:
+ *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels.
+ * Replaces one pass of utils/mesh.py:27-63 (or :82-115) plus the nonzero/min/max of
+ * get_higher_res_cube (utils/mesh.py:208-237); deep_sdf/mesh.py:24-54 for the legacy entry point. */
+int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
+                     float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream);
+
+/* Evaluate both heads on an explicit list of M normalised points xyz_dev[M][3] (device).
+ * Replaces utils.utils.decode_sdf_multi_output (utils/utils.py:561-572) / deep_sdf.utils.decode_sdf
+ * (deep_sdf/utils.py:64-75) for one chunk. */
+int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, float* sdf_hand_dev,
+                       float* sdf_obj_dev, void* stream);
+
+/* ---- Lewiner marching cubes (replaces skimage.measure.marching_cubes_lewiner as called at
+ * utils/mesh.py:354 and deep_sdf/mesh.py:81: level given, step_size 1, allow_degenerate True,
+ * use_classic False, gradient_direction 'descent', no mask).  Volume is [n0][n1][n2] fp32 on the
+ * device.  Two-phase: count (classify + scan, returns V and F), then emit into caller buffers.
+ * Output matches skimage element for element before the `* spacing` step:
+ *   verts[V][3] fp32 in (axis0, axis1, axis2) voxel units, faces[F][3] int32. */
+int asdf_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2, size_t* bytes);
+int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, float level, void* workspace_dev,
+                  size_t workspace_bytes, uint32_t* num_verts, uint32_t* num_faces, void* stream);
+int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, float level, void* workspace_dev,
+                 size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
+
+/* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
+ * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
+ * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*6404, embed 2*ASDF_MAX_POINT_FEATS*4. */
+int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
+                         float* wlat, float* wpt, float* bias02, float* cst, float* embed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNSDF_HIP_H_ */

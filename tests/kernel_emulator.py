@@ -1,0 +1,138 @@
+"""Lane-accurate numpy emulation of the K0 (fold) and K1 (fused MLP) kernels' data flow.
+
+Consumes the REAL packed images produced by the C++ packer (asdf_debug_pack_host) and walks the
+same indices as alignsdf_amd/csrc/sdf_mlp_kernel.h, with v_mfma_f32_32x32x2_f32 modelled by its
+operand maps:  A[i][k] = a[lane = i + 32 k],  B[k][j] = b[lane = j + 32 k],
+               D[row(r, lane >> 5)][lane & 31] = acc[r][lane].
+This is how the layouts are validated without a GPU (CPU test suite); it is test infrastructure.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from alignsdf_amd import _native
+from alignsdf_amd.hip_decoder import _effective, head_point_feats
+
+K_HIDDEN, K_LATENT, K_CST = 512, 256, 6404
+STAGE = 4096
+OFF = dict(A0=0, A2=2048, C0=4096, B1=4608, C2=4864, B3=5376, W4=5888, B4=6400)
+LANE = np.arange(64)
+HALF = LANE >> 5
+ROW = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in range(2)] for r in range(16)])   # [r][half]
+
+
+def pack_host(sd, point_feat_size, encode_style):
+    """Run the C++ packer on a state dict; returns dict of numpy images."""
+    L = _native.lib()
+    pf = head_point_feats(point_feat_size, encode_style)
+    spec = _native.DecoderSpec(256, 512, 2, (ctypes.c_int32 * 2)(*pf))
+    heads = (_native.HeadParams * 2)()
+    keep = []
+    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    for hi, head in enumerate("ho"):
+        for layer in range(5):
+            name = "lin%s%d" % (head, layer)
+            w = _effective(sd, name)
+            b = sd[name + ".bias"].float().contiguous()
+            keep += [w, b]
+            heads[hi].w[layer] = w.data_ptr()
+            heads[hi].b[layer] = b.data_ptr()
+    out = {
+        "stream": np.zeros(256 * STAGE, np.float32), "wlat": np.zeros(2 * 2 * 512 * 256, np.float32),
+        "wpt": np.zeros(2 * 2 * 512 * _native.MAX_POINT_FEATS, np.float32), "b02": np.zeros(2 * 2 * 512, np.float32),
+        "cst": np.zeros(2 * K_CST, np.float32), "emb": np.zeros(2 * _native.MAX_POINT_FEATS * 4, np.float32),
+    }
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _native.check(L.asdf_debug_pack_host(ctypes.byref(spec), heads, ptr(out["stream"]), ptr(out["wlat"]), ptr(out["wpt"]),
+                                         ptr(out["b02"]), ptr(out["cst"]), ptr(out["emb"])), "asdf_debug_pack_host")
+    out["pf"] = pf
+    return out
+
+
+def fold(pk, latent, embed=None):
+    """K0 emulation: fills the per-sample parts of pk['cst'] (returns a new cst array)."""
+    cst = pk["cst"].copy().reshape(2, K_CST)
+    wlat = pk["wlat"].reshape(2, 2, 512, 256)
+    wpt = pk["wpt"].reshape(2, 2, 512, _native.MAX_POINT_FEATS)
+    b02 = pk["b02"].reshape(2, 2, 512)
+    emb = pk["emb"].reshape(2, _native.MAX_POINT_FEATS, 4).copy()
+    if embed is not None:
+        emb[:] = 0
+        for h in range(2):
+            emb[h, :pk["pf"][h]] = np.asarray(embed[h], np.float32)
+    lat = np.asarray(latent, np.float32).reshape(256)
+    for head in range(2):
+        for layer in range(2):
+            dot = (wlat[head, layer].astype(np.float32) @ lat).astype(np.float32)
+            a = (wpt[head, layer, :, :pk["pf"][head]] @ emb[head, :pk["pf"][head]]).astype(np.float32)   # [512,4]
+            c = ((dot + b02[head, layer]).astype(np.float32) + a[:, 3]).astype(np.float32)
+            for row in range(512):
+                t, rr = row >> 5, row & 31
+                hh, r = (rr >> 2) & 1, (rr & 3) + 4 * (rr >> 3)
+                cst[head, (OFF["C2"] if layer else OFF["C0"]) + (t * 2 + hh) * 16 + r] = c[row]
+                for d in range(4):
+                    step, h2 = d >> 1, d & 1
+                    cst[head, (OFF["A2"] if layer else OFF["A0"]) + (t * 2 + step) * 64 + h2 * 32 + rr] = a[row, d] if d < 3 else 0.0
+    return cst
+
+
+def mfma(a, b, acc):
+    """acc[16][64] += A.B with the 32x32x2 operand maps (fp32 products, fp64 accumulate is avoided on purpose)."""
+    A = a.reshape(2, 32)            # A[k][i]
+    B = b.reshape(2, 32)            # B[k][j]
+    D = (A[0][:, None] * B[0][None, :]).astype(np.float32)
+    D = (D + (A[1][:, None] * B[1][None, :]).astype(np.float32)).astype(np.float32)
+    rows = ROW[:, HALF]             # [16][64]
+    cols = (LANE & 31)[None, :].repeat(16, 0)
+    return (acc + D[rows, cols]).astype(np.float32)
+
+
+def bias16(c, off, t):
+    """load_bias16 for all lanes: [16][64]."""
+    out = np.zeros((16, 64), np.float32)
+    for h in range(2):
+        out[:, HALF == h] = c[off + (t * 2 + h) * 16: off + (t * 2 + h) * 16 + 16][:, None]
+    return out
+
+
+def run_wave(pk, cst, xyz32):
+    """K1 emulation for one wave: xyz32 [32,3] -> (hand [32], obj [32])."""
+    x = np.asarray(xyz32, np.float32)
+    pt = LANE & 31
+    bx0 = np.where(HALF == 1, x[pt, 1], x[pt, 0]).astype(np.float32)
+    bx1 = np.where(HALF == 1, 0.0, x[pt, 2]).astype(np.float32)
+    stream = pk["stream"].reshape(256, 16, 64, 4)
+    outs = []
+    for head in range(2):
+        c = cst[head]
+        sbase = head * 128
+
+        def layer(ntiles, stages_per_tile, s0, hin, bias_off, extra=None):
+            res = []
+            for t in range(ntiles):
+                acc = bias16(c, bias_off, t)
+                if extra is not None:
+                    acc = mfma(c[extra + (t * 2 + 0) * 64: extra + (t * 2 + 0) * 64 + 64], bx0, acc)
+                    acc = mfma(c[extra + (t * 2 + 1) * 64: extra + (t * 2 + 1) * 64 + 64], bx1, acc)
+                for q in range(stages_per_tile):
+                    st = stream[sbase + s0 + t * stages_per_tile + q]
+                    for g in range(16):
+                        for j in range(4):
+                            s = q * 64 + g * 4 + j
+                            acc = mfma(st[g, :, j], hin[s >> 4][s & 15], acc)
+                res.append(acc)
+            return res
+
+        h0 = [np.maximum(a, 0) for a in layer(16, 0, 0, None, OFF["C0"], OFF["A0"])]
+        h1 = [np.maximum(a, 0) for a in layer(8, 4, 0, h0, OFF["B1"])]
+        h2 = [np.maximum(a, 0) for a in layer(16, 2, 32, h1, OFF["C2"], OFF["A2"])]
+        h3 = layer(16, 4, 64, h2, OFF["B3"])
+        part = np.zeros(64, np.float32)
+        for t in range(16):
+            w = bias16(c, OFF["W4"], t)
+            for r in range(16):
+                part = (np.maximum(h3[t][r], 0) * w[r] + part).astype(np.float32)
+        tot = part + part[LANE ^ 32]
+        outs.append(np.tanh(tot + c[OFF["B4"]])[:32].astype(np.float32))
+    return outs[0], outs[1]
