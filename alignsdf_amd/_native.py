@@ -19,7 +19,7 @@ ENOSURF = -7
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
     "asdf_version", "asdf_strerror", "asdf_last_hip_error", "asdf_device_count", "asdf_decoder_create",
-    "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_points",
+    "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_points", "asdf_neg_bbox",
     "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_debug_pack_host",
 )
 
@@ -63,10 +63,11 @@ def lib():
     L.asdf_decoder_set_sample.argtypes = [vp, vp, vp, vp]
     L.asdf_decode_grid.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, vp, vp, vp, vp]
     L.asdf_decode_points.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.asdf_neg_bbox.argtypes = [vp, i32, i32, i32, vp, vp]
     L.asdf_mc_workspace_bytes.argtypes = [i32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
-    L.asdf_mc_count.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32),
+    L.asdf_mc_count.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32),
                                 ctypes.POINTER(ctypes.c_uint32), vp]
-    L.asdf_mc_emit.argtypes = [vp, i32, i32, i32, f32, vp, ctypes.c_size_t, vp, vp, vp]
+    L.asdf_mc_emit.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, vp, vp, vp]
     L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
     _lib = L
     return L

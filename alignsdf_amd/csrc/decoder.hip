@@ -69,11 +69,36 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
   }
 }
 
-__global__ void bbox_init_kernel(int* bbox) {
+__global__ void bbox_init_kernel(int* bbox) {   // 16 ints: two records of {min[3], max[3], count, pad}
   const int i = threadIdx.x;
   if (i < 16) {
     const int j = i & 7;
     bbox[i] = j < 3 ? 0x7fffffff : (j < 6 ? -1 : 0);
+  }
+}
+
+// K2 (standalone form; K1 fuses the same reduction into its epilogue): bounding box of the voxels with
+// sdf < 0 - torch.nonzero + per-axis min/max of get_higher_res_cube (utils/mesh.py:208-237).
+__global__ __launch_bounds__(256) void neg_bbox_kernel(const float* __restrict__ vol, long long n, int n1, int n2, int* bbox) {
+  int lo0 = 0x7fffffff, lo1 = 0x7fffffff, lo2 = 0x7fffffff, hi0 = -1, hi1 = -1, hi2 = -1, cnt = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (vol[i] < 0.0f) {
+      const int i2 = (int)(i % n2), i1 = (int)((i / n2) % n1), i0 = (int)((i / n2) / n1);
+      lo0 = min(lo0, i0); lo1 = min(lo1, i1); lo2 = min(lo2, i2);
+      hi0 = max(hi0, i0); hi1 = max(hi1, i1); hi2 = max(hi2, i2);
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo0 = min(lo0, __shfl_xor(lo0, m)); lo1 = min(lo1, __shfl_xor(lo1, m)); lo2 = min(lo2, __shfl_xor(lo2, m));
+    hi0 = max(hi0, __shfl_xor(hi0, m)); hi1 = max(hi1, __shfl_xor(hi1, m)); hi2 = max(hi2, __shfl_xor(hi2, m));
+    cnt += __shfl_xor(cnt, m);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicMin(bbox + 0, lo0); atomicMin(bbox + 1, lo1); atomicMin(bbox + 2, lo2);
+    atomicMax(bbox + 3, hi0); atomicMax(bbox + 4, hi1); atomicMax(bbox + 5, hi2);
+    atomicAdd(bbox + 6, cnt);
   }
 }
 
@@ -177,6 +202,17 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     return e == hipErrorOutOfMemory ? ASDF_ENOMEM : ASDF_EHIP;
   }
   *out = d;
+  return ASDF_OK;
+}
+
+int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int32_t* bbox_dev, void* stream) {
+  if (!vol_dev || !bbox_dev || n0 < 1 || n1 < 1 || n2 < 1) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bbox_dev);
+  const long long n = (long long)n0 * n1 * n2;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(neg_bbox_kernel, dim3(grid), dim3(256), 0, st, vol_dev, n, n1, n2, bbox_dev);
+  ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }
 

@@ -15,7 +15,7 @@
 #include <stdint.h>
 
 #ifdef __HIPCC__
-#define MC33_HD __host__ __device__ __forceinline__
+#define MC33_HD __device__ __forceinline__
 #else
 #define MC33_HD static inline
 #endif

@@ -1,0 +1,68 @@
+"""Device-side Lewiner marching cubes with the call shape of skimage.measure.marching_cubes_lewiner
+as the reference uses it (utils/mesh.py:354, deep_sdf/mesh.py:81).
+
+All arithmetic runs in libalignsdf_hip.so (asdf_mc_count / asdf_mc_emit); torch only owns the buffers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+_workspaces = {}
+
+
+def _workspace(shape, device):
+    key = (tuple(shape), str(device))
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = ctypes.c_size_t()
+        _native.check(_native.lib().asdf_mc_workspace_bytes(shape[0], shape[1], shape[2], ctypes.byref(nbytes)),
+                      "asdf_mc_workspace_bytes")
+        _workspaces.clear()          # keep one workspace alive (a 256^3 one is ~340 MB)
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def marching_cubes_device(volume, level=0.0):
+    """volume: [n0,n1,n2] fp32 CUDA tensor.  Returns (verts [V,3] fp32, faces [F,3] int32) device tensors
+    in voxel units, element-for-element what skimage returns before its `* spacing` step.
+    Raises ValueError / RuntimeError with skimage's messages (the reference catches them, utils/mesh.py:353-358)."""
+    if not isinstance(volume, torch.Tensor) or not volume.is_cuda:
+        raise TypeError("marching_cubes_device needs a CUDA tensor (there is no CPU fallback)")
+    if volume.dim() != 3:
+        raise ValueError("Input volume should be a 3D numpy array.")
+    if min(volume.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    vol = volume.detach().to(torch.float32).contiguous()
+    L = _native.lib()
+    dev = vol.device
+    ws = _workspace(vol.shape, dev)
+    nv, nf = ctypes.c_uint32(), ctypes.c_uint32()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        rc = L.asdf_mc_count(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(float(level)),
+                             ws.data_ptr(), ws.numel(), ctypes.byref(nv), ctypes.byref(nf), stream)
+        if rc == _native.ERANGE:
+            raise ValueError("Surface level must be within volume data range.")
+        if rc == _native.ENOSURF:
+            raise RuntimeError("No surface found at the given iso value.")
+        _native.check(rc, "asdf_mc_count")
+        verts = torch.empty((nv.value, 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((nf.value, 3), dtype=torch.int32, device=dev)
+        _native.check(L.asdf_mc_emit(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(float(level)),
+                                     ws.data_ptr(), ws.numel(), verts.data_ptr(), faces.data_ptr(), stream),
+                      "asdf_mc_emit")
+    return verts, faces
+
+
+def marching_cubes_lewiner(volume, level=0.0, spacing=(1.0, 1.0, 1.0)):
+    """numpy-returning variant: (verts, faces) on the host with skimage's spacing / dtype semantics
+    (`vertices * np.r_[spacing]` unless spacing == (1,1,1))."""
+    verts, faces = marching_cubes_device(volume, level)
+    verts, faces = verts.cpu().numpy(), faces.cpu().numpy()
+    if not np.array_equal(spacing, (1, 1, 1)):
+        verts = verts * np.r_[spacing]
+    return verts, faces

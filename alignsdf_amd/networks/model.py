@@ -1,0 +1,94 @@
+"""Checkpoint-compatible containers for AlignSDF's SDF decoders.
+
+`SeparateDecoder` has the constructor signature, attribute names and state-dict keys of the reference
+class (networks/model.py:191-282: `lin{h,o}{0..4}.weight_g|weight_v|bias`, plain `weight` on the last
+layer), so `module.decoder.*` tensors of a reference `latest.pth` load unchanged.  It exists to carry
+parameters to the HIP path (alignsdf_amd.hip_decoder.HipSdfDecoder); its `forward` is a plain PyTorch
+evaluation of the same network for host-side checks and is never used by the mesh-extraction path.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+
+def _linear(n_in, n_out, normed):
+    lin = nn.Linear(n_in, n_out)
+    if normed:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lin = nn.utils.weight_norm(lin)     # parameters weight_g [out,1], weight_v [out,in]
+    return lin
+
+
+class SeparateDecoder(nn.Module):
+    """Two independent MLP heads (hand, object) over [latent | point features]."""
+
+    def __init__(self, latent_size, point_feat_size, encode_style, dims, num_class=6, dropout=None, dropout_prob=0.0,
+                 norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
+                 use_classifier=False):
+        super().__init__()
+        if use_classifier:
+            raise NotImplementedError("classifier head (ClassifierBranch) is outside the accelerated hot path")
+        if not weight_norm and norm_layers:
+            raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
+        self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
+        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
+        self.dropout, self.dropout_prob = dropout, dropout_prob
+        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = False, use_tanh, xyz_in_all, latent_dropout
+        self.num_class = num_class
+        widths = {"nerf": (point_feat_size, point_feat_size), "hand": (point_feat_size, 3), "obj": (3, point_feat_size),
+                  "both": (point_feat_size - 3, 6)}[encode_style]          # networks/model.py:212-223
+        self.head_point_feats = widths
+        for prefix, pf in zip(("linh", "lino"), widths):
+            sizes = [latent_size + pf] + list(dims) + [1]
+            self.num_layers = len(sizes)
+            for layer in range(len(sizes) - 1):
+                n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
+                setattr(self, prefix + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+
+    def head_inputs(self, inputs):
+        """Per-head input slices (networks/model.py:288-299)."""
+        L = self.latent_size
+        if self.encode_style == "nerf":
+            return inputs, inputs
+        if self.encode_style == "hand":
+            return inputs, inputs[:, :L + 3]
+        if self.encode_style == "obj":
+            return inputs[:, :L + 3], inputs
+        return inputs[:, :-3], torch.cat([inputs[:, :L + 3], inputs[:, -3:]], 1)
+
+    def _head(self, prefix, x0):
+        x = x0
+        last = self.num_layers - 2
+        for layer in range(self.num_layers - 1):
+            if layer in self.latent_in:
+                x = torch.cat([x, x0], 1)
+            x = getattr(self, prefix + str(layer))(x)
+            if layer < last:
+                x = torch.relu(x)
+                if self.training and self.dropout is not None and layer in self.dropout:
+                    x = torch.nn.functional.dropout(x, p=self.dropout_prob, training=True)
+        return torch.tanh(x)
+
+    def forward(self, inputs):
+        xh, xo = self.head_inputs(inputs)
+        return self._head("linh", xh)[:, 0:1], self._head("lino", xo)[:, 0:1], torch.zeros(1, device=inputs.device)
+
+
+def build_decoder(specs, state_dict=None):
+    """SeparateDecoder from a specs.json dict (networks/model_utils.py:14-31 for ModelType 1encoder2decoder)."""
+    if specs.get("ModelType", "1encoder2decoder") != "1encoder2decoder":
+        raise NotImplementedError("only ModelType 1encoder2decoder (SeparateDecoder) is supported")
+    dec = SeparateDecoder(specs["LatentSize"], specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"],
+                          use_classifier=bool(specs.get("ClassifierBranch", False)))
+    if state_dict is not None:
+        sd = {}
+        for k, v in state_dict.items():
+            for pre in ("module.decoder.", "decoder."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            if k.startswith(("linh", "lino")):
+                sd[k] = torch.as_tensor(v)
+        dec.load_state_dict(sd)
+    return dec.eval()

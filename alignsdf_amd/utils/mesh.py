@@ -1,0 +1,147 @@
+"""Drop-in counterpart of the reference's utils/mesh.py hot path (create_mesh_combined_decoder,
+get_higher_res_cube, convert_sdf_samples_to_ply) on the HIP kernels.
+
+Signatures follow utils/mesh.py:17, :198 and :331.  Volumes stay on the device; only the extracted mesh
+(verts / faces) is copied to the host for export.  There is no CPU path: without the HIP library or an
+MI355X the functions raise.
+"""
+import ctypes
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..marching_cubes import marching_cubes_device
+from ..ply import write_ply
+from .utils import hip_decoder_for, sample_embedding
+
+GRID_MODES = {"reference": _native.GRID_REFERENCE, "integer": _native.GRID_INTEGER}
+
+
+def neg_bbox(volume):
+    """int32[7] host array (min0,min1,min2,max0,max1,max2,count) of the voxels with value < 0 of a device volume."""
+    vol = volume.detach().to(torch.float32).contiguous()
+    if not vol.is_cuda:
+        raise TypeError("neg_bbox needs a CUDA tensor (there is no CPU fallback)")
+    out = torch.empty(16, dtype=torch.int32, device=vol.device)
+    with torch.cuda.device(vol.device):
+        _native.check(_native.lib().asdf_neg_bbox(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], out.data_ptr(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(vol.device).cuda_stream)),
+                      "asdf_neg_bbox")
+    return out[:7].cpu().numpy()
+
+
+def zoom_cube_from_bboxes(bboxes, N, voxel_size):
+    """The fp32 arithmetic of get_higher_res_cube (utils/mesh.py:239-254) on per-branch bounding boxes
+    [(min3, max3, count)]; an empty branch contributes zeros (utils/mesh.py:209-211,225-227).
+    Returns (new_voxel_size 0-dim fp32 tensor, new_origin [3] fp32 tensor) on the CPU, like the reference."""
+    los, his = [], []
+    for lo, hi, count in bboxes:
+        if count == 0:
+            los.append(torch.zeros(3)); his.append(torch.zeros(3))
+        else:
+            los.append(torch.tensor([float(v) for v in lo])); his.append(torch.tensor([float(v) for v in hi]))
+    min_index = los[0] if len(los) == 1 else torch.min(los[0], los[1])
+    max_index = his[0] if len(his) == 1 else torch.max(his[0], his[1])
+    new_cube_size = (torch.max(max_index - min_index) + 4) * voxel_size
+    new_voxel_size = new_cube_size / (N - 1)
+    new_origin = (min_index - 2) * voxel_size - 1.0
+    return new_voxel_size, new_origin
+
+
+def get_higher_res_cube(hand_branch, obj_branch, sdf_values_hand, sdf_values_obj, N, voxel_origin, voxel_size):
+    """Zoom cube around the negative voxels of the enabled branches (utils/mesh.py:198-256)."""
+    boxes = []
+    for on, vol in ((hand_branch, sdf_values_hand), (obj_branch, sdf_values_obj)):
+        if on:
+            b = neg_bbox(vol)
+            boxes.append((b[0:3], b[3:6], int(b[6])))
+    return zoom_cube_from_bboxes(boxes, N, voxel_size)
+
+
+def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None):
+    """MC + the vertex arithmetic of utils/mesh.py:354-369 (spacing, origin, optional scale / offset).
+    Returns (verts, faces, mesh_points) as host arrays; raises like skimage on failure."""
+    vol = sdf if isinstance(sdf, torch.Tensor) else torch.as_tensor(np.asarray(sdf))
+    if not vol.is_cuda:
+        vol = vol.cuda()
+    verts_d, faces_d = marching_cubes_device(vol, 0.0)
+    verts, faces = verts_d.cpu().numpy(), faces_d.cpu().numpy()
+    vs = voxel_size.item() if isinstance(voxel_size, torch.Tensor) else voxel_size
+    spacing = [np.float32(vs)] * 3 if isinstance(voxel_size, torch.Tensor) else [vs] * 3
+    if not np.array_equal(spacing, (1, 1, 1)):
+        verts = verts * np.r_[spacing]
+    mesh_points = np.zeros_like(verts)
+    for a in range(3):
+        mesh_points[:, a] = voxel_grid_origin[a] + verts[:, a]
+    if scale is not None:
+        mesh_points = mesh_points * scale
+    if offset is not None:
+        mesh_points = mesh_points + offset
+    return verts, faces, mesh_points
+
+
+def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
+                               scale=None, eval_mode=False, task="obman"):
+    """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale).
+    MC failures are logged and skipped exactly like the reference (utils/mesh.py:353-358).  The
+    largest-component filter and the eval-mode ICP of utils/mesh.py:371-395 are host post-processing outside
+    the accelerated path; the full extracted surface is written."""
+    try:
+        verts, faces, mesh_points = extract_surface(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, offset, scale)
+    except (ValueError, RuntimeError) as e:
+        logging.warning("Cannot reconstruct mesh from '{}'".format(ply_filename_out))
+        print(e)
+        return None, None, np.array([0, 0, 0]), np.array([1])
+    if eval_mode:
+        logging.warning("eval_mode ICP alignment (utils/mesh.py:385-395) is not part of this build; writing the unaligned mesh")
+    if ply_filename_out:
+        os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
+        write_ply(ply_filename_out, mesh_points, faces)
+    return verts, faces, np.array([0, 0, 0]), np.array([1])
+
+
+def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference"):
+    """Pass 1 on [-1,1]^3, zoom cube, pass 2 (utils/mesh.py:21-121) entirely on the device.
+    Returns dict(vol_hand, vol_obj device tensors of pass 2, voxel_size 0-dim fp32 tensor, origin list,
+    bbox int32[16] of pass 1)."""
+    hip = hip_decoder_for(decoder)
+    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results))
+    mode = GRID_MODES[grid_mode]
+    voxel_size = 2.0 / (N - 1)
+    _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode)
+    b = bbox.cpu().numpy()
+    boxes = []
+    if hand_branch:
+        boxes.append((b[0:3], b[3:6], int(b[6])))
+    if obj_branch:
+        boxes.append((b[8:11], b[11:14], int(b[14])))
+    new_voxel_size, new_origin = zoom_cube_from_bboxes(boxes, N, voxel_size)
+    vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False)
+    return {"vol_hand": vol_hand, "vol_obj": vol_obj, "voxel_size": new_voxel_size, "origin": new_origin.tolist(), "bbox": b}
+
+
+def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, latent_vec, mano_results, obj_results, cam_intr,
+                                 specs, filename, N=256, max_batch=32 ** 3, offset=None, scale=None, device="cpu",
+                                 label_out=False, viz=False, eval_mode=False, task="obman", grid_mode="reference"):
+    """Hand + object meshes of one sample (utils/mesh.py:17-195): writes <filename>_hand.ply / _obj.ply.
+    `max_batch` and `device` are accepted for signature compatibility; chunking is internal to the kernel and
+    the decoder's device is used.  `grid_mode="reference"` reproduces the true-division lattice of
+    utils/mesh.py:33-34 bit for bit; "integer" is the axis-aligned lattice.  Returns a dict of per-surface
+    (V, F) counts (the reference returns None)."""
+    if cls_branch or label_out:
+        raise NotImplementedError("classifier / label pass (utils/mesh.py:137-184) is outside the accelerated path")
+    decoder.eval() if hasattr(decoder, "eval") else None
+    r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode)
+    stats = {}
+    if hand_branch:
+        v, f, _, _ = convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"], filename + "_hand.ply", None, None,
+                                                eval_mode, task)
+        stats["hand"] = (0, 0) if v is None else (len(v), len(f))
+    if obj_branch:
+        v, f, _, _ = convert_sdf_samples_to_ply(r["vol_obj"], r["origin"], r["voxel_size"], filename + "_obj.ply", offset, scale,
+                                                False)
+        stats["obj"] = (0, 0) if v is None else (len(v), len(f))
+    return stats

@@ -89,6 +89,12 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
 int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
                      float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream);
 
+/* Bounding box of the voxels with value < 0 of one [n0][n1][n2] fp32 device volume, as int32[16] on the
+ * device (record 0 only: [0..2] min index per axis, [3..5] max index per axis, [6] count; min = INT_MAX and
+ * max = -1 when the count is 0).  Replaces torch.nonzero + min/max in get_higher_res_cube
+ * (utils/mesh.py:208-237) for callers that hold volumes rather than a decoder. */
+int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int32_t* bbox_dev, void* stream);
+
 /* Evaluate both heads on an explicit list of M normalised points xyz_dev[M][3] (device).
  * Replaces utils.utils.decode_sdf_multi_output (utils/utils.py:561-572) / deep_sdf.utils.decode_sdf
  * (deep_sdf/utils.py:64-75) for one chunk. */
@@ -102,9 +108,9 @@ int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, flo
  * Output matches skimage element for element before the `* spacing` step:
  *   verts[V][3] fp32 in (axis0, axis1, axis2) voxel units, faces[F][3] int32. */
 int asdf_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2, size_t* bytes);
-int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, float level, void* workspace_dev,
+int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                   size_t workspace_bytes, uint32_t* num_verts, uint32_t* num_faces, void* stream);
-int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, float level, void* workspace_dev,
+int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                  size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
