@@ -58,7 +58,8 @@ def test_create_mesh_combined_decoder_files(tag, tmp_path, golden_dir):
         assert stats[part] == (len(ref_v), len(ref_f))
         assert f.shape == ref_f.shape and np.array_equal(f, ref_f)
         world = ref_v + gd["mc_origin_32"].astype(np.float32)
-        assert np.abs(v - world).max() <= 2e-4 * float(gd["mc_voxel_size_32"][0]) + 1e-6
+        # an SDF difference d moves a vertex by d / (SDF change per voxel ~ 0.5 * voxel) along its edge
+        assert np.abs(v - world).max() <= 5e-5
 
 
 def test_mc_failure_is_skipped_like_reference(tmp_path, capsys):
