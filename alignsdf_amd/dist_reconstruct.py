@@ -1,0 +1,113 @@
+"""Multi-GPU reconstruction: counterpart of the reference's dist_reconstruct.py (dist_reconstruct.py:27-84).
+
+The reference slices the test split into contiguous ranges and Popen()s one reconstruct.py per GPU, with no
+communication (and a thread race on the GPU index, dist_reconstruct.py:21).  Here the launcher is torchrun
+(one process per GPU, rank -> device bound explicitly), the ranges are the reference's, and the only
+collective is one gather of fixed-size per-sample records to rank 0 at the end (RCCL over xGMI on the GPU
+box; gloo in the CPU tests).  No data-path collective exists because samples are independent.
+
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m alignsdf_amd.dist_reconstruct -e EXP -t obman
+"""
+import argparse
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+RECORD_FIELDS = ("index", "V_hand", "F_hand", "V_obj", "F_obj", "milliseconds")
+
+
+def shard_range(num_items, world_size, rank):
+    """Contiguous [start, end) of `rank` exactly as dist_reconstruct.py:63-76: equal `len // W` slices, the
+    last rank also takes the remainder."""
+    division = num_items // world_size
+    start = rank * division
+    end = start + division if rank != world_size - 1 else num_items
+    return start, end
+
+
+def gather_records(local_records, group=None):
+    """Gather per-sample records (dicts with RECORD_FIELDS) from every rank to rank 0, ordered by sample index.
+    One size exchange + one padded gather; returns the merged list on rank 0 and None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([[float(r.get(k, 0)) for k in RECORD_FIELDS] for r in local_records], dtype=torch.float64,
+                     device=device).reshape(-1, len(RECORD_FIELDS))
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=device), group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts) if counts else 0
+    buf = torch.zeros((pad, len(RECORD_FIELDS)), dtype=torch.float64, device=device)
+    buf[:t.shape[0]] = t
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0, group=group)
+    if rank != 0:
+        return None
+    merged = []
+    for r in range(world):
+        for row in out[r][:counts[r]].cpu().tolist():
+            rec = {k: (v if k == "milliseconds" else int(v)) for k, v in zip(RECORD_FIELDS, row)}
+            rec["rank"] = r
+            merged.append(rec)
+    merged.sort(key=lambda x: x["index"])
+    return merged
+
+
+def run_sharded(num_items, process_range, backend=None):
+    """Initialise the process group from the torchrun environment, run `process_range(start, end, rank)` on this
+    rank's shard and gather the records on rank 0."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)       # explicit rank -> device binding
+    created = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        created = True
+    start, end = shard_range(num_items, world, rank)
+    records = process_range(start, end, rank)
+    merged = gather_records(records) if world > 1 else sorted(records, key=lambda x: x["index"])
+    if created:
+        dist.barrier()
+        dist.destroy_process_group()
+    return merged
+
+
+def main(argv=None):
+    from . import reconstruct as rc
+    p = argparse.ArgumentParser(description="Generate meshes in parallel (one process per GPU under torchrun)")
+    p.add_argument("--experiment", "-e", dest="experiment_directory", required=True)
+    p.add_argument("--task", "-t", dest="task", default="obman", choices=["obman", "dexycb"])
+    p.add_argument("--optim", dest="optim", action="store_true")
+    p.add_argument("--codes", dest="code_dir", default=None)
+    p.add_argument("--cube_dim", type=int, default=128)
+    args = p.parse_args(argv)
+    split = {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
+    names = json.load(open(split))["filenames"]
+    specs, decoder = rc.load_experiment(args.experiment_directory)
+    output_dir = os.path.join(args.experiment_directory, "Eval_" + args.task)
+    source = rc.npz_code_source(args.code_dir) if args.code_dir else None
+
+    def process(start, end, rank):
+        print("rank %d: samples %d to %d" % (rank, start, end - 1), flush=True)
+        recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
+                              eval_mode=True, label_out=args.optim, code_source=source)
+        for r in recs:
+            r["milliseconds"] = 1e3 * r["seconds"]
+        return recs
+
+    merged = run_sharded(len(names), process)
+    if merged is not None:
+        with open(os.path.join(output_dir, "reconstruct_summary.json"), "w") as f:
+            json.dump(merged, f)
+        print("reconstructed %d samples" % len(merged))
+
+
+if __name__ == "__main__":
+    main()

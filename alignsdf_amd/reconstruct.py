@@ -1,0 +1,151 @@
+"""Per-GPU reconstruction driver: counterpart of the reference's reconstruct.py (reconstruct.py:33-95,
+CLI :107-178) for the accelerated hot path.
+
+The reference's per-image front end (ResNet-18 encoder, MANO branch: utils.decode_model_output,
+utils/utils.py:575-625) is out of scope of this build; what it hands to the hot path - a latent code
+[1,256] and, for pose-aligned models, `global_trans` / `rot_center` / `obj_trans` - comes from a
+`code_source(sample_name, index) -> (latent, mano_results, obj_results)` callable instead.  Two sources
+are provided: precomputed `.npz` codes on disk and the deterministic synthetic codes used by the tests
+and the benchmark.  Everything after that point (two-pass grid decode, zoom cube, marching cubes, PLY)
+is the HIP path.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import synthetic
+from .networks.model import build_decoder
+from .utils import mesh as mesh_utils
+
+
+def synthetic_code_source(tag="nerf3", device="cuda"):
+    """Deterministic per-sample codes (64 distinct samples, cycled)."""
+    def source(name, index):
+        s = index % 64
+        lat = torch.from_numpy(synthetic.latent_code(s)).to(device)
+        if tag == "nerf3":
+            return lat, None, None
+        m, o = synthetic.pose_inputs(s)
+        return lat, {k: torch.from_numpy(v).to(device) for k, v in m.items()}, {k: torch.from_numpy(v).to(device) for k, v in o.items()}
+    return source
+
+
+def npz_code_source(code_dir, device="cuda"):
+    """Codes saved by an external encoder run: <code_dir>/<sample>.npz with `latent` [1,256] and optionally
+    `global_trans` [1,16,4,4], `rot_center` [1,1,3], `obj_trans` [1,4,4]."""
+    def source(name, index):
+        z = np.load(os.path.join(code_dir, name + ".npz"))
+        lat = torch.from_numpy(z["latent"]).float().to(device)
+        mano = obj = None
+        if "global_trans" in z.files:
+            mano = {"global_trans": torch.from_numpy(z["global_trans"]).float().to(device),
+                    "rot_center": torch.from_numpy(z["rot_center"]).float().to(device)}
+        if "obj_trans" in z.files:
+            obj = {"obj_trans": torch.from_numpy(z["obj_trans"]).float().to(device)}
+        return lat, mano, obj
+    return source
+
+
+def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
+                       eval_mode=False, task="obman", scale=None):
+    """One sample through the hot path.  Returns a record dict; writes <mesh_filename>_hand.ply / _obj.ply when
+    a filename is given, otherwise leaves the meshes on the device (`verts_*`, `faces_*` tensors)."""
+    from .marching_cubes import marching_cubes_device
+    hand_branch, obj_branch = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
+    t0 = time.perf_counter()
+    r = mesh_utils.decode_two_pass(hand_branch, obj_branch, decoder, latent, mano_results, obj_results, specs, N, grid_mode)
+    rec = {"V_hand": 0, "F_hand": 0, "V_obj": 0, "F_obj": 0}
+    if mesh_filename is not None:
+        stats = {}
+        if hand_branch:
+            v, f, _, _ = mesh_utils.convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"],
+                                                                mesh_filename + "_hand.ply", None, None, eval_mode, task)
+            stats["hand"] = (0, 0) if v is None else (len(v), len(f))
+        if obj_branch:
+            v, f, _, _ = mesh_utils.convert_sdf_samples_to_ply(r["vol_obj"], r["origin"], r["voxel_size"],
+                                                                mesh_filename + "_obj.ply", None, scale, False)
+            stats["obj"] = (0, 0) if v is None else (len(v), len(f))
+        for part, (nv, nf) in stats.items():
+            rec["V_" + part], rec["F_" + part] = nv, nf
+    else:
+        for part, on in (("hand", hand_branch), ("obj", obj_branch)):
+            if not on:
+                continue
+            try:
+                v, f = marching_cubes_device(r["vol_" + part], 0.0)
+            except (ValueError, RuntimeError):
+                continue          # the reference logs and skips (utils/mesh.py:353-358)
+            rec["V_" + part], rec["F_" + part] = v.shape[0], f.shape[0]
+            rec["verts_" + part], rec["faces_" + part] = v, f
+    rec["voxel_size"], rec["origin"] = float(r["voxel_size"]), r["origin"]
+    rec["seconds"] = time.perf_counter() - t0
+    return rec
+
+
+def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, end_point, task="obman", device="cuda", scale=None,
+                cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference"):
+    """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
+    decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
+    Returns the list of per-sample records."""
+    if label_out or viz:
+        raise NotImplementedError("label / viz outputs (utils/mesh.py:137-184) are outside the accelerated path")
+    mesh_dir = os.path.join(output_dir, "meshes")
+    os.makedirs(mesh_dir, exist_ok=True)
+    with open(split_filename, "r") as f:
+        names = json.load(f)["filenames"][int(start_point):int(end_point)]
+    decoder = loaded_model
+    for attr in ("module", "decoder"):
+        decoder = getattr(decoder, attr, decoder)
+    if code_source is None:
+        code_source = synthetic_code_source("nerf3" if specs["PointFeatSize"] == 3 else "both9", device)
+    records = []
+    with torch.no_grad():
+        for k, path in enumerate(names):
+            name = path.split("/")[-1].split(".")[0]                       # reconstruct.py:78
+            latent, mano_results, obj_results = code_source(name, int(start_point) + k)
+            rec = reconstruct_sample(decoder, specs, latent, mano_results, obj_results, cube_dim, os.path.join(mesh_dir, name),
+                                     grid_mode, eval_mode, task, scale)
+            rec["index"], rec["name"] = int(start_point) + k, name
+            records.append(rec)
+    return records
+
+
+def load_experiment(model_directory, device="cuda"):
+    """specs.json + ModelParameters/latest.pth -> (specs, decoder module) (reconstruct.py:166-170,
+    networks/model_utils.py:40-47; only the `module.decoder.*` tensors are read)."""
+    specs = json.load(open(os.path.join(model_directory, "specs.json")))
+    ckpt = torch.load(os.path.join(model_directory, "ModelParameters", "latest.pth"), map_location="cpu")
+    return specs, build_decoder(specs, ckpt.get("model_state_dict", ckpt))
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="Reconstruct hand / object meshes with the MI355X-native hot path.")
+    p.add_argument("--model", "-e", dest="model_directory", default="./pretrained_model")
+    p.add_argument("--split", "-s", dest="split_filename", default=None)
+    p.add_argument("--task", "-t", dest="task", default="obman", choices=["obman", "dexycb"])
+    p.add_argument("--start_point", dest="start_point")
+    p.add_argument("--end_point", dest="end_point")
+    p.add_argument("--eval_mode", dest="eval_mode", action="store_true")
+    p.add_argument("--label", dest="label_out", action="store_true")
+    p.add_argument("--viz", dest="viz", action="store_true")
+    p.add_argument("--codes", dest="code_dir", default=None, help="directory of precomputed <sample>.npz codes")
+    p.add_argument("--cube_dim", type=int, default=128, help="grid resolution (reference CLI hard-codes 128, reconstruct.py:178)")
+    args = p.parse_args(argv)
+    split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
+    output_dir = os.path.join(args.model_directory, "Eval_" + args.task)
+    os.makedirs(output_dir, exist_ok=True)
+    specs, decoder = load_experiment(args.model_directory)
+    if args.start_point is None or args.end_point is None:
+        with open(split) as f:
+            args.start_point, args.end_point = 0, len(json.load(f)["filenames"])
+    source = npz_code_source(args.code_dir) if args.code_dir else None
+    return reconstruct(decoder, specs, split, output_dir, args.start_point, args.end_point, task=args.task, cube_dim=args.cube_dim,
+                       label_out=args.label_out, viz=args.viz, eval_mode=args.eval_mode, code_source=source)
+
+
+if __name__ == "__main__":
+    main()
