@@ -11,6 +11,7 @@
 #include "common.h"
 #include "pack.h"
 #include "sdf_mlp_kernel.h"
+#include "sdf_mlp_kernel_v2.h"
 
 namespace asdf {
 
@@ -196,6 +197,8 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sdf_mlp_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
     asdf_decoder_destroy(d);
@@ -255,7 +258,12 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
-  hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  // schedule variant: 2 = mid-stage barrier + deferred epilogues (default), 1 = barrier per stage start
+  const char* var = std::getenv("ASDF_K1_VARIANT");
+  if (var && var[0] == '1')
+    hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  else
+    hipLaunchKernelGGL(sdf_mlp_kernel_v2, dim3(grid), dim3(256), kLdsBytes, st, p);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }

@@ -1,0 +1,251 @@
+// K1, variant 2 of the fused SDF decoder kernel: same data layout and arithmetic as sdf_mlp_kernel
+// (sdf_mlp_kernel.h), different schedule:
+//   * the per-stage barrier sits in the MIDDLE of a stage (in the shadow of an in-flight MFMA) and certifies
+//     the NEXT stage, so the A-fragment prefetch runs across stage boundaries and never drains;
+//   * the ReLU / dot-product epilogue of output tile t is deferred into the MFMA stream of tile t+1;
+//   * ReLU is an integer max on the float bits (one VALU op, no canonicalisation).
+#pragma once
+#include "sdf_mlp_kernel.h"
+
+namespace asdf {
+
+__device__ __forceinline__ f32x16 relu16i(f32x16 v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = __int_as_float(max(__float_as_int(v[r]), 0));
+  return v;
+}
+
+// sum of the two accumulator chains of a tile (DUAL = 1) or just the single chain
+template <int DUAL>
+__device__ __forceinline__ f32x16 chains(const f32x16& a, const f32x16& b) { return DUAL ? a + b : a; }
+
+struct NoEpilogue {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// One 64-K-step stage of the weight stream.  On entry (a0, a1) hold the A fragments of groups 0 and 1 of THIS
+// stage; on exit they hold those of the next stage in stream order.  `epi` (the previous tile's epilogue) is
+// issued behind the first eight MFMAs.
+// ABL is an ablation mask for tools/k1_ablate.hip (0 in the product): 1 = no DMA / vmcnt wait / barrier,
+// 2 = no LDS reads of A fragments, 4 = no tile epilogues, 8 = no layer 0.
+template <int KT, int Q, int SLOT, int ABL, int DUAL, class Epi>
+__device__ __forceinline__ void stage2(f32x16& acc, f32x16& accb, const f32x16 (&hin)[KT], const float* ring, const float* next_src,
+                                       unsigned lds_ring_base, int lane, int wave, f32x4& a0, f32x4& a1, Epi&& epi) {
+  constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
+  const float* src = next_src + wave * 1024 + lane * 4;
+  const unsigned dst = lds_ring_base + (nslot * kStageFloats + wave * 1024) * 4;
+  const f32x4* cur = reinterpret_cast<const f32x4*>(ring + SLOT * kStageFloats) + lane;
+  const f32x4* nxt = reinterpret_cast<const f32x4*>(ring + ((SLOT + 1) % kRing) * kStageFloats) + lane;
+  f32x4 abuf[18];
+  abuf[0] = a0;
+  abuf[1] = a1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    if (g == 8 && !(ABL & 1)) {
+      // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (ABL & 2) { abuf[g + 2] = abuf[g]; asm volatile("" : "+v"(abuf[g + 2])); }
+    else abuf[g + 2] = g + 2 < 16 ? cur[(g + 2) * 64] : nxt[(g + 2 - 16) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = Q * 64 + g * 4 + j;
+      // two independent accumulator chains (even / odd K-steps): a dependent 32x32x2 MFMA issues ~5 cycles
+      // later than the 64-cycle pipe interval, an independent one does not
+      if (DUAL && (j & 1)) accb = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], accb);
+      else acc = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], acc);
+      if (g == 8 && !(ABL & 1)) {
+        // one DMA piece per MFMA shadow (an LDS-DMA issue costs about one 64-cycle MFMA slot); pinned so the
+        // scheduler cannot cluster the four pieces behind a single MFMA
+        lds_dma16(src + j * 256, dst + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (g == 1 && !(ABL & 4)) epi();
+  }
+  a0 = abuf[16];
+  a1 = abuf[17];
+}
+
+template <int ABL, int DUAL>
+__device__ __forceinline__ void sdf_mlp_body_v2(const DecodeParams& p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ring = smem;
+  float* cst = smem + kLdsRingFloats;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+
+  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  if ((long long)blockIdx.x >= ntiles) return;
+
+  // per-sample constants -> LDS (once per workgroup)
+  for (int i = tid; i < kHeads * kCstFloats / 4; i += 256)
+    reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
+  __syncthreads();
+
+  const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+
+  // prologue: stages 0..2 in flight
+#pragma unroll
+  for (int s = 0; s < kRing - 1; ++s) {
+    const float* src = p.stream + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
+    const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0
+  __builtin_amdgcn_s_barrier();                         // everybody's pieces of stage 0
+  f32x4 a0 = (reinterpret_cast<const f32x4*>(ring) + lane)[0];
+  f32x4 a1 = (reinterpret_cast<const f32x4*>(ring) + lane)[64];
+
+  int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1;
+  int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1;
+  int bcnt = 0, ocnt = 0;
+
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
+    const bool valid = pi < p.P;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (p.mode == kPointList) {
+      if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
+    } else {
+      grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+    }
+    // B operands of the two xyz K-steps: lane half 0 supplies k = 0 / 2, half 1 supplies k = 1 / 3
+    const float bx0 = half ? x1 : x0;
+    const float bx1 = half ? 0.0f : x2;
+
+#pragma unroll 1
+    for (int head = 0; head < kHeads; ++head) {
+      const float* hc = cst + head * kCstFloats;
+      // source of stage (s + 3) relative to this head's first stage, wrapping to the other head
+      const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
+      const float* swrap = p.stream + (size_t)(1 - head) * kStagesHead * kStageFloats;
+      auto src_of = [&](int s) -> const float* {   // s = stage index within head + 3
+        return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
+      };
+
+      // ---- layer 0: K = 4 (xyz + zero pad), per-sample A fragments from LDS
+      f32x16 h0[kTilesHidden];
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16 acc = load_bias16(hc + kCstC0 + (t * 2 + half) * 16);
+        if (!(ABL & 8)) {
+          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 0) * 64 + lane], bx0, acc);
+          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        }
+        h0[t] = (ABL & 8) ? acc : relu16i(acc);
+      }
+
+#define ASDF_STAGE(KT, Q, SLOT, ACC, HIN, SIDX, EPI) \
+  stage2<KT, Q, SLOT, ABL, DUAL>(ACC, ACC##b, HIN, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, a0, a1, EPI)
+
+      // ---- layer 1: 512 -> 256 (rows >= n1 are zero padding); epilogue of tile t-1 rides in tile t
+      f32x16 h1[kTilesL1];
+      f32x16 acc1[2], acc1b[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < kTilesL1; ++t) {
+        f32x16& acc = acc1[t & 1];
+        f32x16& accb = acc1b[t & 1];
+        acc = load_bias16(hc + kCstB1 + (t * 2 + half) * 16);
+        accb = zero16;
+        auto epi = [&]() { if (t > 0) h1[t - 1] = relu16i(chains<DUAL>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1])); };
+        ASDF_STAGE(16, 0, 0, acc, h0, t * 4 + 0, epi);
+        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, NoEpilogue());
+        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, NoEpilogue());
+        ASDF_STAGE(16, 3, 3, acc, h0, t * 4 + 3, NoEpilogue());
+      }
+
+      // ---- layer 2: [h1 (256) | xyz (4)] -> 512
+      f32x16 h2[kTilesHidden];
+      f32x16 acc2[2], acc2b[2];
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16& acc = acc2[t & 1];
+        f32x16& accb = acc2b[t & 1];
+        acc = load_bias16(hc + kCstC2 + (t * 2 + half) * 16);
+        acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 0) * 64 + lane], bx0, acc);
+        if (DUAL) accb = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, zero16);
+        else acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        auto epi = [&]() {
+          if (t > 0) h2[t - 1] = relu16i(chains<DUAL>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1]));
+          else h1[kTilesL1 - 1] = relu16i(chains<DUAL>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1]));   // consumed by K-steps >= 112
+        };
+        constexpr int S0 = kStagesL1;
+        if (t & 1) {
+          ASDF_STAGE(8, 0, 2, acc, h1, S0 + t * 2 + 0, epi);
+          ASDF_STAGE(8, 1, 3, acc, h1, S0 + t * 2 + 1, NoEpilogue());
+        } else {
+          ASDF_STAGE(8, 0, 0, acc, h1, S0 + t * 2 + 0, epi);
+          ASDF_STAGE(8, 1, 1, acc, h1, S0 + t * 2 + 1, NoEpilogue());
+        }
+      }
+
+      // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4) and tanh
+      float part = 0.0f;
+      f32x16 acc3[2], acc3b[2];
+      auto dot_w4 = [&](const f32x16 a, int t) {
+        const f32x16 w = load_bias16(hc + kCstW4 + (t * 2 + half) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), w[r], part);
+      };
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16& acc = acc3[t & 1];
+        f32x16& accb = acc3b[t & 1];
+        acc = load_bias16(hc + kCstB3 + (t * 2 + half) * 16);
+        accb = zero16;
+        auto epi = [&]() {
+          if (t > 0) dot_w4(chains<DUAL>(acc3[(t - 1) & 1], acc3b[(t - 1) & 1]), t - 1);
+          else h2[kTilesHidden - 1] = relu16i(chains<DUAL>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1]));   // consumed by K-steps >= 240
+        };
+        constexpr int S0 = kStagesL1 + kStagesL2;
+        ASDF_STAGE(16, 0, 0, acc, h2, S0 + t * 4 + 0, epi);
+        ASDF_STAGE(16, 1, 1, acc, h2, S0 + t * 4 + 1, NoEpilogue());
+        ASDF_STAGE(16, 2, 2, acc, h2, S0 + t * 4 + 2, NoEpilogue());
+        ASDF_STAGE(16, 3, 3, acc, h2, S0 + t * 4 + 3, NoEpilogue());
+      }
+      dot_w4(chains<DUAL>(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1]), kTilesHidden - 1);
+#undef ASDF_STAGE
+      part += __shfl_xor(part, 32);
+      const float sdf = tanhf(part + hc[kCstB4]);
+
+      float* out = head == 0 ? p.sdf0 : p.sdf1;
+      if (valid && half == 0 && out) out[pi] = sdf;
+
+      if (p.bbox && valid && half == 0 && sdf < 0.0f && p.mode != kPointList) {
+        const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
+        if (head == 0) {
+          bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
+          bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
+        } else {
+          omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
+          omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (p.bbox) {
+    if (bcnt) {
+      atomicMin(p.bbox + 0, bmin0); atomicMin(p.bbox + 1, bmin1); atomicMin(p.bbox + 2, bmin2);
+      atomicMax(p.bbox + 3, bmax0); atomicMax(p.bbox + 4, bmax1); atomicMax(p.bbox + 5, bmax2);
+      atomicAdd(p.bbox + 6, bcnt);
+    }
+    if (ocnt) {
+      atomicMin(p.bbox + 8, omin0); atomicMin(p.bbox + 9, omin1); atomicMin(p.bbox + 10, omin2);
+      atomicMax(p.bbox + 11, omax0); atomicMax(p.bbox + 12, omax1); atomicMax(p.bbox + 13, omax2);
+      atomicAdd(p.bbox + 14, ocnt);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel_v2(const DecodeParams p) { sdf_mlp_body_v2<0, 0>(p); }
+
+}  // namespace asdf
