@@ -32,7 +32,7 @@ class NativeError(RuntimeError):
 
 class DecoderSpec(ctypes.Structure):
     _fields_ = [("latent_size", ctypes.c_int32), ("hidden", ctypes.c_int32), ("num_heads", ctypes.c_int32),
-                ("point_feats", ctypes.c_int32 * MAX_HEADS)]
+                ("point_feats", ctypes.c_int32 * MAX_HEADS), ("outputs", ctypes.c_int32 * MAX_HEADS)]
 
 
 class HeadParams(ctypes.Structure):

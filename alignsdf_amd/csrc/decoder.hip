@@ -11,7 +11,6 @@
 #include "common.h"
 #include "pack.h"
 #include "sdf_mlp_kernel.h"
-#include "sdf_mlp_kernel_v2.h"
 
 namespace asdf {
 
@@ -122,9 +121,17 @@ struct asdf_decoder {
   bool sample_bound;
 };
 
+// SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
+static bool spec_supported(const asdf_decoder_spec_t* s) {
+  if (s->latent_size != kLatent || s->hidden != kHidden) return false;
+  if (s->num_heads == 2) return s->outputs[0] == 1 && s->outputs[1] == 1;
+  if (s->num_heads == 1) return s->outputs[0] == 2;
+  return false;
+}
+
 extern "C" {
 
-int asdf_version(void) { return 100; }
+int asdf_version(void) { return 101; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -163,8 +170,8 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
 int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, asdf_decoder_t** out) {
   if (!spec || !heads || !out) return ASDF_EINVAL;
   *out = nullptr;
-  if (spec->latent_size != kLatent || spec->hidden != kHidden || spec->num_heads != kHeads) return ASDF_EINVAL;
-  for (int h = 0; h < kHeads; ++h) {
+  if (!spec_supported(spec)) return ASDF_EINVAL;
+  for (int h = 0; h < spec->num_heads; ++h) {
     if (spec->point_feats[h] < 1 || spec->point_feats[h] > ASDF_MAX_POINT_FEATS) return ASDF_EINVAL;
     if (kHidden - kLatent - spec->point_feats[h] < 1) return ASDF_EINVAL;
     for (int l = 0; l < 5; ++l)
@@ -185,7 +192,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
 
   HostPack hp;
   if (!pack_decoder(*spec, heads, hp)) { delete d; return ASDF_ENOMEM; }
-  for (int h = 0; h < kHeads; ++h) d->n1[h] = kHidden - kLatent - spec->point_feats[h];
+  for (int h = 0; h < spec->num_heads; ++h) d->n1[h] = kHidden - kLatent - spec->point_feats[h];
   std::vector<float>&stream = hp.stream, &wlat = hp.wlat, &wpt = hp.wpt, &b02 = hp.b02, &cst = hp.cst, &emb = hp.emb;
 
   hipError_t e = hipSuccess;
@@ -198,7 +205,8 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sdf_mlp_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    e = hipFuncSetAttribute((const void*)sdf_mlp_combined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
     asdf_decoder_destroy(d);
@@ -221,8 +229,7 @@ int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int3
 
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed) {
-  if (!spec || !heads) return ASDF_EINVAL;
-  if (spec->latent_size != kLatent || spec->hidden != kHidden || spec->num_heads != kHeads) return ASDF_EINVAL;
+  if (!spec || !heads || !spec_supported(spec)) return ASDF_EINVAL;
   HostPack hp;
   if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
   auto cp = [](float* dst, const std::vector<float>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(float)); };
@@ -239,8 +246,8 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
   }
   FoldParams fp;
   fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
-  for (int h = 0; h < kHeads; ++h) fp.pf[h] = d->spec.point_feats[h];
-  hipLaunchKernelGGL(fold_sample_kernel, dim3(kHeads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+  for (int h = 0; h < kHeads; ++h) fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0;
+  hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
   return ASDF_OK;
@@ -250,7 +257,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (!d->sample_bound) return ASDF_EINVAL;
   p.stream = d->stream;
   p.cst = d->cst;
-  p.heads_mask = 3;
+  p.num_mlps = d->spec.num_heads;
   if (p.bbox) {
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
     ASDF_HIP(hipGetLastError());
@@ -258,12 +265,10 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
-  // schedule variant: 2 = mid-stage barrier + deferred epilogues (default), 1 = barrier per stage start
-  const char* var = std::getenv("ASDF_K1_VARIANT");
-  if (var && var[0] == '1')
+  if (p.num_mlps == 2)
     hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
   else
-    hipLaunchKernelGGL(sdf_mlp_kernel_v2, dim3(grid), dim3(256), kLdsBytes, st, p);
+    hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }

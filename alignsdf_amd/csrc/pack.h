@@ -27,7 +27,7 @@ inline bool pack_decoder(const asdf_decoder_spec_t& spec, const asdf_head_params
   } catch (...) {
     return false;
   }
-  for (int h = 0; h < kHeads; ++h) {
+  for (int h = 0; h < spec.num_heads; ++h) {
     const int pf = spec.point_feats[h];
     const int in = kLatent + pf;
     const int n1 = kHidden - in;       // layer-1 width: dims[1] - dims[0] (networks/model.py:244-245)
@@ -72,8 +72,10 @@ inline bool pack_decoder(const asdf_decoder_spec_t& spec, const asdf_head_params
           if (t < kTilesL1) c[kCstB1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] : 0.0f;
           c[kCstB3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row];
           c[kCstW4 + (t * 2 + hh) * 16 + r] = W4[row];
+          c[kCstW4b + (t * 2 + hh) * 16 + r] = spec.outputs[h] > 1 ? W4[kHidden + row] : 0.0f;
         }
     c[kCstB4] = heads[h].b[4][0];
+    c[kCstB4 + 1] = spec.outputs[h] > 1 ? heads[h].b[4][1] : 0.0f;
     // default embedding: identity on xyz (PointFeatSize 3)
     for (int f = 0; f < 3 && f < pf; ++f) hp.emb[((size_t)h * ASDF_MAX_POINT_FEATS + f) * 4 + f] = 1.0f;
   }

@@ -10,7 +10,7 @@
 //   h1 = relu(W1 [256x512] . h0               + b1)      K = 512   (rows >= n1 are zero)
 //   h2 = relu(W2a[512x256] . h1 + A2[512x4].p + c2)      K = 256+4 (per-sample A2, c2)
 //   h3 = relu(W3 [512x512] . h2               + b3)      K = 512
-//   s  = tanh(w4 . h3 + b4)
+//   s  = tanh(w4 . h3 + b4)                               (CombinedDecoder: two rows w4, two outputs)
 //
 // Everything is laid out for v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand
 // (M = output features) and the POINTS as the B operand (N = 32 points per wave):
@@ -54,8 +54,9 @@ constexpr int kCstB1 = kCstC0 + kHidden;                    // 256
 constexpr int kCstC2 = kCstB1 + kTilesL1 * 32;              // 512
 constexpr int kCstB3 = kCstC2 + kHidden;                    // 512
 constexpr int kCstW4 = kCstB3 + kHidden;                    // 512
-constexpr int kCstB4 = kCstW4 + kHidden;                    // 1 (+3 pad)
-constexpr int kCstFloats = kCstB4 + 4;                      // 6404 floats = 25 616 B
+constexpr int kCstW4b = kCstW4 + kHidden;                   // 512: second output row (CombinedDecoder), zero otherwise
+constexpr int kCstB4 = kCstW4b + kHidden;                   // 2 (+2 pad): b4 of output 0 and output 1
+constexpr int kCstFloats = kCstB4 + 4;                      // 6916 floats = 27 664 B
 
 // feature row held by (register r, lane half h) of a 32x32 D tile
 __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -1,0 +1,102 @@
+// K1 (shared declarations): fused 5-layer SDF decoder over a dense grid (or an explicit point list), gfx950 only.
+//
+// Replaces, per chunk of the reference hot loop (utils/mesh.py:46-63,98-115):
+//   grid-coordinate construction (utils/mesh.py:27-44,82-96),
+//   latent expand + cat (utils/utils.py:568-569),
+//   SeparateDecoder.forward - 10 GEMMs, ReLU, tanh (networks/model.py:285-350),
+//   the negative-voxel bounding box of get_higher_res_cube (utils/mesh.py:208-237).
+//
+// Structure (see sdf_layout.h for the operand maps):
+//   * one 256-thread workgroup per CU, one wave per SIMD, up to 512 VGPR+AGPR per lane;
+//   * every wave owns 32 query points for BOTH heads and ALL layers: the 512-wide activation
+//     of a layer lives in 256 registers per lane and is consumed in place as the MFMA B operand
+//     of the next layer (no LDS / HBM round trip for activations);
+//   * the weights are the MFMA A operand.  They are pre-packed on the host into a linear stream
+//     of 16 KiB stages and flow HBM/L2 -> LDS through a 4-slot ring filled by LDS-DMA
+//     (global_load_lds_dwordx4), shared by the 4 waves; one s_barrier per stage;
+//   * bias / ReLU / final dot-product + tanh are fused epilogues on the accumulator registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sdf_layout.h"
+
+namespace asdf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRing = 4;
+constexpr int kLdsRingFloats = kRing * kStageFloats;                 // 64 KiB
+constexpr int kLdsFloats = kLdsRingFloats + kHeads * kCstFloats;     // + 51 232 B
+constexpr int kLdsBytes = kLdsFloats * 4;
+
+enum GridMode : int {
+  kGridReference = 0,   // true-division ("sheared") indices of utils/mesh.py:33-34
+  kGridInteger = 1,     // integer floor-division indices (what the code presumably intended)
+  kPointList = 2,       // explicit xyz list
+};
+
+struct DecodeParams {
+  const float* stream;      // [kStagesAll][kStageFloats] packed static weights
+  const float* cst;         // [kHeads][kCstFloats] per-sample constants
+  float* sdf0;              // [P] hand SDF (may be null)
+  float* sdf1;              // [P] object SDF (may be null)
+  const float* xyz;         // [P][3] when mode == kPointList
+  int* bbox;                // [kHeads][8]: min0,min1,min2,max0,max1,max2,count,pad (or null)
+  long long P;              // number of query points
+  int N;                    // grid resolution (P == N^3 for grid modes)
+  int mode;
+  float vs;                 // voxel size (fp32, as the reference rounds it)
+  float o0, o1, o2;         // origin added to axis-0/1/2 coordinates
+  int num_mlps;             // 2 = SeparateDecoder (one output each), 1 = CombinedDecoder (two outputs)
+};
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// Reference grid coordinates, bit-for-bit (utils/mesh.py:32-40): fp32 true division, fp32 fmod,
+// then separately rounded multiply and add (no FMA contraction).
+__device__ __forceinline__ void grid_point(long long i, int N, int mode, float vs, float o0, float o1, float o2,
+                                           float& c0, float& c1, float& c2) {
+  float i0, i1, i2;
+  if (mode == kGridReference) {
+    const float Nf = (float)N;
+    const float fi = (float)i;                      // int64 -> fp32 (RNE), as torch does
+    const float q1 = __fdiv_rn(fi, Nf);             // overall_index / N
+    i2 = (float)(i % N);
+    i1 = fmodf(q1, Nf);
+    i0 = fmodf(__fdiv_rn(q1, Nf), Nf);
+  } else {
+    i2 = (float)(i % N);
+    i1 = (float)((i / N) % N);
+    i0 = (float)((i / N) / N);
+  }
+  c0 = __fadd_rn(__fmul_rn(i0, vs), o0);
+  c1 = __fadd_rn(__fmul_rn(i1, vs), o1);
+  c2 = __fadd_rn(__fmul_rn(i2, vs), o2);
+}
+
+#define ASDF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 load_bias16(const float* lds_bias) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(lds_bias);
+  f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+  f32x16 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3];
+  v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
+  return v;
+}
+
+}  // namespace asdf

@@ -1,141 +1,76 @@
-// K1: fused 5-layer SDF decoder over a dense grid (or an explicit point list), gfx950 only.
-//
-// Replaces, per chunk of the reference hot loop (utils/mesh.py:46-63,98-115):
-//   grid-coordinate construction (utils/mesh.py:27-44,82-96),
-//   latent expand + cat (utils/utils.py:568-569),
-//   SeparateDecoder.forward - 10 GEMMs, ReLU, tanh (networks/model.py:285-350),
-//   the negative-voxel bounding box of get_higher_res_cube (utils/mesh.py:208-237).
-//
-// Structure (see sdf_layout.h for the operand maps):
-//   * one 256-thread workgroup per CU, one wave per SIMD, up to 512 VGPR+AGPR per lane;
-//   * every wave owns 32 query points for BOTH heads and ALL layers: the 512-wide activation
-//     of a layer lives in 256 registers per lane and is consumed in place as the MFMA B operand
-//     of the next layer (no LDS / HBM round trip for activations);
-//   * the weights are the MFMA A operand.  They are pre-packed on the host into a linear stream
-//     of 16 KiB stages and flow HBM/L2 -> LDS through a 4-slot ring filled by LDS-DMA
-//     (global_load_lds_dwordx4), shared by the 4 waves; one s_barrier per stage;
-//   * bias / ReLU / final dot-product + tanh are fused epilogues on the accumulator registers.
+// K1: the fused SDF decoder kernel (operand maps and structure: sdf_mlp_common.h / sdf_layout.h).
+// Schedule (second generation - profiles/r01_k1_tuning_log.txt has the measurements against the first):
+//   * the per-stage barrier sits in the MIDDLE of a stage (in the shadow of an in-flight MFMA) and certifies
+//     the NEXT stage, so the A-fragment prefetch runs across stage boundaries and never drains;
+//   * the ReLU / dot-product epilogue of output tile t is deferred into the MFMA stream of tile t+1;
+//   * ReLU is an integer max on the float bits (one VALU op, no canonicalisation).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "sdf_layout.h"
+#include "sdf_mlp_common.h"
 
 namespace asdf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kRing = 4;
-constexpr int kLdsRingFloats = kRing * kStageFloats;                 // 64 KiB
-constexpr int kLdsFloats = kLdsRingFloats + kHeads * kCstFloats;     // + 51 232 B
-constexpr int kLdsBytes = kLdsFloats * 4;
-
-enum GridMode : int {
-  kGridReference = 0,   // true-division ("sheared") indices of utils/mesh.py:33-34
-  kGridInteger = 1,     // integer floor-division indices (what the code presumably intended)
-  kPointList = 2,       // explicit xyz list
-};
-
-struct DecodeParams {
-  const float* stream;      // [kStagesAll][kStageFloats] packed static weights
-  const float* cst;         // [kHeads][kCstFloats] per-sample constants
-  float* sdf0;              // [P] hand SDF (may be null)
-  float* sdf1;              // [P] object SDF (may be null)
-  const float* xyz;         // [P][3] when mode == kPointList
-  int* bbox;                // [kHeads][8]: min0,min1,min2,max0,max1,max2,count,pad (or null)
-  long long P;              // number of query points
-  int N;                    // grid resolution (P == N^3 for grid modes)
-  int mode;
-  float vs;                 // voxel size (fp32, as the reference rounds it)
-  float o0, o1, o2;         // origin added to axis-0/1/2 coordinates
-  int heads_mask;           // bit h set -> evaluate head h
-};
-
-__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-
-// Reference grid coordinates, bit-for-bit (utils/mesh.py:32-40): fp32 true division, fp32 fmod,
-// then separately rounded multiply and add (no FMA contraction).
-__device__ __forceinline__ void grid_point(long long i, int N, int mode, float vs, float o0, float o1, float o2,
-                                           float& c0, float& c1, float& c2) {
-  float i0, i1, i2;
-  if (mode == kGridReference) {
-    const float Nf = (float)N;
-    const float fi = (float)i;                      // int64 -> fp32 (RNE), as torch does
-    const float q1 = __fdiv_rn(fi, Nf);             // overall_index / N
-    i2 = (float)(i % N);
-    i1 = fmodf(q1, Nf);
-    i0 = fmodf(__fdiv_rn(q1, Nf), Nf);
-  } else {
-    i2 = (float)(i % N);
-    i1 = (float)((i / N) % N);
-    i0 = (float)((i / N) / N);
-  }
-  c0 = __fadd_rn(__fmul_rn(i0, vs), o0);
-  c1 = __fadd_rn(__fmul_rn(i1, vs), o1);
-  c2 = __fadd_rn(__fmul_rn(i2, vs), o2);
-}
-
-#define ASDF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ f32x16 load_bias16(const float* lds_bias) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(lds_bias);
-  f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
-  f32x16 v;
-  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-  v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3];
-  v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
-  return v;
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+__device__ __forceinline__ f32x16 relu16i(f32x16 v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+  for (int r = 0; r < 16; ++r) v[r] = __int_as_float(max(__float_as_int(v[r]), 0));
   return v;
 }
 
-// One weight-stream stage: wait for it, hand the slot of the previous stage back to the DMA
-// engine, then run its 64 K-steps on `acc`.  KT = number of input tiles (registers = 16 KT),
-// Q = stage number within the output tile (K-steps 64 Q .. 64 Q + 63).
-template <int KT, int Q, int SLOT>
-__device__ __forceinline__ void stage(f32x16& acc, const f32x16 (&hin)[KT], const float* ring,
-                                      const float* next_src, unsigned lds_ring_base, int lane, int wave) {
-  // my 4 pieces of this stage were issued 3 stages ago: at most 8 younger loads may stay in flight
-  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1) == (this + 3)
+// sum of the two accumulator chains of a tile (DUAL = 1) or just the single chain
+template <int DUAL>
+__device__ __forceinline__ f32x16 chains(const f32x16& a, const f32x16& b) { return DUAL ? a + b : a; }
+
+struct NoEpilogue {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// One 64-K-step stage of the weight stream.  On entry (a0, a1) hold the A fragments of groups 0 and 1 of THIS
+// stage; on exit they hold those of the next stage in stream order.  `epi` (the previous tile's epilogue) is
+// issued behind the first eight MFMAs.
+// ABL is an ablation mask for tools/k1_ablate.hip (0 in the product): 1 = no DMA / vmcnt wait / barrier,
+// 2 = no LDS reads of A fragments, 4 = no tile epilogues, 8 = no layer 0.
+template <int KT, int Q, int SLOT, int ABL, int DUAL, class Epi>
+__device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&hin)[KT], const float* ring, const float* next_src,
+                                       unsigned lds_ring_base, int lane, int wave, f32x4& a0, f32x4& a1, Epi&& epi) {
+  constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
   const float* src = next_src + wave * 1024 + lane * 4;
   const unsigned dst = lds_ring_base + (nslot * kStageFloats + wave * 1024) * 4;
-  const f32x4* a4 = reinterpret_cast<const f32x4*>(ring + SLOT * kStageFloats) + lane;
-  // A fragments are read two groups (8 K-steps) ahead of their MFMAs
+  const f32x4* cur = reinterpret_cast<const f32x4*>(ring + SLOT * kStageFloats) + lane;
+  const f32x4* nxt = reinterpret_cast<const f32x4*>(ring + ((SLOT + 1) % kRing) * kStageFloats) + lane;
   f32x4 abuf[18];
-  abuf[0] = a4[0];
-  abuf[1] = a4[64];
+  abuf[0] = a0;
+  abuf[1] = a1;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    if (g + 2 < 16) abuf[g + 2] = a4[(g + 2) * 64];
+    if (g == 8 && !(ABL & 1)) {
+      // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (ABL & 2) { abuf[g + 2] = abuf[g]; asm volatile("" : "+v"(abuf[g + 2])); }
+    else abuf[g + 2] = g + 2 < 16 ? cur[(g + 2) * 64] : nxt[(g + 2 - 16) * 64];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int s = Q * 64 + g * 4 + j;
-      acc = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], acc);
-      // the 4 DMA pieces of stage (this + 3) go into the shadow of the first MFMAs
-      if (g == 0) lds_dma16(src + j * 256, dst + j * 1024);
+      // two independent accumulator chains (even / odd K-steps): a dependent 32x32x2 MFMA issues ~5 cycles
+      // later than the 64-cycle pipe interval, an independent one does not
+      if (DUAL && (j & 1)) accb = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], accb);
+      else acc = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], acc);
+      if (g == 8 && !(ABL & 1)) {
+        // one DMA piece per MFMA shadow (an LDS-DMA issue costs about one 64-cycle MFMA slot); pinned so the
+        // scheduler cannot cluster the four pieces behind a single MFMA
+        lds_dma16(src + j * 256, dst + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    if (g == 1 && !(ABL & 4)) epi();
   }
+  a0 = abuf[16];
+  a1 = abuf[17];
 }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
+// MLPS = 2: SeparateDecoder (two MLPs, one output each); MLPS = 1: CombinedDecoder (one MLP, two outputs).
+template <int ABL, int DUAL, int MLPS>
+__device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
   float* cst = smem + kLdsRingFloats;
@@ -149,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
   if ((long long)blockIdx.x >= ntiles) return;
 
   // per-sample constants -> LDS (once per workgroup)
-  for (int i = tid; i < kHeads * kCstFloats / 4; i += 256)
+  for (int i = tid; i < MLPS * kCstFloats / 4; i += 256)
     reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
   __syncthreads();
 
@@ -163,6 +98,10 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
   }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0
+  __builtin_amdgcn_s_barrier();                         // everybody's pieces of stage 0
+  f32x4 a0 = (reinterpret_cast<const f32x4*>(ring) + lane)[0];
+  f32x4 a1 = (reinterpret_cast<const f32x4*>(ring) + lane)[64];
 
   int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1;
   int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1;
@@ -182,11 +121,11 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
     const float bx1 = half ? 0.0f : x2;
 
 #pragma unroll 1
-    for (int head = 0; head < kHeads; ++head) {
+    for (int head = 0; head < MLPS; ++head) {
       const float* hc = cst + head * kCstFloats;
-      // source of stage (s + 3) relative to this head's first stage, wrapping to the other head
+      // source of stage (s + 3) relative to this MLP's first stage, wrapping to the next MLP in stream order
       const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
-      const float* swrap = p.stream + (size_t)(1 - head) * kStagesHead * kStageFloats;
+      const float* swrap = p.stream + (size_t)(head + 1 == MLPS ? 0 : head + 1) * kStagesHead * kStageFloats;
       auto src_of = [&](int s) -> const float* {   // s = stage index within head + 3
         return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
       };
@@ -196,68 +135,110 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16 acc = load_bias16(hc + kCstC0 + (t * 2 + half) * 16);
-        acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 0) * 64 + lane], bx0, acc);
-        acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 1) * 64 + lane], bx1, acc);
-        h0[t] = relu16(acc);
+        if (!(ABL & 8)) {
+          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 0) * 64 + lane], bx0, acc);
+          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        }
+        h0[t] = (ABL & 8) ? acc : relu16i(acc);
       }
 
-      // ---- layer 1: 512 -> 256 (rows >= n1 are zero padding)
+#define ASDF_STAGE(KT, Q, SLOT, ACC, HIN, SIDX, EPI) \
+  stage<KT, Q, SLOT, ABL, DUAL>(ACC, ACC##b, HIN, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, a0, a1, EPI)
+
+      // ---- layer 1: 512 -> 256 (rows >= n1 are zero padding); epilogue of tile t-1 rides in tile t
       f32x16 h1[kTilesL1];
+      f32x16 acc1[2], acc1b[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < kTilesL1; ++t) {
-        f32x16 acc = load_bias16(hc + kCstB1 + (t * 2 + half) * 16);
-        constexpr int S0 = 0;
-        stage<16, 0, 0>(acc, h0, ring, src_of(S0 + t * 4 + 0 + 3), lds_ring_base, lane, wave);
-        stage<16, 1, 1>(acc, h0, ring, src_of(S0 + t * 4 + 1 + 3), lds_ring_base, lane, wave);
-        stage<16, 2, 2>(acc, h0, ring, src_of(S0 + t * 4 + 2 + 3), lds_ring_base, lane, wave);
-        stage<16, 3, 3>(acc, h0, ring, src_of(S0 + t * 4 + 3 + 3), lds_ring_base, lane, wave);
-        h1[t] = relu16(acc);
+        f32x16& acc = acc1[t & 1];
+        f32x16& accb = acc1b[t & 1];
+        acc = load_bias16(hc + kCstB1 + (t * 2 + half) * 16);
+        accb = zero16;
+        auto epi = [&]() { if (t > 0) h1[t - 1] = relu16i(chains<DUAL>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1])); };
+        ASDF_STAGE(16, 0, 0, acc, h0, t * 4 + 0, epi);
+        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, NoEpilogue());
+        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, NoEpilogue());
+        ASDF_STAGE(16, 3, 3, acc, h0, t * 4 + 3, NoEpilogue());
       }
 
       // ---- layer 2: [h1 (256) | xyz (4)] -> 512
       f32x16 h2[kTilesHidden];
+      f32x16 acc2[2], acc2b[2];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
-        f32x16 acc = load_bias16(hc + kCstC2 + (t * 2 + half) * 16);
+        f32x16& acc = acc2[t & 1];
+        f32x16& accb = acc2b[t & 1];
+        acc = load_bias16(hc + kCstC2 + (t * 2 + half) * 16);
         acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 0) * 64 + lane], bx0, acc);
-        acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        if (DUAL) accb = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, zero16);
+        else acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        auto epi = [&]() {
+          if (t > 0) h2[t - 1] = relu16i(chains<DUAL>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1]));
+          else h1[kTilesL1 - 1] = relu16i(chains<DUAL>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1]));   // consumed by K-steps >= 112
+        };
         constexpr int S0 = kStagesL1;
         if (t & 1) {
-          stage<8, 0, 2>(acc, h1, ring, src_of(S0 + t * 2 + 0 + 3), lds_ring_base, lane, wave);
-          stage<8, 1, 3>(acc, h1, ring, src_of(S0 + t * 2 + 1 + 3), lds_ring_base, lane, wave);
+          ASDF_STAGE(8, 0, 2, acc, h1, S0 + t * 2 + 0, epi);
+          ASDF_STAGE(8, 1, 3, acc, h1, S0 + t * 2 + 1, NoEpilogue());
         } else {
-          stage<8, 0, 0>(acc, h1, ring, src_of(S0 + t * 2 + 0 + 3), lds_ring_base, lane, wave);
-          stage<8, 1, 1>(acc, h1, ring, src_of(S0 + t * 2 + 1 + 3), lds_ring_base, lane, wave);
+          ASDF_STAGE(8, 0, 0, acc, h1, S0 + t * 2 + 0, epi);
+          ASDF_STAGE(8, 1, 1, acc, h1, S0 + t * 2 + 1, NoEpilogue());
         }
-        h2[t] = relu16(acc);
       }
 
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4) and tanh
-      float part = 0.0f;
-#pragma unroll
-      for (int t = 0; t < kTilesHidden; ++t) {
-        f32x16 acc = load_bias16(hc + kCstB3 + (t * 2 + half) * 16);
-        constexpr int S0 = kStagesL1 + kStagesL2;
-        stage<16, 0, 0>(acc, h2, ring, src_of(S0 + t * 4 + 0 + 3), lds_ring_base, lane, wave);
-        stage<16, 1, 1>(acc, h2, ring, src_of(S0 + t * 4 + 1 + 3), lds_ring_base, lane, wave);
-        stage<16, 2, 2>(acc, h2, ring, src_of(S0 + t * 4 + 2 + 3), lds_ring_base, lane, wave);
-        stage<16, 3, 3>(acc, h2, ring, src_of(S0 + t * 4 + 3 + 3), lds_ring_base, lane, wave);
+      float part = 0.0f, partb = 0.0f;      // partb: second output row (CombinedDecoder; its weights are 0 otherwise)
+      f32x16 acc3[2], acc3b[2];
+      auto dot_w4 = [&](const f32x16 a, int t) {
         const f32x16 w = load_bias16(hc + kCstW4 + (t * 2 + half) * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part = fmaf(fmaxf(acc[r], 0.0f), w[r], part);
+        for (int r = 0; r < 16; ++r) part = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), w[r], part);
+        if (MLPS == 1) {
+          const f32x16 wb = load_bias16(hc + kCstW4b + (t * 2 + half) * 16);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) partb = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), wb[r], partb);
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16& acc = acc3[t & 1];
+        f32x16& accb = acc3b[t & 1];
+        acc = load_bias16(hc + kCstB3 + (t * 2 + half) * 16);
+        accb = zero16;
+        auto epi = [&]() {
+          if (t > 0) dot_w4(chains<DUAL>(acc3[(t - 1) & 1], acc3b[(t - 1) & 1]), t - 1);
+          else h2[kTilesHidden - 1] = relu16i(chains<DUAL>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1]));   // consumed by K-steps >= 240
+        };
+        constexpr int S0 = kStagesL1 + kStagesL2;
+        ASDF_STAGE(16, 0, 0, acc, h2, S0 + t * 4 + 0, epi);
+        ASDF_STAGE(16, 1, 1, acc, h2, S0 + t * 4 + 1, NoEpilogue());
+        ASDF_STAGE(16, 2, 2, acc, h2, S0 + t * 4 + 2, NoEpilogue());
+        ASDF_STAGE(16, 3, 3, acc, h2, S0 + t * 4 + 3, NoEpilogue());
       }
+      dot_w4(chains<DUAL>(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1]), kTilesHidden - 1);
+#undef ASDF_STAGE
       part += __shfl_xor(part, 32);
       const float sdf = tanhf(part + hc[kCstB4]);
-
-      float* out = head == 0 ? p.sdf0 : p.sdf1;
-      if (valid && half == 0 && out) out[pi] = sdf;
-
-      if (p.bbox && valid && half == 0 && sdf < 0.0f && p.mode != kPointList) {
+      float sdfb = 1.0f;
+      if (MLPS == 1) {
+        partb += __shfl_xor(partb, 32);
+        sdfb = tanhf(partb + hc[kCstB4 + 1]);
+      }
+      // output 0 of MLP 0 is the hand SDF; the object SDF is output 0 of MLP 1 or output 1 of a combined MLP
+      const bool is_hand = head == 0;
+      if (valid && half == 0) {
+        float* out = is_hand ? p.sdf0 : p.sdf1;
+        if (out) out[pi] = sdf;
+        if (MLPS == 1 && p.sdf1) p.sdf1[pi] = sdfb;
+      }
+      if (p.bbox && valid && half == 0 && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
-        if (head == 0) {
+        if (is_hand && sdf < 0.0f) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
           bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
-        } else {
+        }
+        if ((!is_hand && sdf < 0.0f) || (MLPS == 1 && sdfb < 0.0f)) {
           omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
           omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
         }
@@ -279,5 +260,8 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) {
     }
   }
 }
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1>(p); }
 
 }  // namespace asdf

@@ -34,7 +34,7 @@ def head_point_feats(point_feat_size, encode_style):
     }[encode_style]
 
 
-def kinematic_affine(point_feat_size, encode_style, scale_factor, mano_results, obj_results):
+def kinematic_affine(point_feat_size, encode_style, scale_factor, mano_results, obj_results, combined=False):
     """Affine form of utils.utils.kinematic_embedding (utils/utils.py:376-430): returns, per head,
     E [pf_head, 4] with  feat = E[:, :3] @ xyz + E[:, 3].  Computed in float64 from the same inputs.
 
@@ -67,6 +67,12 @@ def kinematic_affine(point_feat_size, encode_style, scale_factor, mano_results, 
         off = Ti[:3, 3] / w
         rows_obj_tail.append(np.concatenate([lin * sf / 2.0, (off * sf / 2.0)[:, None]], 1))
     ident = np.concatenate([np.eye(3), np.zeros((3, 1))], 1)
+    if combined:      # CombinedDecoder consumes the whole embedding (networks/model.py:150-157)
+        if encode_style == "hand":
+            return (np.concatenate(rows_hand, 0),)
+        if encode_style == "obj":
+            return (np.concatenate([ident] + rows_obj_tail, 0),)
+        return (np.concatenate(rows_hand + rows_obj_tail, 0),)
     if encode_style == "hand":
         return np.concatenate(rows_hand, 0), rows_hand[0]            # obj head sees input[:, :L+3] = mano_xyz*sf/2
     if encode_style == "obj":
@@ -87,11 +93,16 @@ class HipSdfDecoder:
             encode_style = encode_style if encode_style is not None else m.encode_style
             if getattr(m, "use_classifier", False):
                 raise NotImplementedError("classifier head is not part of the HIP path yet")
+            if getattr(m, "use_tanh", False) or getattr(m, "xyz_in_all", False):
+                raise NotImplementedError("use_tanh / xyz_in_all decoder variants are outside the HIP path")
         else:
             sd = {k: torch.as_tensor(v) for k, v in module_or_state_dict.items()}
         sd = {k[len("module.decoder."):] if k.startswith("module.decoder.") else k: v for k, v in sd.items()}
-        if "linh0.bias" not in sd or "lino4.bias" not in sd:
-            raise NotImplementedError("HIP path supports SeparateDecoder-shaped modules (linh*/lino* parameters)")
+        self.combined = "lin0.bias" in sd and "lin4.bias" in sd
+        if not self.combined and ("linh0.bias" not in sd or "lino4.bias" not in sd):
+            raise NotImplementedError("HIP path supports SeparateDecoder (linh*/lino*) and CombinedDecoder (lin*) modules")
+        if any(k.startswith(("bn", "classifier_head")) for k in sd):
+            raise NotImplementedError("LayerNorm / classifier variants are outside the HIP path")
         self.latent_size = int(latent_size)
         self.point_feat_size = int(point_feat_size)
         self.encode_style = encode_style
@@ -99,15 +110,19 @@ class HipSdfDecoder:
         L = _native.lib()
         if L.asdf_device_count() < 1:
             raise _native.NativeError(-4, "no gfx950 (MI355X) device visible - the HIP path has no CPU fallback")
-        pf = head_point_feats(self.point_feat_size, encode_style)
-        spec = _native.DecoderSpec(self.latent_size, 512, 2, (ctypes.c_int32 * 2)(*pf))
+        if self.combined:
+            pf, prefixes, n_out = (self.point_feat_size,), ("lin",), 2
+            spec = _native.DecoderSpec(self.latent_size, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0))
+        else:
+            pf, prefixes, n_out = head_point_feats(self.point_feat_size, encode_style), ("linh", "lino"), 1
+            spec = _native.DecoderSpec(self.latent_size, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1))
         heads = (_native.HeadParams * 2)()
         keep = []
-        for hi, head in enumerate("ho"):
+        for hi, prefix in enumerate(prefixes):
             n_in = self.latent_size + pf[hi]
-            shapes = [(512, n_in), (512 - n_in, 512), (512, 512), (512, 512), (1, 512)]
+            shapes = [(512, n_in), (512 - n_in, 512), (512, 512), (512, 512), (n_out, 512)]
             for layer in range(5):
-                name = "lin%s%d" % (head, layer)
+                name = "%s%d" % (prefix, layer)
                 w = _effective(sd, name)
                 b = sd[name + ".bias"].detach().float().cpu().contiguous()
                 if tuple(w.shape) != shapes[layer] or b.numel() != shapes[layer][0]:
@@ -146,14 +161,14 @@ class HipSdfDecoder:
         emb_ptr = None
         if embed is not None:
             buf = np.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=np.float32)
-            for h in range(2):
+            for h in range(len(self._pf)):
                 e = np.asarray(embed[h], dtype=np.float64)
                 if e.shape != (self._pf[h], 4):
                     raise ValueError("embedding of head %d has shape %s, expected %s" % (h, e.shape, (self._pf[h], 4)))
                 buf[h, :self._pf[h]] = e.astype(np.float32)
             emb_ptr = buf.ctypes.data_as(ctypes.c_void_p)
             self._emb_keep = buf
-        elif self._pf != (3, 3):
+        elif any(f != 3 for f in self._pf):
             raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
         self._latent = lat   # keep the device buffer alive until the next set_sample
         with torch.cuda.device(self.device):

@@ -76,19 +76,55 @@ class SeparateDecoder(nn.Module):
         return self._head("linh", xh)[:, 0:1], self._head("lino", xo)[:, 0:1], torch.zeros(1, device=inputs.device)
 
 
+class CombinedDecoder(nn.Module):
+    """One MLP over [latent | point features] with a two-row last layer: column 0 = hand SDF, column 1 = object
+    SDF (networks/model.py:79-188; state-dict keys `lin{0..4}.*`)."""
+
+    def __init__(self, latent_size, point_feat_size, encode_style, dims, num_class=6, dropout=None, dropout_prob=0.0,
+                 norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
+                 use_classifier=False):
+        super().__init__()
+        if use_classifier or xyz_in_all or use_tanh:
+            raise NotImplementedError("classifier / xyz_in_all / use_tanh variants are outside the accelerated hot path")
+        if not weight_norm and norm_layers:
+            raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
+        self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
+        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
+        self.dropout, self.dropout_prob = dropout, dropout_prob
+        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = False, False, xyz_in_all, latent_dropout
+        sizes = [latent_size + point_feat_size] + list(dims) + [2]
+        self.num_layers = len(sizes)
+        for layer in range(len(sizes) - 1):
+            n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
+            setattr(self, "lin" + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+
+    def forward(self, inputs):
+        x = inputs
+        for layer in range(self.num_layers - 1):
+            if layer in self.latent_in:
+                x = torch.cat([x, inputs], 1)
+            x = getattr(self, "lin" + str(layer))(x)
+            if layer < self.num_layers - 2:
+                x = torch.relu(x)
+        x = torch.tanh(x)
+        return x[:, 0:1], x[:, 1:2], torch.zeros(1, device=inputs.device)
+
+
 def build_decoder(specs, state_dict=None):
-    """SeparateDecoder from a specs.json dict (networks/model_utils.py:14-31 for ModelType 1encoder2decoder)."""
-    if specs.get("ModelType", "1encoder2decoder") != "1encoder2decoder":
-        raise NotImplementedError("only ModelType 1encoder2decoder (SeparateDecoder) is supported")
-    dec = SeparateDecoder(specs["LatentSize"], specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"],
-                          use_classifier=bool(specs.get("ClassifierBranch", False)))
+    """Decoder module from a specs.json dict (networks/model_utils.py:14-31): SeparateDecoder for ModelType
+    1encoder2decoder, CombinedDecoder for 1encoder1decoder."""
+    cls = {"1encoder2decoder": SeparateDecoder, "1encoder1decoder": CombinedDecoder}.get(specs.get("ModelType", "1encoder2decoder"))
+    if cls is None:
+        raise NotImplementedError("unsupported ModelType %r" % specs.get("ModelType"))
+    dec = cls(specs["LatentSize"], specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"],
+              use_classifier=bool(specs.get("ClassifierBranch", False)))
     if state_dict is not None:
         sd = {}
         for k, v in state_dict.items():
             for pre in ("module.decoder.", "decoder."):
                 if k.startswith(pre):
                     k = k[len(pre):]
-            if k.startswith(("linh", "lino")):
+            if k.startswith("lin"):
                 sd[k] = torch.as_tensor(v)
         dec.load_state_dict(sd)
     return dec.eval()

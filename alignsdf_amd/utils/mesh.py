@@ -108,7 +108,7 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     Returns dict(vol_hand, vol_obj device tensors of pass 2, voxel_size 0-dim fp32 tensor, origin list,
     bbox int32[16] of pass 1)."""
     hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results))
+    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, hip.combined))
     mode = GRID_MODES[grid_mode]
     voxel_size = 2.0 / (N - 1)
     _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode)

@@ -25,13 +25,13 @@ def hip_decoder_for(decoder, device=None):
     return per_mod[str(dev)]
 
 
-def sample_embedding(specs, mano_results, obj_results):
+def sample_embedding(specs, mano_results, obj_results, combined=False):
     """Per-head affine embeddings for this sample, or None for plain xyz (utils/mesh.py:49-55)."""
     if specs["PointFeatSize"] <= 3:
         return None
     if mano_results is not None and specs["EncodeStyle"] != "nerf":
         return kinematic_affine(specs["PointFeatSize"], specs["EncodeStyle"], specs["SdfScaleFactor"], mano_results,
-                                obj_results)
+                                obj_results, combined)
     raise NotImplementedError("NeRF positional encoding (PointFeatSize > 3 without pose alignment) is not affine in xyz "
                               "and is not part of the HIP path")
 
@@ -60,6 +60,6 @@ def decode_sdf_multi_output(decoder, latent_vector, queries, mano_results, cam_i
     if queries.shape[1] != 3:
         raise NotImplementedError("pass raw normalised xyz [M,3]; the pose embedding is folded into the HIP decoder")
     hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vector, sample_embedding(specs, mano_results, obj_results))
+    hip.set_sample(latent_vector, sample_embedding(specs, mano_results, obj_results, hip.combined))
     h, o = hip.decode_points(queries)
     return h.unsqueeze(1), o.unsqueeze(1), torch.zeros(1, device=h.device)

@@ -42,8 +42,11 @@ typedef struct asdf_decoder asdf_decoder_t;
 typedef struct asdf_decoder_spec {
   int32_t latent_size;                    /* 256 */
   int32_t hidden;                         /* 512 */
-  int32_t num_heads;                      /* 2: hand, object */
+  int32_t num_heads;                      /* independent MLPs: 2 = SeparateDecoder (hand, object),
+                                             1 = CombinedDecoder (networks/model.py:79-188) */
   int32_t point_feats[ASDF_MAX_HEADS];    /* 3 ("nerf", PointFeatSize 3) or 6 ("both", PointFeatSize 9) ... */
+  int32_t outputs[ASDF_MAX_HEADS];        /* rows of the last layer: 1 (SeparateDecoder) or 2 (CombinedDecoder:
+                                             row 0 = hand, row 1 = object, networks/model.py:99,185-188) */
 } asdf_decoder_spec_t;
 
 /* Host-side effective parameters of one head, row-major [out][in] like nn.Linear.weight:
@@ -51,7 +54,7 @@ typedef struct asdf_decoder_spec {
  *   w[1] [hidden-latent-pf][hidden]  b[1]           lin{h,o}1   (out = dims[1] - dims[0], :244-245)
  *   w[2] [hidden][hidden]      b[2] [hidden]        lin{h,o}2   (input = cat(x1, head_input), :311)
  *   w[3] [hidden][hidden]      b[3] [hidden]        lin{h,o}3
- *   w[4] [1][hidden]           b[4] [1]             lin{h,o}4   (plain Linear, then tanh :324-325) */
+ *   w[4] [outputs][hidden]     b[4] [outputs]       lin{h,o}4   (plain Linear, then tanh :324-325) */
 typedef struct asdf_head_params {
   const float* w[5];
   const float* b[5];
@@ -115,7 +118,7 @@ int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doubl
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
- * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*6404, embed 2*ASDF_MAX_POINT_FEATS*4. */
+ * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*6916, embed 2*ASDF_MAX_POINT_FEATS*4. */
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed);
 

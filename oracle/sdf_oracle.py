@@ -138,15 +138,41 @@ def separate_decoder(hand_params, obj_params, inputs, latent_size, point_feat_si
     return _run_head(hand_params, xh, xh)[:, 0:1], _run_head(obj_params, xo, xo)[:, 0:1]
 
 
+def combined_decoder(params, inputs):
+    """CombinedDecoder.forward (networks/model.py:149-188; no classifier, xyz_in_all False): one MLP whose last
+    layer has two rows - column 0 is the hand SDF, column 1 the object SDF."""
+    x = _run_head(params, inputs, inputs)
+    return x[:, 0:1], x[:, 1:2]
+
+
+def combined_params(state_dict):
+    """[(W, b)] * 5 of a CombinedDecoder state dict (keys `lin{k}.*`)."""
+    out = []
+    for layer in range(5):
+        name = "lin%d" % layer
+        if name + ".weight_v" in state_dict:
+            w = effective_weight(state_dict[name + ".weight_v"], state_dict[name + ".weight_g"])
+        else:
+            w = torch.as_tensor(state_dict[name + ".weight"])
+        out.append((w.float().contiguous(), torch.as_tensor(state_dict[name + ".bias"]).float().contiguous()))
+    return out
+
+
 def decode_sdf_multi_output(hand_params, obj_params, latent, queries, specs):
-    """latent expand + cat + decoder (utils/utils.py:561-572, PixelAlign False)."""
+    """latent expand + cat + decoder (utils/utils.py:561-572, PixelAlign False).  obj_params None => hand_params
+    are those of a CombinedDecoder."""
     inputs = torch.cat([latent.expand(queries.shape[0], -1), queries], 1)
+    if obj_params is None:
+        return combined_decoder(hand_params, inputs)
     return separate_decoder(hand_params, obj_params, inputs, latent.shape[1], specs["PointFeatSize"], specs["EncodeStyle"])
 
 
 def decode_points(state_dict, latent, xyz, specs, mano_results=None, obj_results=None, max_batch=2 ** 18):
     """Chunked decode of explicit points [M,3] -> (hand [M], obj [M]) fp32 tensors."""
-    hp, op = effective_head_params(state_dict, "h"), effective_head_params(state_dict, "o")
+    if "lin0.bias" in state_dict:
+        hp, op = combined_params(state_dict), None
+    else:
+        hp, op = effective_head_params(state_dict, "h"), effective_head_params(state_dict, "o")
     latent = torch.as_tensor(latent).float().reshape(1, -1)
     xyz = torch.as_tensor(xyz).float()
     hand, obj = torch.zeros(xyz.shape[0]), torch.zeros(xyz.shape[0])

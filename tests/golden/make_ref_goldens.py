@@ -86,6 +86,20 @@ def fit_last_layers():
                 print("fit %s head %s: rms %.3e" % (tag, head, rms))
                 out["%s.lin%s4.weight" % (tag, head)] = w[:-1].astype(np.float32).reshape(1, 512)
                 out["%s.lin%s4.bias" % (tag, head)] = w[-1:].astype(np.float32)
+    # CombinedDecoder ("comb3"): one MLP, the two-row last layer fitted to both targets
+    sd = syn.combined_hidden_state_dict(256, 3, 0)
+    latent = torch.from_numpy(syn.latent_code(0))
+    with torch.no_grad():
+        inputs = torch.cat([latent.expand(pts.shape[0], -1), torch.from_numpy(pts)], 1)
+        params = [(orc.effective_weight(sd["lin%d.weight_v" % k], sd["lin%d.weight_g" % k]), torch.from_numpy(sd["lin%d.bias" % k]))
+                  for k in range(4)] + [(torch.zeros(2, 512), torch.zeros(2))]
+        hid = orc._run_head(params, inputs, inputs, stop_before_last=True).double().numpy()
+    X = np.concatenate([hid, np.ones((hid.shape[0], 1))], 1)
+    A = X.T @ X + 1e-3 * np.eye(X.shape[1])
+    W = np.stack([np.linalg.solve(A, X.T @ targets[h]) for h in "ho"])
+    print("fit comb3: rms", [float(np.sqrt(np.mean((X @ W[i] - targets[h]) ** 2))) for i, h in enumerate("ho")])
+    out["comb3.lin4.weight"] = W[:, :-1].astype(np.float32)
+    out["comb3.lin4.bias"] = W[:, -1].astype(np.float32)
     np.savez(os.path.join(HERE, "synth_last_layer.npz"), **out)
 
 
@@ -118,11 +132,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_grid.npz"), **grid)
 
     # ---- full two-pass runs of the reference
-    for tag in ("nerf3", "both9"):
+    for tag in ("nerf3", "both9", "comb3"):
         specs = syn.specs_for(tag)
         sd = syn.full_state_dict(tag)
-        dec = arch.SeparateDecoder(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"],
-                                   use_classifier=False).eval()
+        cls = arch.CombinedDecoder if tag == "comb3" else arch.SeparateDecoder
+        dec = cls(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
         dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         latent = torch.from_numpy(syn.latent_code(0))
         mano, obj = None, None
@@ -188,7 +202,7 @@ def main():
         gold["rand_hand"] = h.squeeze(1).numpy()
         gold["rand_obj"] = o.squeeze(1).numpy()
         # effective weights as the module's hook computes them (row 0 of each layer, for the fold check)
-        for head in "ho":
+        for head in ("",) if tag == "comb3" else "ho":
             for layer in range(4):
                 gold["effw_%s%d_rows" % (head, layer)] = getattr(dec, "lin%s%d" % (head, layer)).weight.detach().numpy()[:4]
         np.savez_compressed(os.path.join(HERE, "ref_decoder_%s.npz" % tag), **gold)

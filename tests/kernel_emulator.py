@@ -14,9 +14,9 @@ import torch
 from alignsdf_amd import _native
 from alignsdf_amd.hip_decoder import _effective, head_point_feats
 
-K_HIDDEN, K_LATENT, K_CST = 512, 256, 6404
+K_HIDDEN, K_LATENT, K_CST = 512, 256, 6916
 STAGE = 4096
-OFF = dict(A0=0, A2=2048, C0=4096, B1=4608, C2=4864, B3=5376, W4=5888, B4=6400)
+OFF = dict(A0=0, A2=2048, C0=4096, B1=4608, C2=4864, B3=5376, W4=5888, W4B=6400, B4=6912)
 LANE = np.arange(64)
 HALF = LANE >> 5
 ROW = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in range(2)] for r in range(16)])   # [r][half]
@@ -26,13 +26,19 @@ def pack_host(sd, point_feat_size, encode_style):
     """Run the C++ packer on a state dict; returns dict of numpy images."""
     L = _native.lib()
     pf = head_point_feats(point_feat_size, encode_style)
-    spec = _native.DecoderSpec(256, 512, 2, (ctypes.c_int32 * 2)(*pf))
+    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    combined = "lin0.bias" in sd
+    if combined:
+        pf, prefixes = (point_feat_size,), ("lin",)
+        spec = _native.DecoderSpec(256, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0))
+    else:
+        prefixes = ("linh", "lino")
+        spec = _native.DecoderSpec(256, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1))
     heads = (_native.HeadParams * 2)()
     keep = []
-    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
-    for hi, head in enumerate("ho"):
+    for hi, prefix in enumerate(prefixes):
         for layer in range(5):
-            name = "lin%s%d" % (head, layer)
+            name = "%s%d" % (prefix, layer)
             w = _effective(sd, name)
             b = sd[name + ".bias"].float().contiguous()
             keep += [w, b]
@@ -47,6 +53,7 @@ def pack_host(sd, point_feat_size, encode_style):
     _native.check(L.asdf_debug_pack_host(ctypes.byref(spec), heads, ptr(out["stream"]), ptr(out["wlat"]), ptr(out["wpt"]),
                                          ptr(out["b02"]), ptr(out["cst"]), ptr(out["emb"])), "asdf_debug_pack_host")
     out["pf"] = pf
+    out["combined"] = combined
     return out
 
 
@@ -59,10 +66,10 @@ def fold(pk, latent, embed=None):
     emb = pk["emb"].reshape(2, _native.MAX_POINT_FEATS, 4).copy()
     if embed is not None:
         emb[:] = 0
-        for h in range(2):
+        for h in range(len(pk["pf"])):
             emb[h, :pk["pf"][h]] = np.asarray(embed[h], np.float32)
     lat = np.asarray(latent, np.float32).reshape(256)
-    for head in range(2):
+    for head in range(len(pk["pf"])):
         for layer in range(2):
             dot = (wlat[head, layer].astype(np.float32) @ lat).astype(np.float32)
             a = (wpt[head, layer, :, :pk["pf"][head]] @ emb[head, :pk["pf"][head]]).astype(np.float32)   # [512,4]
@@ -104,7 +111,7 @@ def run_wave(pk, cst, xyz32):
     bx1 = np.where(HALF == 1, 0.0, x[pt, 2]).astype(np.float32)
     stream = pk["stream"].reshape(256, 16, 64, 4)
     outs = []
-    for head in range(2):
+    for head in range(len(pk["pf"])):
         c = cst[head]
         sbase = head * 128
 
@@ -135,4 +142,12 @@ def run_wave(pk, cst, xyz32):
                 part = (np.maximum(h3[t][r], 0) * w[r] + part).astype(np.float32)
         tot = part + part[LANE ^ 32]
         outs.append(np.tanh(tot + c[OFF["B4"]])[:32].astype(np.float32))
+        if pk["combined"]:
+            partb = np.zeros(64, np.float32)
+            for t in range(16):
+                w = bias16(c, OFF["W4B"], t)
+                for r in range(16):
+                    partb = (np.maximum(h3[t][r], 0) * w[r] + partb).astype(np.float32)
+            totb = partb + partb[LANE ^ 32]
+            outs.append(np.tanh(totb + c[OFF["B4"] + 1])[:32].astype(np.float32))
     return outs[0], outs[1]

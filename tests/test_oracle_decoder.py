@@ -36,17 +36,17 @@ def test_sheared_closed_form():
     assert np.array_equal(idx[:, 1], y + z / N) and np.array_equal(idx[:, 0], x + y / N + z / N ** 2)
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
 def test_effective_weights_match_module_hook(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     sd = syn.full_state_dict(tag)
-    for head in "ho":
-        params = orc.effective_head_params(sd, head)
+    for head in ("",) if tag == "comb3" else "ho":
+        params = orc.combined_params(sd) if tag == "comb3" else orc.effective_head_params(sd, head)
         for layer in range(4):
             assert np.array_equal(params[layer][0].numpy()[:4], g["effw_%s%d_rows" % (head, layer)])
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
 def test_decoder_and_embedding_vs_reference(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     specs, sd, lat, mano, obj = _inputs(tag)
@@ -59,7 +59,7 @@ def test_decoder_and_embedding_vs_reference(tag, golden_dir):
     assert np.abs(o.numpy() - g["rand_obj"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
 def test_two_pass_flow_vs_reference(tag, golden_dir):
     """Full create_mesh_combined_decoder restatement at N=32: volumes, bbox, zoom cube."""
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))

@@ -4,12 +4,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "sdf_mlp_kernel_v2.h"
+#include "sdf_mlp_kernel.h"
 using namespace asdf;
 #ifndef ABL_LIST
 #define ABL_LIST X(0) X(8)
 #endif
-#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { sdf_mlp_body_v2<n, 0>(p); }
+#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { sdf_mlp_body<n, 0, 2>(p); }
 ABL_LIST
 #undef X
 int main(int argc, char** argv) {
@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipMalloc(&cst, c.size() * 4); hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
   hipMalloc(&o0, P * 4); hipMalloc(&o1, P * 4);
   DecodeParams p{}; p.stream = stream; p.cst = cst; p.sdf0 = o0; p.sdf1 = o1; p.P = P; p.N = N; p.mode = kGridReference;
-  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.heads_mask = 3;
+  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double flop = (double)P * 2 * 1057792.0;
 #define X(n) { hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes); \
