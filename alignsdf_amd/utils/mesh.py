@@ -14,6 +14,7 @@ import torch
 
 from .. import _native
 from ..marching_cubes import marching_cubes_device
+from ..mesh_post import keep_largest_component
 from ..ply import write_ply
 from .utils import hip_decoder_for, sample_embedding
 
@@ -84,11 +85,12 @@ def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None)
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
-                               scale=None, eval_mode=False, task="obman"):
-    """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale).
-    MC failures are logged and skipped exactly like the reference (utils/mesh.py:353-358).  The
-    largest-component filter and the eval-mode ICP of utils/mesh.py:371-395 are host post-processing outside
-    the accelerated path; the full extracted surface is written."""
+                               scale=None, eval_mode=False, task="obman", largest_component=True):
+    """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale) with
+    verts / faces the raw marching-cubes output like the reference.  MC failures are logged and skipped exactly
+    like the reference (utils/mesh.py:353-358).  The written file holds the largest watertight component when the
+    surface splits into several (utils/mesh.py:371-381, alignsdf_amd.mesh_post); the eval-mode ICP of
+    utils/mesh.py:385-395 needs ground-truth meshes and is not part of this build."""
     try:
         verts, faces, mesh_points = extract_surface(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, offset, scale)
     except (ValueError, RuntimeError) as e:
@@ -99,7 +101,8 @@ def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_s
         logging.warning("eval_mode ICP alignment (utils/mesh.py:385-395) is not part of this build; writing the unaligned mesh")
     if ply_filename_out:
         os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
-        write_ply(ply_filename_out, mesh_points, faces)
+        out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
+        write_ply(ply_filename_out, out_v, out_f)
     return verts, faces, np.array([0, 0, 0]), np.array([1])
 
 
