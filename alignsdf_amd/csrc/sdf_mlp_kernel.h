@@ -26,8 +26,9 @@ struct NoEpilogue {
 // One 64-K-step stage of the weight stream.  On entry (a0, a1) hold the A fragments of groups 0 and 1 of THIS
 // stage; on exit they hold those of the next stage in stream order.  `epi` (the previous tile's epilogue) is
 // issued behind the first eight MFMAs.
-// ABL is an ablation mask for tools/k1_ablate.hip (0 in the product): 1 = no DMA / vmcnt wait / barrier,
-// 2 = no LDS reads of A fragments, 4 = no tile epilogues, 8 = no layer 0.
+// ABL is an ablation mask for tools/k1_ablate.hip (0 in the product; timing only, results invalid):
+// 1 = no DMA / vmcnt wait / barrier in the loop (ring filled once), 4 = tile epilogues skipped (accumulators kept
+// live), 8 = no layer 0, 16 = no s_barrier (DMA and waits kept).
 template <int KT, int Q, int SLOT, int ABL, int DUAL, class Epi>
 __device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&hin)[KT], const float* ring, const float* next_src,
                                        unsigned lds_ring_base, int lane, int wave, f32x4& a0, f32x4& a1, Epi&& epi) {
@@ -44,10 +45,9 @@ __device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&
     if (g == 8 && !(ABL & 1)) {
       // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     }
-    if (ABL & 2) { abuf[g + 2] = abuf[g]; asm volatile("" : "+v"(abuf[g + 2])); }
-    else abuf[g + 2] = g + 2 < 16 ? cur[(g + 2) * 64] : nxt[(g + 2 - 16) * 64];
+    abuf[g + 2] = g + 2 < 16 ? cur[(g + 2) * 64] : nxt[(g + 2 - 16) * 64];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int s = Q * 64 + g * 4 + j;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (g == 1 && !(ABL & 4)) epi();
+    if (g == 1) epi();
   }
   a0 = abuf[16];
   a1 = abuf[17];
@@ -92,12 +92,13 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
   // prologue: stages 0..2 in flight
 #pragma unroll
-  for (int s = 0; s < kRing - 1; ++s) {
+  for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
     const float* src = p.stream + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
     const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
   }
+  if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0
   __builtin_amdgcn_s_barrier();                         // everybody's pieces of stage 0
   f32x4 a0 = (reinterpret_cast<const f32x4*>(ring) + lane)[0];
@@ -130,7 +131,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
       };
 
-      // ---- layer 0: K = 4 (xyz + zero pad), per-sample A fragments from LDS
+      // ---- layer 0: K = 4 (xyz + zero pad), per-sample A fragments from LDS.  All 32 MFMAs are issued as
+      // independent 2-deep chains; the ReLU of tiles 0-3 (consumed by the first layer-1 stage) follows, the
+      // ReLUs of tiles 4-15 ride in the MFMA shadows of layer 1's first tile (stage Q needs tiles 4Q..4Q+3).
       f32x16 h0[kTilesHidden];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
@@ -139,14 +142,21 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
           acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 0) * 64 + lane], bx0, acc);
           acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 1) * 64 + lane], bx1, acc);
         }
-        h0[t] = (ABL & 8) ? acc : relu16i(acc);
+        h0[t] = acc;
       }
+      auto relu_h0 = [&](int first) {
+        if (ABL & 8) return;
+#pragma unroll
+        for (int t = first; t < first + 4; ++t) h0[t] = relu16i(h0[t]);
+      };
+      relu_h0(0);
 
 #define ASDF_STAGE(KT, Q, SLOT, ACC, HIN, SIDX, EPI) \
   stage<KT, Q, SLOT, ABL, DUAL>(ACC, ACC##b, HIN, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, a0, a1, EPI)
 
       // ---- layer 1: 512 -> 256 (rows >= n1 are zero padding); epilogue of tile t-1 rides in tile t
       f32x16 h1[kTilesL1];
+      if (ABL & 4) for (int t = 0; t < kTilesL1; ++t) h1[t] = h0[t];
       f32x16 acc1[2], acc1b[2];
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -155,15 +165,22 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         f32x16& accb = acc1b[t & 1];
         acc = load_bias16(hc + kCstB1 + (t * 2 + half) * 16);
         accb = zero16;
-        auto epi = [&]() { if (t > 0) h1[t - 1] = relu16i(chains<DUAL>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1])); };
+        auto epi = [&]() {
+          if (t == 0) { relu_h0(4); return; }
+          if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
+          h1[t - 1] = relu16i(chains<DUAL>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1]));
+        };
+        auto epi1 = [&]() { if (t == 0) relu_h0(8); };
+        auto epi2 = [&]() { if (t == 0) relu_h0(12); };
         ASDF_STAGE(16, 0, 0, acc, h0, t * 4 + 0, epi);
-        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, NoEpilogue());
-        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, NoEpilogue());
+        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, epi1);
+        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, epi2);
         ASDF_STAGE(16, 3, 3, acc, h0, t * 4 + 3, NoEpilogue());
       }
 
       // ---- layer 2: [h1 (256) | xyz (4)] -> 512
       f32x16 h2[kTilesHidden];
+      if (ABL & 4) for (int t = 0; t < kTilesHidden; ++t) h2[t] = h0[t];
       f32x16 acc2[2], acc2b[2];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
@@ -174,6 +191,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         if (DUAL) accb = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, zero16);
         else acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, acc);
         auto epi = [&]() {
+          if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) h2[t - 1] = relu16i(chains<DUAL>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1]));
           else h1[kTilesL1 - 1] = relu16i(chains<DUAL>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1]));   // consumed by K-steps >= 112
         };
@@ -207,6 +225,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         acc = load_bias16(hc + kCstB3 + (t * 2 + half) * 16);
         accb = zero16;
         auto epi = [&]() {
+          if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) dot_w4(chains<DUAL>(acc3[(t - 1) & 1], acc3b[(t - 1) & 1]), t - 1);
           else h2[kTilesHidden - 1] = relu16i(chains<DUAL>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1]));   // consumed by K-steps >= 240
         };
