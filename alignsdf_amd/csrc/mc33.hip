@@ -6,12 +6,14 @@
 // references it, so "first reference" is decidable locally: the owner of an edge is the adjacent
 // in-bounds cell that comes first in scan order (axis 0 slowest).  That makes the output - vertex
 // order, face order, vertex ids - reproducible in parallel, element for element:
-//   K3 mc_classify    one thread per cell: MC33 case selection (mc33_common.h) -> 32-bit cell code
-//                     (tiling offset, #triangles, #owned vertices); per-block totals; volume min/max
+//   K3 mc_classify    one thread per 4 x-consecutive cells (float4 corner-row loads): MC33 case selection
+//                     (mc33_common.h) -> 32-bit cell codes (tiling offset, #triangles, #owned vertices) in
+//                     row-padded scan order; per-block totals; volume min/max
 //   K4 mc_scan_blocks exclusive scan of the per-block totals (one workgroup)
 //   K5 mc_emit_verts  in-block scan + block base -> vertex ids; interpolate owned vertices (fp64, as
 //                     the routine does), publish their ids in a per-grid-edge table
 //   K6 mc_emit_faces  same scan for triangles; look the three vertex ids up and write the face
+//                     (K5 / K6 blocks whose 1024 cell slots hold nothing return immediately)
 // All four are HBM-bound streaming kernels: 4 B read per voxel in K3, 4 B per cell code in K5/K6.
 #include <hip/hip_runtime.h>
 
@@ -46,7 +48,8 @@ struct McHeader {          // first 64 bytes of the workspace
 struct McDims {
   int nx, ny, nz;          // nx = fastest axis (axis 2)
   int cx, cy, cz;          // cells per axis
-  long long ncells;
+  int cxp;                 // cells per row padded to a multiple of 4 (one thread classifies 4 x-consecutive cells)
+  long long nslots;        // cxp * cy * cz cell slots, row-major = scan order; padding slots carry code 0
   int nblocks;
 };
 
@@ -61,9 +64,9 @@ __host__ inline float key_float(unsigned k) {
   return f;
 }
 
-__device__ __forceinline__ void cell_coords(const McDims& d, long long cell, int& x, int& y, int& z) {
-  x = (int)(cell % d.cx);
-  const long long r = cell / d.cx;
+__device__ __forceinline__ void cell_coords(const McDims& d, long long slot, int& x, int& y, int& z) {
+  x = (int)(slot % d.cxp);
+  const long long r = slot / d.cxp;
   y = (int)(r % d.cy);
   z = (int)(r / d.cy);
 }
@@ -90,44 +93,69 @@ __device__ __forceinline__ void load_corners(const float* vol, const McDims& d, 
   v[6] = (double)p1[d.nx + 1] - level; v[7] = (double)p1[d.nx] - level;
 }
 
+// 5 consecutive values of one volume row starting at x0 (a multiple of 4); entries beyond the row are not used
+__device__ __forceinline__ void load_row5(const float* __restrict__ row, int x0, int nx, bool vec, float* v) {
+  if (vec) {
+    const float4 q = *reinterpret_cast<const float4*>(row + x0);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    v[4] = x0 + 4 < nx ? row[x0 + 4] : 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = x0 + i < nx ? row[x0 + i] : 0.0f;
+  }
+}
+
 __global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restrict__ vol, McDims d, double level,
-                                                          unsigned* __restrict__ code, uint2* __restrict__ block_sums,
-                                                          McHeader* hdr) {
+                                                          uint4* __restrict__ code4, uint2* __restrict__ block_tot,
+                                                          uint2* __restrict__ block_minmax) {
   __shared__ unsigned s_tri[kMcThreads / 64], s_vert[kMcThreads / 64], s_min[kMcThreads / 64], s_max[kMcThreads / 64];
   unsigned ntri = 0, nvert = 0;
   float lo = INFINITY, hi = -INFINITY;
-  const long long base = (long long)blockIdx.x * kMcChunk;
+  const long long group = (long long)blockIdx.x * kMcThreads + threadIdx.x;     // 4 x-consecutive cell slots
+  if (group * 4 < d.nslots) {
+    int x0, y, z;
+    cell_coords(d, group * 4, x0, y, z);
+    const bool vec = (d.nx & 3) == 0 && ((size_t)vol & 15) == 0;
+    const float* r00 = vol + ((size_t)z * d.ny + y) * d.nx;
+    float a[4][5];      // rows (z,y) (z,y+1) (z+1,y) (z+1,y+1)
+    load_row5(r00, x0, d.nx, vec, a[0]);
+    load_row5(r00 + d.nx, x0, d.nx, vec, a[1]);
+    load_row5(r00 + (size_t)d.ny * d.nx, x0, d.nx, vec, a[2]);
+    load_row5(r00 + (size_t)d.ny * d.nx + d.nx, x0, d.nx, vec, a[3]);
+    unsigned cc[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < kMcCellsPerThread; ++i) {
-    const long long cell = base + i * kMcThreads + threadIdx.x;
-    if (cell >= d.ncells) break;
-    int x, y, z;
-    cell_coords(d, cell, x, y, z);
-    double v[8];
-    load_corners(vol, d, x, y, z, 0.0, v);     // raw values first: min/max and the trivial-cell test
-    bool any_hi = false, any_lo = false;
+    for (int i = 0; i < 4; ++i) {
+      const int x = x0 + i;
+      if (x >= d.cx) break;
+      // corners v0..v7: (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) and the same at z+1
+      const float c[8] = {a[0][i], a[0][i + 1], a[1][i + 1], a[1][i], a[2][i], a[2][i + 1], a[3][i + 1], a[3][i]};
+      bool any_hi = false, any_lo = false;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      lo = fminf(lo, (float)v[c]); hi = fmaxf(hi, (float)v[c]);
-      v[c] -= level;
-      any_hi |= v[c] > 0.0; any_lo |= !(v[c] > 0.0);
-    }
-    unsigned cc = 0;
-    if (any_hi && any_lo) {
-      int off;
-      const int nt = mc33_select_tiling(v, &off);
-      int nv = 0;
-      unsigned seen = 0;
-      for (int k = 0; k < 3 * nt; ++k) {
-        const int e = kMcTiles[off + k];
-        if (seen & (1u << e)) continue;
-        seen |= 1u << e;
-        if (e == 12 || owns_edge(e, x, y, z)) ++nv;
+      for (int k = 0; k < 8; ++k) {
+        lo = fminf(lo, c[k]); hi = fmaxf(hi, c[k]);
+        const bool above = (double)c[k] - level > 0.0;
+        any_hi |= above; any_lo |= !above;
       }
-      cc = code_pack(off, nt, nv);
-      ntri += nt; nvert += nv;
+      if (any_hi && any_lo) {
+        // the deciders index the corner array dynamically (it lives in scratch): only active cells pay for it
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (double)c[k] - level;
+        int off;
+        const int nt = mc33_select_tiling(v, &off);
+        int nv = 0;
+        unsigned seen = 0;
+        for (int k = 0; k < 3 * nt; ++k) {
+          const int e = kMcTiles[off + k];
+          if (seen & (1u << e)) continue;
+          seen |= 1u << e;
+          if (e == 12 || owns_edge(e, x, y, z)) ++nv;
+        }
+        cc[i] = code_pack(off, nt, nv);
+        ntri += nt; nvert += nv;
+      }
     }
-    code[cell] = cc;
+    code4[group] = make_uint4(cc[0], cc[1], cc[2], cc[3]);
   }
   // workgroup totals
   unsigned klo = float_key(lo), khi = float_key(hi);
@@ -140,24 +168,27 @@ __global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restric
   if ((threadIdx.x & 63) == 0) { s_tri[w] = ntri; s_vert[w] = nvert; s_min[w] = klo; s_max[w] = khi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned t = 0, vv = 0, a = 0xffffffffu, b = 0;
-    for (int i = 0; i < kMcThreads / 64; ++i) { t += s_tri[i]; vv += s_vert[i]; a = min(a, s_min[i]); b = max(b, s_max[i]); }
-    block_sums[blockIdx.x] = make_uint2(t, vv);
-    atomicMin(&hdr->min_key, a);
-    atomicMax(&hdr->max_key, b);
+    unsigned t = 0, vv = 0, a2 = 0xffffffffu, b2 = 0;
+    for (int i = 0; i < kMcThreads / 64; ++i) { t += s_tri[i]; vv += s_vert[i]; a2 = min(a2, s_min[i]); b2 = max(b2, s_max[i]); }
+    block_tot[blockIdx.x] = make_uint2(t, vv);
+    block_minmax[blockIdx.x] = make_uint2(a2, b2);     // reduced by mc_scan_blocks (one hot atomic word would serialise)
   }
 }
 
-// exclusive scan of block_sums (in place) by one workgroup; totals into the header
-__global__ __launch_bounds__(1024) void mc_scan_blocks(uint2* block_sums, int nblocks, McHeader* hdr) {
+// exclusive scan of the per-block totals into block_base by one workgroup; grand totals into the header
+__global__ __launch_bounds__(1024) void mc_scan_blocks(const uint2* __restrict__ block_sums, uint2* __restrict__ block_base,
+                                                       const uint2* __restrict__ block_minmax, int nblocks, McHeader* hdr) {
   __shared__ uint2 s_wave[16];
   __shared__ uint2 s_carry;
+  __shared__ unsigned s_lo[16], s_hi[16];
   if (threadIdx.x == 0) s_carry = make_uint2(0, 0);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned klo = 0xffffffffu, khi = 0;
   for (int start = 0; start < nblocks; start += 1024) {
     const int i = start + threadIdx.x;
     uint2 v = i < nblocks ? block_sums[i] : make_uint2(0, 0);
+    if (i < nblocks) { const uint2 mm = block_minmax[i]; klo = min(klo, mm.x); khi = max(khi, mm.y); }
     uint2 inc = v;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -168,12 +199,21 @@ __global__ __launch_bounds__(1024) void mc_scan_blocks(uint2* block_sums, int nb
     __syncthreads();
     uint2 pre = s_carry;
     for (int k = 0; k < w; ++k) { pre.x += s_wave[k].x; pre.y += s_wave[k].y; }
-    if (i < nblocks) block_sums[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
+    if (i < nblocks) block_base[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = make_uint2(pre.x + inc.x, pre.y + inc.y);
     __syncthreads();
   }
-  if (threadIdx.x == 0) { hdr->total_tris = s_carry.x; hdr->total_verts = s_carry.y; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    klo = min(klo, (unsigned)__shfl_xor((int)klo, m)); khi = max(khi, (unsigned)__shfl_xor((int)khi, m));
+  }
+  if (lane == 0) { s_lo[w] = klo; s_hi[w] = khi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) { klo = min(klo, s_lo[k]); khi = max(khi, s_hi[k]); }
+    hdr->total_tris = s_carry.x; hdr->total_verts = s_carry.y; hdr->min_key = klo; hdr->max_key = khi;
+  }
 }
 
 // exclusive scan of `val` over the workgroup's 256 threads, plus running carry
@@ -203,14 +243,16 @@ __device__ __forceinline__ size_t vid_slot(const McDims& d, int e, int x, int y,
 
 __global__ __launch_bounds__(kMcThreads) void mc_emit_verts(const float* __restrict__ vol, McDims d, double level,
                                                             const unsigned* __restrict__ code,
+                                                            const uint2* __restrict__ block_tot,
                                                             const uint2* __restrict__ block_base, unsigned* __restrict__ vid,
                                                             float* __restrict__ verts) {
   __shared__ unsigned s_wave[kMcThreads / 64];
+  if (block_tot[blockIdx.x].y == 0) return;             // no vertex is owned by this block's 1024 cell slots
   unsigned carry = block_base[blockIdx.x].y;
   const long long base = (long long)blockIdx.x * kMcChunk;
   for (int i = 0; i < kMcCellsPerThread; ++i) {
     const long long cell = base + i * kMcThreads + threadIdx.x;
-    const unsigned cc = cell < d.ncells ? code[cell] : 0;
+    const unsigned cc = cell < d.nslots ? code[cell] : 0;
     unsigned id = block_excl_scan(code_nv(cc), s_wave, carry);
     if (code_nv(cc) == 0) continue;
     int x, y, z;
@@ -252,14 +294,16 @@ __global__ __launch_bounds__(kMcThreads) void mc_emit_verts(const float* __restr
 }
 
 __global__ __launch_bounds__(kMcThreads) void mc_emit_faces(McDims d, const unsigned* __restrict__ code,
+                                                            const uint2* __restrict__ block_tot,
                                                             const uint2* __restrict__ block_base,
                                                             const unsigned* __restrict__ vid, int* __restrict__ faces) {
   __shared__ unsigned s_wave[kMcThreads / 64];
+  if (block_tot[blockIdx.x].x == 0) return;             // no triangle in this block's 1024 cell slots
   unsigned carry = block_base[blockIdx.x].x;
   const long long base = (long long)blockIdx.x * kMcChunk;
   for (int i = 0; i < kMcCellsPerThread; ++i) {
     const long long cell = base + i * kMcThreads + threadIdx.x;
-    const unsigned cc = cell < d.ncells ? code[cell] : 0;
+    const unsigned cc = cell < d.nslots ? code[cell] : 0;
     const unsigned tri0 = block_excl_scan(code_nt(cc), s_wave, carry);
     const int nt = code_nt(cc);
     if (nt == 0) continue;
@@ -276,13 +320,9 @@ __global__ __launch_bounds__(kMcThreads) void mc_emit_faces(McDims d, const unsi
   }
 }
 
-__global__ void mc_init_header(McHeader* hdr) {
-  if (threadIdx.x == 0) { hdr->total_tris = 0; hdr->total_verts = 0; hdr->min_key = 0xffffffffu; hdr->max_key = 0; }
-}
-
 struct McLayout {
   McDims d;
-  size_t off_code, off_sums, off_vid, total;
+  size_t off_code, off_sums, off_base, off_minmax, off_vid, total;
 };
 
 static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
@@ -291,12 +331,15 @@ static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
   McDims& d = L.d;
   d.nx = n2; d.ny = n1; d.nz = n0;
   d.cx = n2 - 1; d.cy = n1 - 1; d.cz = n0 - 1;
-  d.ncells = (long long)d.cx * d.cy * d.cz;
-  d.nblocks = (int)((d.ncells + kMcChunk - 1) / kMcChunk);
+  d.cxp = (d.cx + 3) & ~3;
+  d.nslots = (long long)d.cxp * d.cy * d.cz;
+  d.nblocks = (int)((d.nslots + kMcChunk - 1) / kMcChunk);
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = align(sizeof(McHeader));
-  L.off_code = o; o = align(o + sizeof(unsigned) * (size_t)d.ncells);
+  L.off_code = o; o = align(o + sizeof(unsigned) * (size_t)d.nblocks * kMcChunk);
   L.off_sums = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_base = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_minmax = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
   L.off_vid = o; o = align(o + sizeof(unsigned) * 4 * (size_t)n0 * n1 * n2);
   L.total = o;
   return true;
@@ -323,11 +366,12 @@ int asdf_mc_count(const float* vol, int32_t n0, int32_t n1, int32_t n2, double l
   hipStream_t st = (hipStream_t)stream;
   char* w = (char*)ws;
   McHeader* hdr = (McHeader*)w;
-  unsigned* code = (unsigned*)(w + L.off_code);
+  uint4* code4 = (uint4*)(w + L.off_code);
   uint2* sums = (uint2*)(w + L.off_sums);
-  hipLaunchKernelGGL(mc_init_header, dim3(1), dim3(64), 0, st, hdr);
-  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code, sums, hdr);
-  hipLaunchKernelGGL(mc_scan_blocks, dim3(1), dim3(1024), 0, st, sums, L.d.nblocks, hdr);
+  uint2* base = (uint2*)(w + L.off_base);
+  uint2* minmax = (uint2*)(w + L.off_minmax);
+  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code4, sums, minmax);
+  hipLaunchKernelGGL(mc_scan_blocks, dim3(1), dim3(1024), 0, st, sums, base, minmax, L.d.nblocks, hdr);
   ASDF_HIP(hipGetLastError());
   McHeader h;
   ASDF_HIP(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -350,9 +394,10 @@ int asdf_mc_emit(const float* vol, int32_t n0, int32_t n1, int32_t n2, double le
   char* w = (char*)ws;
   unsigned* code = (unsigned*)(w + L.off_code);
   uint2* sums = (uint2*)(w + L.off_sums);
+  uint2* base = (uint2*)(w + L.off_base);
   unsigned* vid = (unsigned*)(w + L.off_vid);
-  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code, sums, vid, verts);
-  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, L.d, code, sums, vid, faces);
+  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code, sums, base, vid, verts);
+  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, L.d, code, sums, base, vid, faces);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }
