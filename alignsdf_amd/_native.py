@@ -12,6 +12,8 @@ MAX_HEADS = 2
 MAX_POINT_FEATS = 64
 GRID_REFERENCE = 0
 GRID_INTEGER = 1
+FEATURES_AFFINE = 0
+FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
@@ -32,7 +34,8 @@ class NativeError(RuntimeError):
 
 class DecoderSpec(ctypes.Structure):
     _fields_ = [("latent_size", ctypes.c_int32), ("hidden", ctypes.c_int32), ("num_heads", ctypes.c_int32),
-                ("point_feats", ctypes.c_int32 * MAX_HEADS), ("outputs", ctypes.c_int32 * MAX_HEADS)]
+                ("point_feats", ctypes.c_int32 * MAX_HEADS), ("outputs", ctypes.c_int32 * MAX_HEADS),
+                ("feature_mode", ctypes.c_int32)]
 
 
 class HeadParams(ctypes.Structure):

@@ -30,8 +30,9 @@ struct FoldParams {
   const float* bias02;   // [heads][2][512]
   const float* embed;    // [heads][ASDF_MAX_POINT_FEATS][4]
   const float* latent;   // [256]
-  float* cst;            // [heads][kCstFloats]
+  float* cst;            // [heads][cst_offsets(kp).floats]
   int pf[ASDF_MAX_HEADS];
+  int kp;                // point-feature K-steps (2 = affine xyz: the A fragments are folded here; > 2 = NeRF: static)
 };
 
 __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
@@ -56,16 +57,17 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
     for (int f = 0; f < p.pf[head]; ++f) a = fmaf(wp[f], E[f * 4 + lane], a);
   const float a3 = __shfl(a, 3);
 
-  float* cst = p.cst + (size_t)head * kCstFloats;
+  const CstOffsets co = cst_offsets(p.kp);
+  float* cst = p.cst + (size_t)head * co.floats;
   const int t = row >> 5, rr = row & 31;
   if (lane == 0) {
-    const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + a3;
+    const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + (p.kp == 2 ? a3 : 0.0f);
     const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
-    cst[(layer ? kCstC2 : kCstC0) + (t * 2 + hh) * 16 + r] = c;
+    cst[(layer ? co.c2 : co.c0) + (t * 2 + hh) * 16 + r] = c;
   }
-  if (lane < 4) {
+  if (lane < 4 && p.kp == 2) {
     const int step = lane >> 1, hh = lane & 1;
-    cst[(layer ? kCstA2 : kCstA0) + (t * 2 + step) * 64 + hh * 32 + rr] = (lane < 3) ? a : 0.0f;
+    cst[(layer ? co.a2 : co.a0) + (t * 2 + step) * 64 + hh * 32 + rr] = (lane < 3) ? a : 0.0f;
   }
 }
 
@@ -115,7 +117,8 @@ struct asdf_decoder {
   float* wlat;      // [heads][2][512][256]
   float* wpt;       // [heads][2][512][MAXPF]
   float* bias02;    // [heads][2][512]
-  float* cst;       // [heads][kCstFloats]  (static parts written at create time)
+  float* cst;       // [heads][cst_offsets(kp).floats]  (static parts written at create time)
+  int kp;           // point-feature K-steps: 2 (affine xyz) or ceil(pf / 2) (NeRF encoding)
   float* embed;     // [heads][MAXPF][4]
   float* latent;    // last bound latent (device pointer owned by the caller)
   bool sample_bound;
@@ -124,6 +127,12 @@ struct asdf_decoder {
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
 static bool spec_supported(const asdf_decoder_spec_t* s) {
   if (s->latent_size != kLatent || s->hidden != kHidden) return false;
+  if (s->feature_mode == ASDF_FEATURES_NERF) {
+    if (s->point_feats[0] != 9 && s->point_feats[0] != 15) return false;
+    if (s->num_heads == 2 && s->point_feats[1] != s->point_feats[0]) return false;
+  } else if (s->feature_mode != ASDF_FEATURES_AFFINE) {
+    return false;
+  }
   if (s->num_heads == 2) return s->outputs[0] == 1 && s->outputs[1] == 1;
   if (s->num_heads == 1) return s->outputs[0] == 2;
   return false;
@@ -193,6 +202,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   HostPack hp;
   if (!pack_decoder(*spec, heads, hp)) { delete d; return ASDF_ENOMEM; }
   for (int h = 0; h < spec->num_heads; ++h) d->n1[h] = kHidden - kLatent - spec->point_feats[h];
+  d->kp = hp.kp;
   std::vector<float>&stream = hp.stream, &wlat = hp.wlat, &wpt = hp.wpt, &b02 = hp.b02, &cst = hp.cst, &emb = hp.emb;
 
   hipError_t e = hipSuccess;
@@ -204,8 +214,10 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sdf_mlp_combined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  for (const void* k : {(const void*)sdf_mlp_combined_kernel, (const void*)sdf_mlp_nerf9_kernel,
+                        (const void*)sdf_mlp_nerf15_kernel, (const void*)sdf_mlp_combined_nerf9_kernel,
+                        (const void*)sdf_mlp_combined_nerf15_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kMaxKP));
 
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -239,6 +251,7 @@ int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params
 
 int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const float* embed_host, void* stream) {
   if (!d || !latent_dev) return ASDF_EINVAL;
+  if (embed_host && d->spec.feature_mode != ASDF_FEATURES_AFFINE) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (embed_host) {
     ASDF_HIP(hipMemcpyAsync(d->embed, embed_host, sizeof(float) * kHeads * ASDF_MAX_POINT_FEATS * 4,
@@ -247,6 +260,7 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
   FoldParams fp;
   fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
   for (int h = 0; h < kHeads; ++h) fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0;
+  fp.kp = d->kp;
   hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
@@ -265,10 +279,18 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
-  if (p.num_mlps == 2)
-    hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
-  else
-    hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  p.pf = d->spec.point_feats[0];
+  const bool sep = p.num_mlps == 2;
+  if (d->kp == 2) {
+    if (sep) hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  } else if (d->kp == 5) {
+    if (sep) hipLaunchKernelGGL(sdf_mlp_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_combined_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+  } else {
+    if (sep) hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+  }
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }

@@ -12,17 +12,25 @@ struct HostPack {
   std::vector<float> wlat;     // [heads][2][512][256]   latent columns of layers 0 and 2
   std::vector<float> wpt;      // [heads][2][512][ASDF_MAX_POINT_FEATS]  point columns of layers 0 and 2
   std::vector<float> b02;      // [heads][2][512]
-  std::vector<float> cst;      // [heads][kCstFloats]    static parts filled, per-sample parts zero
+  std::vector<float> cst;      // [heads][cst_offsets(kp).floats]  static parts filled, per-sample parts zero
+  int kp;                      // point-feature K-steps of layers 0 / 2
   std::vector<float> emb;      // [heads][ASDF_MAX_POINT_FEATS][4]  identity-on-xyz default
 };
 
+// K-steps the point features occupy in layers 0 and 2: 2 for (affine) xyz, ceil(pf / 2) for the NeRF encoding
+inline int point_ksteps(const asdf_decoder_spec_t& spec) {
+  return spec.feature_mode == ASDF_FEATURES_NERF ? (spec.point_feats[0] + 1) / 2 : 2;
+}
+
 inline bool pack_decoder(const asdf_decoder_spec_t& spec, const asdf_head_params_t* heads, HostPack& hp) {
+  hp.kp = point_ksteps(spec);
+  const CstOffsets co = cst_offsets(hp.kp);
   try {
     hp.stream.assign((size_t)kStagesAll * kStageFloats, 0.f);
     hp.wlat.assign((size_t)kHeads * 2 * kHidden * kLatent, 0.f);
     hp.wpt.assign((size_t)kHeads * 2 * kHidden * ASDF_MAX_POINT_FEATS, 0.f);
     hp.b02.assign((size_t)kHeads * 2 * kHidden, 0.f);
-    hp.cst.assign((size_t)kHeads * kCstFloats, 0.f);
+    hp.cst.assign((size_t)kHeads * co.floats, 0.f);
     hp.emb.assign((size_t)kHeads * ASDF_MAX_POINT_FEATS * 4, 0.f);
   } catch (...) {
     return false;
@@ -64,20 +72,30 @@ inline bool pack_decoder(const asdf_decoder_spec_t& spec, const asdf_head_params
     pack(kTilesHidden, 2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 4, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
     // static constants in D-layout order
-    float* c = &hp.cst[(size_t)h * kCstFloats];
+    float* c = &hp.cst[(size_t)h * co.floats];
     for (int t = 0; t < kTilesHidden; ++t)
       for (int hh = 0; hh < 2; ++hh)
         for (int r = 0; r < 16; ++r) {
           const int row = 32 * t + tile_row(r, hh);
-          if (t < kTilesL1) c[kCstB1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] : 0.0f;
-          c[kCstB3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row];
-          c[kCstW4 + (t * 2 + hh) * 16 + r] = W4[row];
-          c[kCstW4b + (t * 2 + hh) * 16 + r] = spec.outputs[h] > 1 ? W4[kHidden + row] : 0.0f;
+          if (t < kTilesL1) c[co.b1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] : 0.0f;
+          c[co.b3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row];
+          c[co.w4 + (t * 2 + hh) * 16 + r] = W4[row];
+          c[co.w4b + (t * 2 + hh) * 16 + r] = spec.outputs[h] > 1 ? W4[kHidden + row] : 0.0f;
         }
-    c[kCstB4] = heads[h].b[4][0];
-    c[kCstB4 + 1] = spec.outputs[h] > 1 ? heads[h].b[4][1] : 0.0f;
+    c[co.b4] = heads[h].b[4][0];
+    c[co.b4 + 1] = spec.outputs[h] > 1 ? heads[h].b[4][1] : 0.0f;
     // default embedding: identity on xyz (PointFeatSize 3)
     for (int f = 0; f < 3 && f < pf; ++f) hp.emb[((size_t)h * ASDF_MAX_POINT_FEATS + f) * 4 + f] = 1.0f;
+    // NeRF encoding: the point columns are static weights, not a per-sample fold -> A fragments packed here
+    if (spec.feature_mode == ASDF_FEATURES_NERF)
+      for (int layer = 0; layer < 2; ++layer)
+        for (int t = 0; t < kTilesHidden; ++t)
+          for (int s = 0; s < hp.kp; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int row = 32 * t + (lane & 31), f = 2 * s + (lane >> 5);
+              const float* wp = &hp.wpt[((size_t)(h * 2 + layer) * kHidden + row) * ASDF_MAX_POINT_FEATS];
+              c[(layer ? co.a2 : co.a0) + (t * hp.kp + s) * 64 + lane] = f < pf ? wp[f] : 0.0f;
+            }
   }
   return true;
 }

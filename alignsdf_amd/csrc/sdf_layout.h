@@ -44,19 +44,45 @@ constexpr int kStagesHead = kStagesL1 + kStagesL2 + kStagesL3;   // 128
 constexpr int kHeads = 2;
 constexpr int kStagesAll = kStagesHead * kHeads;                  // 256 stages = 4 MiB
 
-// Per-head constants block (floats), loaded into LDS once per workgroup.
-//   frag arrays: [tile][kstep = 0..1][lane]  (A operand images)
+// Per-head constants block (floats), resident in LDS.  KP = number of point-feature K-steps of layers 0 and 2:
+// 2 when the point features are (an affine function of) xyz, ceil(pf / 2) for the NeRF positional encoding.
+//   frag arrays: [tile][kstep = 0..KP-1][lane]  (A operand images)
 //   bias arrays: [tile][half = 0..1][r = 0..15]  (D-layout order)
-constexpr int kCstA0 = 0;                                   // 16 * 2 * 64 = 2048
-constexpr int kCstA2 = kCstA0 + kTilesHidden * 2 * 64;      // 2048
-constexpr int kCstC0 = kCstA2 + kTilesHidden * 2 * 64;      // 512
-constexpr int kCstB1 = kCstC0 + kHidden;                    // 256
-constexpr int kCstC2 = kCstB1 + kTilesL1 * 32;              // 512
-constexpr int kCstB3 = kCstC2 + kHidden;                    // 512
-constexpr int kCstW4 = kCstB3 + kHidden;                    // 512
-constexpr int kCstW4b = kCstW4 + kHidden;                   // 512: second output row (CombinedDecoder), zero otherwise
-constexpr int kCstB4 = kCstW4b + kHidden;                   // 2 (+2 pad): b4 of output 0 and output 1
-constexpr int kCstFloats = kCstB4 + 4;                      // 6916 floats = 27 664 B
+template <int KP>
+struct CstLayout {
+  static constexpr int kA0 = 0;                                   // 16 * KP * 64
+  static constexpr int kA2 = kA0 + kTilesHidden * KP * 64;        // 16 * KP * 64
+  static constexpr int kC0 = kA2 + kTilesHidden * KP * 64;        // 512
+  static constexpr int kB1 = kC0 + kHidden;                       // 256
+  static constexpr int kC2 = kB1 + kTilesL1 * 32;                 // 512
+  static constexpr int kB3 = kC2 + kHidden;                       // 512
+  static constexpr int kW4 = kB3 + kHidden;                       // 512
+  static constexpr int kW4b = kW4 + kHidden;                      // 512: second output row (CombinedDecoder), zero otherwise
+  static constexpr int kB4 = kW4b + kHidden;                      // 2 (+2 pad): b4 of output 0 and output 1
+  static constexpr int kFloats = kB4 + 4;
+};
+constexpr int kCstFloats = CstLayout<2>::kFloats;                 // 6916 floats = 27 664 B (xyz features)
+constexpr int kMaxKP = 8;                                          // NeRF encoding up to PointFeatSize 15
+constexpr int kCstFloatsMax = CstLayout<kMaxKP>::kFloats;
+
+// runtime view of the same offsets (host packer, fold kernel)
+struct CstOffsets {
+  int a0, a2, c0, b1, c2, b3, w4, w4b, b4, floats;
+};
+__host__ __device__ constexpr CstOffsets cst_offsets(int kp) {
+  CstOffsets o{};
+  o.a0 = 0;
+  o.a2 = o.a0 + kTilesHidden * kp * 64;
+  o.c0 = o.a2 + kTilesHidden * kp * 64;
+  o.b1 = o.c0 + kHidden;
+  o.c2 = o.b1 + kTilesL1 * 32;
+  o.b3 = o.c2 + kHidden;
+  o.w4 = o.b3 + kHidden;
+  o.w4b = o.w4 + kHidden;
+  o.b4 = o.w4b + kHidden;
+  o.floats = o.b4 + 4;
+  return o;
+}
 
 // feature row held by (register r, lane half h) of a 32x32 D tile
 __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

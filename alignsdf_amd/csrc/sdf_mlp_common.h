@@ -27,8 +27,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 4;
 constexpr int kLdsRingFloats = kRing * kStageFloats;                 // 64 KiB
-constexpr int kLdsFloats = kLdsRingFloats + kHeads * kCstFloats;     // + 51 232 B
-constexpr int kLdsBytes = kLdsFloats * 4;
+// xyz-feature kernels keep both heads' constants resident; NeRF-feature kernels (KP > 2) hold one head's
+// (larger) block and reload it when they switch heads
+constexpr int lds_bytes(int kp) { return (kLdsRingFloats + (kp == 2 ? kHeads * kCstFloats : cst_offsets(kp).floats)) * 4; }
+constexpr int kLdsBytes = lds_bytes(2);
 
 enum GridMode : int {
   kGridReference = 0,   // true-division ("sheared") indices of utils/mesh.py:33-34
@@ -49,6 +51,7 @@ struct DecodeParams {
   float vs;                 // voxel size (fp32, as the reference rounds it)
   float o0, o1, o2;         // origin added to axis-0/1/2 coordinates
   int num_mlps;             // 2 = SeparateDecoder (one output each), 1 = CombinedDecoder (two outputs)
+  int pf;                   // raw point-feature count (NeRF-feature kernels only)
 };
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {

@@ -68,9 +68,22 @@ __device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&
   a1 = abuf[17];
 }
 
+// k-th NeRF positional-encoding feature of a point (get_nerf_embedder, utils/utils.py:433-463,521-533):
+// [x0 x1 x2 | sin(2^0 x) (3) cos(2^0 x) (3) | sin(2^1 x) (3) cos(2^1 x) (3) | ...]; fp32 like torch (x * freq, then sin).
+__device__ __forceinline__ float nerf_feature(int f, float x0, float x1, float x2) {
+  if (f < 3) return f == 0 ? x0 : (f == 1 ? x1 : x2);
+  const int j = f - 3, r = j % 6, d = r % 3;
+  const float xd = d == 0 ? x0 : (d == 1 ? x1 : x2);
+  const float arg = __fmul_rn(xd, (float)(1 << (j / 6)));
+  return r < 3 ? sinf(arg) : cosf(arg);
+}
+
 // MLPS = 2: SeparateDecoder (two MLPs, one output each); MLPS = 1: CombinedDecoder (one MLP, two outputs).
-template <int ABL, int DUAL, int MLPS>
+// KP = K-steps taken by the point features in layers 0 and 2: 2 = (affine) xyz, 5 / 8 = NeRF encoding of 9 / 15 features.
+template <int ABL, int DUAL, int MLPS, int KP>
 __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
+  using CL = CstLayout<KP>;
+  constexpr bool kReloadCst = KP > 2;        // one head's constants in LDS at a time
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
   float* cst = smem + kLdsRingFloats;
@@ -84,9 +97,11 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   if ((long long)blockIdx.x >= ntiles) return;
 
   // per-sample constants -> LDS (once per workgroup)
-  for (int i = tid; i < MLPS * kCstFloats / 4; i += 256)
-    reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
-  __syncthreads();
+  if (!kReloadCst) {
+    for (int i = tid; i < MLPS * CL::kFloats / 4; i += 256)
+      reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
+    __syncthreads();
+  }
 
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
 
@@ -117,13 +132,26 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
     } else {
       grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
     }
-    // B operands of the two xyz K-steps: lane half 0 supplies k = 0 / 2, half 1 supplies k = 1 / 3
-    const float bx0 = half ? x1 : x0;
-    const float bx1 = half ? 0.0f : x2;
+    // B operands of the point-feature K-steps: lane half h supplies feature 2 s + h of K-step s
+    float bp[KP];
+    if (KP == 2) {
+      bp[0] = half ? x1 : x0;
+      bp[1] = half ? 0.0f : x2;
+    } else {
+#pragma unroll
+      for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
+    }
 
 #pragma unroll 1
     for (int head = 0; head < MLPS; ++head) {
-      const float* hc = cst + head * kCstFloats;
+      const float* hc = cst + (kReloadCst ? 0 : head * CL::kFloats);
+      if (kReloadCst) {
+        // every wave is done with the previous head's constants -> refill the block -> publish
+        __builtin_amdgcn_s_barrier();
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
+        for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
+        __syncthreads();
+      }
       // source of stage (s + 3) relative to this MLP's first stage, wrapping to the next MLP in stream order
       const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
       const float* swrap = p.stream + (size_t)(head + 1 == MLPS ? 0 : head + 1) * kStagesHead * kStageFloats;
@@ -137,10 +165,10 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       f32x16 h0[kTilesHidden];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
-        f32x16 acc = load_bias16(hc + kCstC0 + (t * 2 + half) * 16);
+        f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
         if (!(ABL & 8)) {
-          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 0) * 64 + lane], bx0, acc);
-          acc = ASDF_MFMA(hc[kCstA0 + (t * 2 + 1) * 64 + lane], bx1, acc);
+#pragma unroll
+          for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
         }
         h0[t] = acc;
       }
@@ -163,7 +191,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
         f32x16& accb = acc1b[t & 1];
-        acc = load_bias16(hc + kCstB1 + (t * 2 + half) * 16);
+        acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
         accb = zero16;
         auto epi = [&]() {
           if (t == 0) { relu_h0(4); return; }
@@ -186,10 +214,10 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc2[t & 1];
         f32x16& accb = acc2b[t & 1];
-        acc = load_bias16(hc + kCstC2 + (t * 2 + half) * 16);
-        acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 0) * 64 + lane], bx0, acc);
-        if (DUAL) accb = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, zero16);
-        else acc = ASDF_MFMA(hc[kCstA2 + (t * 2 + 1) * 64 + lane], bx1, acc);
+        acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
+        if (DUAL) accb = zero16;
+#pragma unroll
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
         auto epi = [&]() {
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) h2[t - 1] = relu16i(chains<DUAL>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1]));
@@ -209,11 +237,11 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       float part = 0.0f, partb = 0.0f;      // partb: second output row (CombinedDecoder; its weights are 0 otherwise)
       f32x16 acc3[2], acc3b[2];
       auto dot_w4 = [&](const f32x16 a, int t) {
-        const f32x16 w = load_bias16(hc + kCstW4 + (t * 2 + half) * 16);
+        const f32x16 w = load_bias16(hc + CL::kW4 + (t * 2 + half) * 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), w[r], part);
         if (MLPS == 1) {
-          const f32x16 wb = load_bias16(hc + kCstW4b + (t * 2 + half) * 16);
+          const f32x16 wb = load_bias16(hc + CL::kW4b + (t * 2 + half) * 16);
 #pragma unroll
           for (int r = 0; r < 16; ++r) partb = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), wb[r], partb);
         }
@@ -222,7 +250,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
         f32x16& accb = acc3b[t & 1];
-        acc = load_bias16(hc + kCstB3 + (t * 2 + half) * 16);
+        acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
         accb = zero16;
         auto epi = [&]() {
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
@@ -238,11 +266,11 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       dot_w4(chains<DUAL>(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1]), kTilesHidden - 1);
 #undef ASDF_STAGE
       part += __shfl_xor(part, 32);
-      const float sdf = tanhf(part + hc[kCstB4]);
+      const float sdf = tanhf(part + hc[CL::kB4]);
       float sdfb = 1.0f;
       if (MLPS == 1) {
         partb += __shfl_xor(partb, 32);
-        sdfb = tanhf(partb + hc[kCstB4 + 1]);
+        sdfb = tanhf(partb + hc[CL::kB4 + 1]);
       }
       // output 0 of MLP 0 is the hand SDF; the object SDF is output 0 of MLP 1 or output 1 of a combined MLP
       const bool is_hand = head == 0;
@@ -280,7 +308,12 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 2>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 2>(p); }
+// NeRF positional encoding of the query point (PointFeatSize 9 / 15 without pose alignment, utils/mesh.py:53-55)
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 5>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 8>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 5>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 8>(p); }
 
 }  // namespace asdf

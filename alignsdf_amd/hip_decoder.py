@@ -110,12 +110,17 @@ class HipSdfDecoder:
         L = _native.lib()
         if L.asdf_device_count() < 1:
             raise _native.NativeError(-4, "no gfx950 (MI355X) device visible - the HIP path has no CPU fallback")
+        # NeRF positional encoding: PointFeatSize > 3 with EncodeStyle "nerf" (utils/mesh.py:49-55) - not affine in xyz
+        self.nerf_features = self.point_feat_size > 3 and encode_style == "nerf"
+        if self.nerf_features and self.point_feat_size not in (9, 15):
+            raise NotImplementedError("NeRF positional encoding is supported for PointFeatSize 9 and 15")
+        mode = _native.FEATURES_NERF if self.nerf_features else _native.FEATURES_AFFINE
         if self.combined:
             pf, prefixes, n_out = (self.point_feat_size,), ("lin",), 2
-            spec = _native.DecoderSpec(self.latent_size, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0))
+            spec = _native.DecoderSpec(self.latent_size, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0), mode)
         else:
             pf, prefixes, n_out = head_point_feats(self.point_feat_size, encode_style), ("linh", "lino"), 1
-            spec = _native.DecoderSpec(self.latent_size, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1))
+            spec = _native.DecoderSpec(self.latent_size, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1), mode)
         heads = (_native.HeadParams * 2)()
         keep = []
         for hi, prefix in enumerate(prefixes):
@@ -159,7 +164,10 @@ class HipSdfDecoder:
         if lat.numel() != self.latent_size:
             raise ValueError("latent has %d elements, expected %d" % (lat.numel(), self.latent_size))
         emb_ptr = None
-        if embed is not None:
+        if self.nerf_features:
+            if embed is not None:
+                raise ValueError("a NeRF-encoded decoder takes raw xyz; no affine embedding applies")
+        elif embed is not None:
             buf = np.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=np.float32)
             for h in range(len(self._pf)):
                 e = np.asarray(embed[h], dtype=np.float64)
@@ -168,7 +176,7 @@ class HipSdfDecoder:
                 buf[h, :self._pf[h]] = e.astype(np.float32)
             emb_ptr = buf.ctypes.data_as(ctypes.c_void_p)
             self._emb_keep = buf
-        elif any(f != 3 for f in self._pf):
+        elif not self.nerf_features and any(f != 3 for f in self._pf):
             raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
         self._latent = lat   # keep the device buffer alive until the next set_sample
         with torch.cuda.device(self.device):

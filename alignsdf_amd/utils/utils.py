@@ -32,8 +32,10 @@ def sample_embedding(specs, mano_results, obj_results, combined=False):
     if mano_results is not None and specs["EncodeStyle"] != "nerf":
         return kinematic_affine(specs["PointFeatSize"], specs["EncodeStyle"], specs["SdfScaleFactor"], mano_results,
                                 obj_results, combined)
-    raise NotImplementedError("NeRF positional encoding (PointFeatSize > 3 without pose alignment) is not affine in xyz "
-                              "and is not part of the HIP path")
+    if specs["EncodeStyle"] == "nerf":
+        return None      # NeRF positional encoding: computed inside the kernel (decoder packed with FEATURES_NERF)
+    raise NotImplementedError("a pose-aligned decoder (EncodeStyle %r) evaluated without mano_results falls back to the NeRF "
+                              "encoding in the reference (utils/mesh.py:53-55); that combination is not supported" % specs["EncodeStyle"])
 
 
 def kinematic_embedding(xyz, mano_results, num_points_per_scene, point_feat_size, scale_factor, obj_results, encode_style):

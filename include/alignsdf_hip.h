@@ -29,6 +29,11 @@ extern "C" {
 #define ASDF_MAX_HEADS 2
 #define ASDF_MAX_POINT_FEATS 64
 
+/* How a head's point features are obtained from a normalised query point. */
+#define ASDF_FEATURES_AFFINE 0 /* feat = E xyz + t (plain xyz, or utils.utils.kinematic_embedding folded in) */
+#define ASDF_FEATURES_NERF 1   /* [x, sin(2^k x), cos(2^k x)], k < (pf-3)/6: get_nerf_embedder, utils/utils.py:433-463,
+                                  521-533; point_feats must be 9 or 15 and equal for all heads */
+
 /* Grid index modes of asdf_decode_grid. */
 #define ASDF_GRID_REFERENCE 0 /* true-division indices exactly as utils/mesh.py:32-34 computes them */
 #define ASDF_GRID_INTEGER 1   /* floor-division indices (an axis-aligned lattice) */
@@ -47,6 +52,7 @@ typedef struct asdf_decoder_spec {
   int32_t point_feats[ASDF_MAX_HEADS];    /* 3 ("nerf", PointFeatSize 3) or 6 ("both", PointFeatSize 9) ... */
   int32_t outputs[ASDF_MAX_HEADS];        /* rows of the last layer: 1 (SeparateDecoder) or 2 (CombinedDecoder:
                                              row 0 = hand, row 1 = object, networks/model.py:99,185-188) */
+  int32_t feature_mode;                   /* ASDF_FEATURES_AFFINE or ASDF_FEATURES_NERF */
 } asdf_decoder_spec_t;
 
 /* Host-side effective parameters of one head, row-major [out][in] like nn.Linear.weight:
@@ -118,7 +124,7 @@ int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doubl
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
- * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*6916, embed 2*ASDF_MAX_POINT_FEATS*4. */
+ * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed);
 

@@ -55,7 +55,7 @@ def fit_last_layers():
     pts = syn.uniform((60000, 3), 424242, -1.0, 1.0).astype(np.float32)
     hand_t, obj_t = syn.analytic_sdf(pts)
     targets = {"h": np.arctanh(np.clip(0.5 * hand_t, -0.05, 0.05)), "o": np.arctanh(np.clip(0.5 * obj_t, -0.05, 0.05))}
-    for tag in ("nerf3", "both9"):
+    for tag in ("nerf3", "both9", "nerf9"):
         specs = syn.specs_for(tag)
         sd = syn.hidden_state_dict(256, specs["PointFeatSize"], specs["EncodeStyle"], 0)
         latent = torch.from_numpy(syn.latent_code(0))
@@ -132,7 +132,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_grid.npz"), **grid)
 
     # ---- full two-pass runs of the reference
-    for tag in ("nerf3", "both9", "comb3"):
+    for tag in ("nerf3", "both9", "comb3", "nerf9"):
         specs = syn.specs_for(tag)
         sd = syn.full_state_dict(tag)
         cls = arch.CombinedDecoder if tag == "comb3" else arch.SeparateDecoder
@@ -193,9 +193,13 @@ def main():
         pts = torch.from_numpy(syn.uniform((4096, 3), 777, -1.0, 1.0).astype(np.float32))
         with torch.no_grad():
             q = pts
-            if specs["PointFeatSize"] > 3:
+            if specs["PointFeatSize"] > 3 and mano is not None and specs["EncodeStyle"] != "nerf":
                 q = uu.kinematic_embedding(pts, mano, pts.shape[0], specs["PointFeatSize"], specs["SdfScaleFactor"], obj,
                                            specs["EncodeStyle"])
+                gold["embed_pts"] = q.numpy()
+            elif specs["PointFeatSize"] > 3:      # utils/mesh.py:53-55
+                nerf_embedding, _ = uu.get_nerf_embedder((specs["PointFeatSize"] - 3) // 6)
+                q = nerf_embedding(pts)
                 gold["embed_pts"] = q.numpy()
             h, o, _ = uu.decode_sdf_multi_output(dec, latent, q, mano, None, specs)
         gold["rand_pts"] = pts.numpy()

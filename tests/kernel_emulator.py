@@ -14,9 +14,16 @@ import torch
 from alignsdf_amd import _native
 from alignsdf_amd.hip_decoder import _effective, head_point_feats
 
-K_HIDDEN, K_LATENT, K_CST = 512, 256, 6916
+K_HIDDEN, K_LATENT = 512, 256
 STAGE = 4096
-OFF = dict(A0=0, A2=2048, C0=4096, B1=4608, C2=4864, B3=5376, W4=5888, W4B=6400, B4=6912)
+
+
+def offsets(kp):
+    """cst_offsets(kp) of sdf_layout.h."""
+    a2 = 16 * kp * 64
+    c0 = 2 * a2
+    return dict(A0=0, A2=a2, C0=c0, B1=c0 + 512, C2=c0 + 768, B3=c0 + 1280, W4=c0 + 1792, W4B=c0 + 2304, B4=c0 + 2816,
+                FLOATS=c0 + 2820)
 LANE = np.arange(64)
 HALF = LANE >> 5
 ROW = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in range(2)] for r in range(16)])   # [r][half]
@@ -28,12 +35,15 @@ def pack_host(sd, point_feat_size, encode_style):
     pf = head_point_feats(point_feat_size, encode_style)
     sd = {k: torch.as_tensor(v) for k, v in sd.items()}
     combined = "lin0.bias" in sd
+    nerf = point_feat_size > 3 and encode_style == "nerf"
+    mode = _native.FEATURES_NERF if nerf else _native.FEATURES_AFFINE
+    kp = (point_feat_size + 1) // 2 if nerf else 2
     if combined:
         pf, prefixes = (point_feat_size,), ("lin",)
-        spec = _native.DecoderSpec(256, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0))
+        spec = _native.DecoderSpec(256, 512, 1, (ctypes.c_int32 * 2)(pf[0], 0), (ctypes.c_int32 * 2)(2, 0), mode)
     else:
         prefixes = ("linh", "lino")
-        spec = _native.DecoderSpec(256, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1))
+        spec = _native.DecoderSpec(256, 512, 2, (ctypes.c_int32 * 2)(*pf), (ctypes.c_int32 * 2)(1, 1), mode)
     heads = (_native.HeadParams * 2)()
     keep = []
     for hi, prefix in enumerate(prefixes):
@@ -47,19 +57,22 @@ def pack_host(sd, point_feat_size, encode_style):
     out = {
         "stream": np.zeros(256 * STAGE, np.float32), "wlat": np.zeros(2 * 2 * 512 * 256, np.float32),
         "wpt": np.zeros(2 * 2 * 512 * _native.MAX_POINT_FEATS, np.float32), "b02": np.zeros(2 * 2 * 512, np.float32),
-        "cst": np.zeros(2 * K_CST, np.float32), "emb": np.zeros(2 * _native.MAX_POINT_FEATS * 4, np.float32),
+        "cst": np.zeros(2 * offsets(kp)["FLOATS"], np.float32), "emb": np.zeros(2 * _native.MAX_POINT_FEATS * 4, np.float32),
     }
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     _native.check(L.asdf_debug_pack_host(ctypes.byref(spec), heads, ptr(out["stream"]), ptr(out["wlat"]), ptr(out["wpt"]),
                                          ptr(out["b02"]), ptr(out["cst"]), ptr(out["emb"])), "asdf_debug_pack_host")
     out["pf"] = pf
     out["combined"] = combined
+    out["kp"] = kp
+    out["nerf"] = nerf
     return out
 
 
 def fold(pk, latent, embed=None):
     """K0 emulation: fills the per-sample parts of pk['cst'] (returns a new cst array)."""
-    cst = pk["cst"].copy().reshape(2, K_CST)
+    OFF = offsets(pk["kp"])
+    cst = pk["cst"].copy().reshape(2, OFF["FLOATS"])
     wlat = pk["wlat"].reshape(2, 2, 512, 256)
     wpt = pk["wpt"].reshape(2, 2, 512, _native.MAX_POINT_FEATS)
     b02 = pk["b02"].reshape(2, 2, 512)
@@ -73,12 +86,14 @@ def fold(pk, latent, embed=None):
         for layer in range(2):
             dot = (wlat[head, layer].astype(np.float32) @ lat).astype(np.float32)
             a = (wpt[head, layer, :, :pk["pf"][head]] @ emb[head, :pk["pf"][head]]).astype(np.float32)   # [512,4]
-            c = ((dot + b02[head, layer]).astype(np.float32) + a[:, 3]).astype(np.float32)
+            c = (dot + b02[head, layer]).astype(np.float32)
+            if not pk["nerf"]:
+                c = (c + a[:, 3]).astype(np.float32)
             for row in range(512):
                 t, rr = row >> 5, row & 31
                 hh, r = (rr >> 2) & 1, (rr & 3) + 4 * (rr >> 3)
                 cst[head, (OFF["C2"] if layer else OFF["C0"]) + (t * 2 + hh) * 16 + r] = c[row]
-                for d in range(4):
+                for d in range(0 if pk["nerf"] else 4):
                     step, h2 = d >> 1, d & 1
                     cst[head, (OFF["A2"] if layer else OFF["A0"]) + (t * 2 + step) * 64 + h2 * 32 + rr] = a[row, d] if d < 3 else 0.0
     return cst
@@ -103,12 +118,27 @@ def bias16(c, off, t):
     return out
 
 
+def nerf_feature(f, x):
+    """nerf_feature() of sdf_mlp_kernel.h for all points x [n,3]."""
+    if f < 3:
+        return x[:, f]
+    j = f - 3
+    r, d = j % 6, (j % 6) % 3
+    arg = (x[:, d] * np.float32(1 << (j // 6))).astype(np.float32)
+    return (np.sin(arg) if r < 3 else np.cos(arg)).astype(np.float32)
+
+
 def run_wave(pk, cst, xyz32):
     """K1 emulation for one wave: xyz32 [32,3] -> (hand [32], obj [32])."""
+    OFF = offsets(pk["kp"])
+    KP = pk["kp"]
     x = np.asarray(xyz32, np.float32)
     pt = LANE & 31
-    bx0 = np.where(HALF == 1, x[pt, 1], x[pt, 0]).astype(np.float32)
-    bx1 = np.where(HALF == 1, 0.0, x[pt, 2]).astype(np.float32)
+    if pk["nerf"]:
+        feats = [nerf_feature(f, x) if f < pk["pf"][0] else np.zeros(32, np.float32) for f in range(2 * KP)]
+        bp = [np.where(HALF == 1, feats[2 * s + 1][pt], feats[2 * s][pt]).astype(np.float32) for s in range(KP)]
+    else:
+        bp = [np.where(HALF == 1, x[pt, 1], x[pt, 0]).astype(np.float32), np.where(HALF == 1, 0.0, x[pt, 2]).astype(np.float32)]
     stream = pk["stream"].reshape(256, 16, 64, 4)
     outs = []
     for head in range(len(pk["pf"])):
@@ -120,8 +150,8 @@ def run_wave(pk, cst, xyz32):
             for t in range(ntiles):
                 acc = bias16(c, bias_off, t)
                 if extra is not None:
-                    acc = mfma(c[extra + (t * 2 + 0) * 64: extra + (t * 2 + 0) * 64 + 64], bx0, acc)
-                    acc = mfma(c[extra + (t * 2 + 1) * 64: extra + (t * 2 + 1) * 64 + 64], bx1, acc)
+                    for s in range(KP):
+                        acc = mfma(c[extra + (t * KP + s) * 64: extra + (t * KP + s) * 64 + 64], bp[s], acc)
                 for q in range(stages_per_tile):
                     st = stream[sbase + s0 + t * stages_per_tile + q]
                     for g in range(16):

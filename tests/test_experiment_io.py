@@ -22,7 +22,7 @@ def make_experiment(root, tag, names):
     return specs, split
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_load_experiment_reads_decoder_tensors(tag, tmp_path):
     from alignsdf_amd.reconstruct import load_experiment
     specs, _ = make_experiment(str(tmp_path), tag, ["a"])
@@ -38,8 +38,9 @@ def test_load_experiment_reads_decoder_tensors(tag, tmp_path):
     pts = torch.from_numpy(syn.uniform((64, 3), 9, -1, 1).astype(np.float32))
     lat = torch.from_numpy(syn.latent_code(0))
     if tag != "both9":
+        feats = orc.point_features(pts, specs, None, None)
         with torch.no_grad():
-            h, o, _ = dec(torch.cat([lat.expand(64, -1), pts], 1))
+            h, o, _ = dec(torch.cat([lat.expand(64, -1), feats], 1))
         rh, ro = orc.decode_points(ref, lat, pts, specs)
         assert (h.squeeze(1) - rh).abs().max() <= 1e-6 and (o.squeeze(1) - ro).abs().max() <= 1e-6
 

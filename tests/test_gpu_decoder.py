@@ -27,7 +27,7 @@ def _setup(tag):
     return dec, specs, sd, lat, mano, obj
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_points_vs_reference_golden(tag, golden_dir):
     dec, *_ = _setup(tag)
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
@@ -36,7 +36,7 @@ def test_points_vs_reference_golden(tag, golden_dir):
     assert np.abs(o.cpu().numpy() - g["rand_obj"]).max() <= TOL
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 @pytest.mark.parametrize("M", [0, 1, 31, 32, 33, 127, 129, 1000, 40000])
 def test_points_ragged_vs_oracle(tag, M):
     from oracle import sdf_oracle as orc
@@ -51,7 +51,7 @@ def test_points_ragged_vs_oracle(tag, M):
         assert (o.cpu() - ro).abs().max().item() <= TOL
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_grid_pass1_vs_reference_golden(tag, golden_dir):
     """Pass 1 on [-1,1]^3 at N=32 (full volume) and N=64 (8192 probes), incl. the negative-voxel bbox."""
     dec, *_ = _setup(tag)
@@ -75,7 +75,7 @@ def test_grid_pass1_vs_reference_golden(tag, golden_dir):
         assert np.array_equal(got, ref_bbox), (got, ref_bbox)
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_grid_pass2_vs_reference_golden(tag, golden_dir):
     """Pass 2 inside the reference's own zoom cube (so only the decoder is compared)."""
     dec, *_ = _setup(tag)

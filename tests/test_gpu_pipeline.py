@@ -25,7 +25,7 @@ def _module(tag):
     return specs, dec, lat, mano, obj
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 @pytest.mark.parametrize("N", [32, 64])
 def test_two_pass_matches_reference(tag, N, golden_dir):
     """Pass 1 -> bbox -> zoom cube -> pass 2, all computed by the product, vs the reference's own run."""
@@ -98,7 +98,7 @@ def test_legacy_create_mesh(tmp_path, golden_dir):
 
 def test_decode_sdf_multi_output_dropin(golden_dir):
     from alignsdf_amd.utils.utils import decode_sdf_multi_output
-    for tag in ("nerf3", "both9", "comb3"):
+    for tag in ("nerf3", "both9", "comb3", "nerf9"):
         g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
         specs, dec, lat, mano, obj = _module(tag)
         h, o, _ = decode_sdf_multi_output(dec, lat, torch.from_numpy(g["rand_pts"]).cuda(), mano, None, specs, obj_results=obj)

@@ -36,7 +36,7 @@ def test_sheared_closed_form():
     assert np.array_equal(idx[:, 1], y + z / N) and np.array_equal(idx[:, 0], x + y / N + z / N ** 2)
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_effective_weights_match_module_hook(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     sd = syn.full_state_dict(tag)
@@ -46,20 +46,20 @@ def test_effective_weights_match_module_hook(tag, golden_dir):
             assert np.array_equal(params[layer][0].numpy()[:4], g["effw_%s%d_rows" % (head, layer)])
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_decoder_and_embedding_vs_reference(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     specs, sd, lat, mano, obj = _inputs(tag)
     pts = torch.from_numpy(g["rand_pts"])
-    if tag == "both9":
+    if "embed_pts" in g.files:       # kinematic (both9) or NeRF (nerf9) point features
         e = orc.point_features(pts, specs, mano, obj).numpy()
-        assert np.abs(e - g["embed_pts"]).max() <= 1e-6
+        assert e.shape == g["embed_pts"].shape and np.abs(e - g["embed_pts"]).max() <= 1e-6
     h, o = orc.decode_points(sd, lat, pts, specs, mano, obj)
     assert np.abs(h.numpy() - g["rand_hand"]).max() <= 1e-6
     assert np.abs(o.numpy() - g["rand_obj"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_two_pass_flow_vs_reference(tag, golden_dir):
     """Full create_mesh_combined_decoder restatement at N=32: volumes, bbox, zoom cube."""
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))

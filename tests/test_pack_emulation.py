@@ -10,7 +10,7 @@ from oracle import sdf_oracle as orc
 from tests import kernel_emulator as emu
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_packed_stream_emulation_matches_oracle(tag, native_lib):
     specs, sd = syn.specs_for(tag), syn.full_state_dict(tag)
     pk = emu.pack_host(sd, specs["PointFeatSize"], specs["EncodeStyle"])
