@@ -110,7 +110,6 @@ using namespace asdf;
 
 struct asdf_decoder {
   asdf_decoder_spec_t spec;
-  int n1[ASDF_MAX_HEADS];
   int device;
   int num_cus;
   float* stream;    // [kStagesAll][kStageFloats]
@@ -120,7 +119,6 @@ struct asdf_decoder {
   float* cst;       // [heads][cst_offsets(kp).floats]  (static parts written at create time)
   int kp;           // point-feature K-steps: 2 (affine xyz) or ceil(pf / 2) (NeRF encoding)
   float* embed;     // [heads][MAXPF][4]
-  float* latent;    // last bound latent (device pointer owned by the caller)
   bool sample_bound;
 };
 
@@ -201,7 +199,6 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
 
   HostPack hp;
   if (!pack_decoder(*spec, heads, hp)) { delete d; return ASDF_ENOMEM; }
-  for (int h = 0; h < spec->num_heads; ++h) d->n1[h] = kHidden - kLatent - spec->point_feats[h];
   d->kp = hp.kp;
   std::vector<float>&stream = hp.stream, &wlat = hp.wlat, &wpt = hp.wpt, &b02 = hp.b02, &cst = hp.cst, &emb = hp.emb;
 
@@ -214,9 +211,10 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  for (const void* k : {(const void*)sdf_mlp_combined_kernel, (const void*)sdf_mlp_nerf9_kernel,
-                        (const void*)sdf_mlp_nerf15_kernel, (const void*)sdf_mlp_combined_nerf9_kernel,
-                        (const void*)sdf_mlp_combined_nerf15_kernel})
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sdf_mlp_combined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  for (const void* k : {(const void*)sdf_mlp_nerf9_kernel, (const void*)sdf_mlp_nerf15_kernel,
+                        (const void*)sdf_mlp_combined_nerf9_kernel, (const void*)sdf_mlp_combined_nerf15_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kMaxKP));
 
   if (e != hipSuccess) {
@@ -280,16 +278,16 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   p.pf = d->spec.point_feats[0];
-  const bool sep = p.num_mlps == 2;
+  const bool two_out = p.num_mlps == 1;     // CombinedDecoder: one MLP, two last-layer rows
   if (d->kp == 2) {
-    if (sep) hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
-    else hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
   } else if (d->kp == 5) {
-    if (sep) hipLaunchKernelGGL(sdf_mlp_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
-    else hipLaunchKernelGGL(sdf_mlp_combined_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
   } else {
-    if (sep) hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
-    else hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
   }
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;

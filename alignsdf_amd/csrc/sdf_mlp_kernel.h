@@ -15,10 +15,6 @@ __device__ __forceinline__ f32x16 relu16i(f32x16 v) {
   return v;
 }
 
-// sum of the two accumulator chains of a tile (DUAL = 1) or just the single chain
-template <int DUAL>
-__device__ __forceinline__ f32x16 chains(const f32x16& a, const f32x16& b) { return DUAL ? a + b : a; }
-
 struct NoEpilogue {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -29,8 +25,8 @@ struct NoEpilogue {
 // ABL is an ablation mask for tools/k1_ablate.hip (0 in the product; timing only, results invalid):
 // 1 = no DMA / vmcnt wait / barrier in the loop (ring filled once), 4 = tile epilogues skipped (accumulators kept
 // live), 8 = no layer 0, 16 = no s_barrier (DMA and waits kept).
-template <int KT, int Q, int SLOT, int ABL, int DUAL, class Epi>
-__device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&hin)[KT], const float* ring, const float* next_src,
+template <int KT, int Q, int SLOT, int ABL, class Epi>
+__device__ __forceinline__ void stage(f32x16& acc, const f32x16 (&hin)[KT], const float* ring, const float* next_src,
                                        unsigned lds_ring_base, int lane, int wave, f32x4& a0, f32x4& a1, Epi&& epi) {
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
   const float* src = next_src + wave * 1024 + lane * 4;
@@ -51,10 +47,9 @@ __device__ __forceinline__ void stage(f32x16& acc, f32x16& accb, const f32x16 (&
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int s = Q * 64 + g * 4 + j;
-      // two independent accumulator chains (even / odd K-steps): a dependent 32x32x2 MFMA issues ~5 cycles
-      // later than the 64-cycle pipe interval, an independent one does not
-      if (DUAL && (j & 1)) accb = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], accb);
-      else acc = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], acc);
+      // one dependent chain per tile: tools/mfma_issue_bench shows a chain fed with varying operands already
+      // issues at the pipe rate (65 cycles), and splitting it into two chains measured slower end to end
+      acc = ASDF_MFMA(abuf[g][j], hin[s >> 4][s & 15], acc);
       if (g == 8 && !(ABL & 1)) {
         // one DMA piece per MFMA shadow (an LDS-DMA issue costs about one 64-cycle MFMA slot); pinned so the
         // scheduler cannot cluster the four pieces behind a single MFMA
@@ -78,9 +73,12 @@ __device__ __forceinline__ float nerf_feature(int f, float x0, float x1, float x
   return r < 3 ? sinf(arg) : cosf(arg);
 }
 
-// MLPS = 2: SeparateDecoder (two MLPs, one output each); MLPS = 1: CombinedDecoder (one MLP, two outputs).
+// p.num_mlps = 2: SeparateDecoder (two MLPs, one output each); 1: CombinedDecoder (one MLP, two outputs).  The head loop
+// keeps a runtime trip count on purpose (with a compile-time single trip the compiler hoists ~1400 loop-invariant
+// values out of the tile loop and spills them); TWO_OUT selects, at compile time, whether the second last-layer row
+// is accumulated - it costs the single-output path 3.5 % when merely left in with zero weights.
 // KP = K-steps taken by the point features in layers 0 and 2: 2 = (affine) xyz, 5 / 8 = NeRF encoding of 9 / 15 features.
-template <int ABL, int DUAL, int MLPS, int KP>
+template <int ABL, int KP, bool TWO_OUT>
 __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
   constexpr bool kReloadCst = KP > 2;        // one head's constants in LDS at a time
@@ -98,7 +96,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
   // per-sample constants -> LDS (once per workgroup)
   if (!kReloadCst) {
-    for (int i = tid; i < MLPS * CL::kFloats / 4; i += 256)
+    for (int i = tid; i < p.num_mlps * CL::kFloats / 4; i += 256)
       reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
     __syncthreads();
   }
@@ -143,7 +141,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
     }
 
 #pragma unroll 1
-    for (int head = 0; head < MLPS; ++head) {
+    for (int head = 0; head < p.num_mlps; ++head) {
       const float* hc = cst + (kReloadCst ? 0 : head * CL::kFloats);
       if (kReloadCst) {
         // every wave is done with the previous head's constants -> refill the block -> publish
@@ -154,14 +152,12 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       }
       // source of stage (s + 3) relative to this MLP's first stage, wrapping to the next MLP in stream order
       const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
-      const float* swrap = p.stream + (size_t)(head + 1 == MLPS ? 0 : head + 1) * kStagesHead * kStageFloats;
+      const float* swrap = p.stream + (size_t)(head + 1 == p.num_mlps ? 0 : head + 1) * kStagesHead * kStageFloats;
       auto src_of = [&](int s) -> const float* {   // s = stage index within head + 3
         return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
       };
 
-      // ---- layer 0: K = 4 (xyz + zero pad), per-sample A fragments from LDS.  All 32 MFMAs are issued as
-      // independent 2-deep chains; the ReLU of tiles 0-3 (consumed by the first layer-1 stage) follows, the
-      // ReLUs of tiles 4-15 ride in the MFMA shadows of layer 1's first tile (stage Q needs tiles 4Q..4Q+3).
+      // ---- layer 0: K = 2 KP point features (xyz + zero pad, or the NeRF encoding), per-sample A fragments from LDS
       f32x16 h0[kTilesHidden];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
@@ -170,58 +166,45 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 #pragma unroll
           for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
         }
-        h0[t] = acc;
+        h0[t] = (ABL & 8) ? acc : relu16i(acc);
       }
-      auto relu_h0 = [&](int first) {
-        if (ABL & 8) return;
-#pragma unroll
-        for (int t = first; t < first + 4; ++t) h0[t] = relu16i(h0[t]);
-      };
-      relu_h0(0);
 
 #define ASDF_STAGE(KT, Q, SLOT, ACC, HIN, SIDX, EPI) \
-  stage<KT, Q, SLOT, ABL, DUAL>(ACC, ACC##b, HIN, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, a0, a1, EPI)
+  stage<KT, Q, SLOT, ABL>(ACC, HIN, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, a0, a1, EPI)
 
       // ---- layer 1: 512 -> 256 (rows >= n1 are zero padding); epilogue of tile t-1 rides in tile t
       f32x16 h1[kTilesL1];
       if (ABL & 4) for (int t = 0; t < kTilesL1; ++t) h1[t] = h0[t];
-      f32x16 acc1[2], acc1b[2];
-      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc1[2];
 #pragma unroll
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
-        f32x16& accb = acc1b[t & 1];
         acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
-        accb = zero16;
         auto epi = [&]() {
-          if (t == 0) { relu_h0(4); return; }
+          if (t == 0) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          h1[t - 1] = relu16i(chains<DUAL>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1]));
+          h1[t - 1] = relu16i(acc1[(t - 1) & 1]);
         };
-        auto epi1 = [&]() { if (t == 0) relu_h0(8); };
-        auto epi2 = [&]() { if (t == 0) relu_h0(12); };
         ASDF_STAGE(16, 0, 0, acc, h0, t * 4 + 0, epi);
-        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, epi1);
-        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, epi2);
+        ASDF_STAGE(16, 1, 1, acc, h0, t * 4 + 1, NoEpilogue());
+        ASDF_STAGE(16, 2, 2, acc, h0, t * 4 + 2, NoEpilogue());
         ASDF_STAGE(16, 3, 3, acc, h0, t * 4 + 3, NoEpilogue());
       }
 
       // ---- layer 2: [h1 (256) | xyz (4)] -> 512
       f32x16 h2[kTilesHidden];
       if (ABL & 4) for (int t = 0; t < kTilesHidden; ++t) h2[t] = h0[t];
-      f32x16 acc2[2], acc2b[2];
+      f32x16 acc2[2];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc2[t & 1];
-        f32x16& accb = acc2b[t & 1];
         acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
-        if (DUAL) accb = zero16;
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
         auto epi = [&]() {
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
-          if (t > 0) h2[t - 1] = relu16i(chains<DUAL>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1]));
-          else h1[kTilesL1 - 1] = relu16i(chains<DUAL>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1]));   // consumed by K-steps >= 112
+          if (t > 0) h2[t - 1] = relu16i(acc2[(t - 1) & 1]);
+          else h1[kTilesL1 - 1] = relu16i(acc1[(kTilesL1 - 1) & 1]);   // consumed by K-steps >= 112
         };
         constexpr int S0 = kStagesL1;
         if (t & 1) {
@@ -235,27 +218,32 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4) and tanh
       float part = 0.0f, partb = 0.0f;      // partb: second output row (CombinedDecoder; its weights are 0 otherwise)
-      f32x16 acc3[2], acc3b[2];
+      f32x16 acc3[2];
       auto dot_w4 = [&](const f32x16 a, int t) {
-        const f32x16 w = load_bias16(hc + CL::kW4 + (t * 2 + half) * 16);
+        // 4 registers at a time: keeps the two weight rows out of long-lived registers
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(hc + CL::kW4 + (t * 2 + half) * 16);
+        const f32x4* w4b = reinterpret_cast<const f32x4*>(hc + CL::kW4b + (t * 2 + half) * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), w[r], part);
-        if (MLPS == 1) {
-          const f32x16 wb = load_bias16(hc + CL::kW4b + (t * 2 + half) * 16);
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 w = w4[c];
+          f32x4 wb = w;
+          if (TWO_OUT) wb = w4b[c];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) partb = fmaf(__int_as_float(max(__float_as_int(a[r]), 0)), wb[r], partb);
+          for (int r = 0; r < 4; ++r) {
+            const float v = __int_as_float(max(__float_as_int(a[c * 4 + r]), 0));
+            part = fmaf(v, w[r], part);
+            if (TWO_OUT) partb = fmaf(v, wb[r], partb);
+          }
         }
       };
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
-        f32x16& accb = acc3b[t & 1];
         acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
-        accb = zero16;
         auto epi = [&]() {
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
-          if (t > 0) dot_w4(chains<DUAL>(acc3[(t - 1) & 1], acc3b[(t - 1) & 1]), t - 1);
-          else h2[kTilesHidden - 1] = relu16i(chains<DUAL>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1]));   // consumed by K-steps >= 240
+          if (t > 0) dot_w4(acc3[(t - 1) & 1], t - 1);
+          else h2[kTilesHidden - 1] = relu16i(acc2[(kTilesHidden - 1) & 1]);   // consumed by K-steps >= 240
         };
         constexpr int S0 = kStagesL1 + kStagesL2;
         ASDF_STAGE(16, 0, 0, acc, h2, S0 + t * 4 + 0, epi);
@@ -263,12 +251,13 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         ASDF_STAGE(16, 2, 2, acc, h2, S0 + t * 4 + 2, NoEpilogue());
         ASDF_STAGE(16, 3, 3, acc, h2, S0 + t * 4 + 3, NoEpilogue());
       }
-      dot_w4(chains<DUAL>(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1]), kTilesHidden - 1);
+      dot_w4(acc3[(kTilesHidden - 1) & 1], kTilesHidden - 1);
 #undef ASDF_STAGE
       part += __shfl_xor(part, 32);
       const float sdf = tanhf(part + hc[CL::kB4]);
+      const bool combined = TWO_OUT && p.num_mlps == 1;
       float sdfb = 1.0f;
-      if (MLPS == 1) {
+      if (combined) {
         partb += __shfl_xor(partb, 32);
         sdfb = tanhf(partb + hc[CL::kB4 + 1]);
       }
@@ -277,7 +266,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
         if (out) out[pi] = sdf;
-        if (MLPS == 1 && p.sdf1) p.sdf1[pi] = sdfb;
+        if (combined && p.sdf1) p.sdf1[pi] = sdfb;
       }
       if (p.bbox && valid && half == 0 && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
@@ -285,7 +274,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
           bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
         }
-        if ((!is_hand && sdf < 0.0f) || (MLPS == 1 && sdfb < 0.0f)) {
+        if ((!is_hand && sdf < 0.0f) || (combined && sdfb < 0.0f)) {
           omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
           omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
         }
@@ -308,12 +297,12 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 2>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 2>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, true>(p); }
 // NeRF positional encoding of the query point (PointFeatSize 9 / 15 without pose alignment, utils/mesh.py:53-55)
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 5>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 2, 8>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 5>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 0, 1, 8>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
 
 }  // namespace asdf

@@ -9,7 +9,7 @@ using namespace asdf;
 #ifndef ABL_LIST
 #define ABL_LIST X(0) X(1) X(16) X(4) X(8) X(13)
 #endif
-#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { sdf_mlp_body<n, 0, 2, 2>(p); }
+#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { sdf_mlp_body<n, 2, false>(p); }
 ABL_LIST
 #undef X
 int main(int argc, char** argv) {
