@@ -269,16 +269,24 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (!d->sample_bound) return ASDF_EINVAL;
   p.stream = d->stream;
   p.cst = d->cst;
+  // a SeparateDecoder head whose output pointer is NULL is not evaluated at all (the reference always runs both,
+  // networks/model.py:304-344, and discards one when HandBranch / ObjectBranch is off)
+  p.first_mlp = 0;
   p.num_mlps = d->spec.num_heads;
+  const bool two_out = d->spec.num_heads == 1;     // CombinedDecoder: one MLP, two last-layer rows
   if (p.bbox) {
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
     ASDF_HIP(hipGetLastError());
+  }
+  if (!two_out) {
+    if (!p.sdf0 && !p.sdf1) return ASDF_OK;
+    if (!p.sdf1) p.num_mlps = 1;
+    else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
   }
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   p.pf = d->spec.point_feats[0];
-  const bool two_out = p.num_mlps == 1;     // CombinedDecoder: one MLP, two last-layer rows
   if (d->kp == 2) {
     if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
     else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);

@@ -50,7 +50,8 @@ struct DecodeParams {
   int mode;
   float vs;                 // voxel size (fp32, as the reference rounds it)
   float o0, o1, o2;         // origin added to axis-0/1/2 coordinates
-  int num_mlps;             // 2 = SeparateDecoder (one output each), 1 = CombinedDecoder (two outputs)
+  int num_mlps;             // MLPs to evaluate: 2 = both heads of a SeparateDecoder, 1 = one head or a CombinedDecoder
+  int first_mlp;            // index of the first MLP to evaluate (1 = object head only)
   int pf;                   // raw point-feature count (NeRF-feature kernels only)
 };
 

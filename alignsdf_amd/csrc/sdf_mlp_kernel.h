@@ -96,8 +96,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
   // per-sample constants -> LDS (once per workgroup)
   if (!kReloadCst) {
-    for (int i = tid; i < p.num_mlps * CL::kFloats / 4; i += 256)
-      reinterpret_cast<f32x4*>(cst)[i] = reinterpret_cast<const f32x4*>(p.cst)[i];
+    // the evaluated MLPs' blocks are packed to the front of the LDS area
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)p.first_mlp * CL::kFloats);
+    for (int i = tid; i < p.num_mlps * CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
     __syncthreads();
   }
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   // prologue: stages 0..2 in flight
 #pragma unroll
   for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
-    const float* src = p.stream + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
+    const float* src = p.stream + ((size_t)p.first_mlp * kStagesHead + s) * kStageFloats + wave * 1024 + lane * 4;
     const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
@@ -141,8 +142,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
     }
 
 #pragma unroll 1
-    for (int head = 0; head < p.num_mlps; ++head) {
-      const float* hc = cst + (kReloadCst ? 0 : head * CL::kFloats);
+    for (int slot = 0; slot < p.num_mlps; ++slot) {
+      const int head = p.first_mlp + slot;                 // which MLP of the decoder this iteration evaluates
+      const float* hc = cst + (kReloadCst ? 0 : slot * CL::kFloats);
       if (kReloadCst) {
         // every wave is done with the previous head's constants -> refill the block -> publish
         __builtin_amdgcn_s_barrier();
@@ -152,7 +154,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       }
       // source of stage (s + 3) relative to this MLP's first stage, wrapping to the next MLP in stream order
       const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
-      const float* swrap = p.stream + (size_t)(head + 1 == p.num_mlps ? 0 : head + 1) * kStagesHead * kStageFloats;
+      const float* swrap = p.stream + (size_t)(slot + 1 == p.num_mlps ? p.first_mlp : head + 1) * kStagesHead * kStageFloats;
       auto src_of = [&](int s) -> const float* {   // s = stage index within head + 3
         return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
       };
@@ -255,7 +257,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 #undef ASDF_STAGE
       part += __shfl_xor(part, 32);
       const float sdf = tanhf(part + hc[CL::kB4]);
-      const bool combined = TWO_OUT && p.num_mlps == 1;
+      const bool combined = TWO_OUT;
       float sdfb = 1.0f;
       if (combined) {
         partb += __shfl_xor(partb, 32);

@@ -185,16 +185,19 @@ class HipSdfDecoder:
             if emb_ptr is not None:
                 torch.cuda.current_stream(self.device).synchronize()   # host staging buffer is pageable
 
-    def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True):
-        """Both heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None),
-        all device tensors."""
-        hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device)
-        obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device)
+    def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True):
+        """Heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None), all device
+        tensors; a head switched off (`hand` / `obj` False, SeparateDecoder only) is not evaluated and returns None."""
+        if self.combined:
+            hand = obj = True
+        hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
+        obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
         bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
         with torch.cuda.device(self.device):
             _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
-                                                   int(grid_mode), hand.data_ptr(), obj.data_ptr(),
+                                                   int(grid_mode), hand.data_ptr() if hand is not None else None,
+                                                   obj.data_ptr() if obj is not None else None,
                                                    bbox.data_ptr() if want_bbox else None, self._stream()),
                           "asdf_decode_grid")
         return hand, obj, bbox

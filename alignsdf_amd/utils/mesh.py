@@ -114,7 +114,9 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, hip.combined))
     mode = GRID_MODES[grid_mode]
     voxel_size = 2.0 / (N - 1)
-    _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode)
+    # a branch that is switched off is neither meshed nor used for the zoom cube (utils/mesh.py:239-247), so its
+    # head is not evaluated at all (the reference computes and discards it)
+    _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
     b = bbox.cpu().numpy()
     boxes = []
     if hand_branch:
@@ -122,7 +124,8 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     if obj_branch:
         boxes.append((b[8:11], b[11:14], int(b[14])))
     new_voxel_size, new_origin = zoom_cube_from_bboxes(boxes, N, voxel_size)
-    vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False)
+    vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False,
+                                           hand=hand_branch, obj=obj_branch)
     return {"vol_hand": vol_hand, "vol_obj": vol_obj, "voxel_size": new_voxel_size, "origin": new_origin.tolist(), "bbox": b}
 
 

@@ -90,7 +90,8 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
 
 /* Evaluate both heads on the N^3 lattice
  *     coord[a] = idx[a] * voxel_size + origin[a]     (fp32 mul then add, a = 0,1,2; axis 2 fastest)
- * writing sdf_hand[N^3], sdf_obj[N^3] (device; either may be NULL) and, if bbox_dev != NULL, the
+ * writing sdf_hand[N^3], sdf_obj[N^3] (device; either may be NULL - a SeparateDecoder head whose output is NULL is
+ * not evaluated, and its bbox record stays empty) and, if bbox_dev != NULL, the
  * per-head bounding box of negative voxels as int32[16]:
  *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels.
  * Replaces one pass of utils/mesh.py:27-63 (or :82-115) plus the nonzero/min/max of

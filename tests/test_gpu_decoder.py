@@ -115,3 +115,33 @@ def test_linearity_of_lattice_full_size():
     hp, op = dec.decode_points(c[sel])
     assert torch.equal(h.reshape(-1)[sel.cuda()], hp) and torch.equal(o.reshape(-1)[sel.cuda()], op)
     assert int(bbox[6]) == int((h < 0).sum()) and int(bbox[14]) == int((o < 0).sum())
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "nerf9"])
+def test_single_head_evaluation_matches_both_heads(tag):
+    """A head whose output is not requested is skipped; the other one must be bit-identical to the two-head run."""
+    dec, *_ = _setup(tag)
+    N = 40
+    h, o, b = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+    h1, none_o, b1 = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1), obj=False)
+    none_h, o2, b2 = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1), hand=False)
+    assert none_o is None and none_h is None
+    assert torch.equal(h1, h) and torch.equal(o2, o)
+    b, b1, b2 = b.cpu().numpy(), b1.cpu().numpy(), b2.cpu().numpy()
+    assert list(b1[0:7]) == list(b[0:7]) and b1[14] == 0 and list(b1[8:11]) == [0x7fffffff] * 3
+    assert list(b2[8:15]) == list(b[8:15]) and b2[6] == 0
+
+
+def test_hand_only_two_pass_matches_oracle():
+    """HandBranch only: zoom cube from the hand volume alone (utils/mesh.py:239-241), object head not evaluated."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from oracle import sdf_oracle as orc
+    specs, sd = syn.specs_for("nerf3"), syn.full_state_dict("nerf3")
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in sd.items()})
+    lat = torch.from_numpy(syn.latent_code(2))
+    r = decode_two_pass(True, False, dec, lat.cuda(), None, None, specs, 32)
+    ref = orc.two_pass_volumes(sd, lat, specs, 32, hand_branch=True, obj_branch=False)
+    assert r["vol_obj"] is None
+    assert torch.equal(r["voxel_size"], ref["new_voxel_size"]) and r["origin"] == ref["new_origin"].tolist()
+    assert (r["vol_hand"].cpu() - ref["vol_hand2"]).abs().max().item() <= TOL

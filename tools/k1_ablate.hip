@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipMalloc(&cst, c.size() * 4); hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
   hipMalloc(&o0, P * 4); hipMalloc(&o1, P * 4);
   DecodeParams p{}; p.stream = stream; p.cst = cst; p.sdf0 = o0; p.sdf1 = o1; p.P = P; p.N = N; p.mode = kGridReference;
-  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2;
+  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double flop = (double)P * 2 * 1057792.0;
 #define X(n) { hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes); \
