@@ -143,6 +143,7 @@ class HipSdfDecoder:
         self._L = L
         self._pf = pf
         self._latent = None
+        self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
 
     def close(self):
         if getattr(self, "_h", None):
@@ -168,22 +169,26 @@ class HipSdfDecoder:
             if embed is not None:
                 raise ValueError("a NeRF-encoded decoder takes raw xyz; no affine embedding applies")
         elif embed is not None:
-            buf = np.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=np.float32)
+            # pinned staging ring: the H2D copy is asynchronous, so a slot must outlive the samples in flight (<= 2)
+            if not hasattr(self, "_emb_ring"):
+                self._emb_ring = [torch.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=torch.float32).pin_memory() for _ in range(6)]
+                self._emb_next = 0
+            slot = self._emb_ring[self._emb_next % len(self._emb_ring)]
+            self._emb_next += 1
+            buf = slot.numpy()
+            buf[:] = 0
             for h in range(len(self._pf)):
                 e = np.asarray(embed[h], dtype=np.float64)
                 if e.shape != (self._pf[h], 4):
                     raise ValueError("embedding of head %d has shape %s, expected %s" % (h, e.shape, (self._pf[h], 4)))
                 buf[h, :self._pf[h]] = e.astype(np.float32)
-            emb_ptr = buf.ctypes.data_as(ctypes.c_void_p)
-            self._emb_keep = buf
+            emb_ptr = ctypes.c_void_p(slot.data_ptr())
         elif not self.nerf_features and any(f != 3 for f in self._pf):
             raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
         self._latent = lat   # keep the device buffer alive until the next set_sample
         with torch.cuda.device(self.device):
             _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
                           "asdf_decoder_set_sample")
-            if emb_ptr is not None:
-                torch.cuda.current_stream(self.device).synchronize()   # host staging buffer is pageable
 
     def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True):
         """Heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None), all device
@@ -195,11 +200,17 @@ class HipSdfDecoder:
         bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
         with torch.cuda.device(self.device):
+            if self.event_log is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
                                                    int(grid_mode), hand.data_ptr() if hand is not None else None,
                                                    obj.data_ptr() if obj is not None else None,
                                                    bbox.data_ptr() if want_bbox else None, self._stream()),
                           "asdf_decode_grid")
+            if self.event_log is not None:
+                ev[1].record()
+                self.event_log.append(ev)
         return hand, obj, bbox
 
     def decode_points(self, xyz):

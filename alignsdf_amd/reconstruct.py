@@ -50,6 +50,66 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference"):
+    """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
+    generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
+    marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
+
+    Per sample the GPU work is  pass 1 -> [64-byte bbox readback, zoom cube on the host] -> pass 2 -> marching cubes,
+    and only the bracketed step and the MC size readbacks synchronise with the host.  Pass 1 of sample k+1 is queued
+    right behind pass 2 of sample k, i.e. before sample k's marching cubes and before the consumer's host work
+    (D2H copy, component filter, PLY export), so the GPU never waits for the host between samples."""
+    from .marching_cubes import marching_cubes_device
+    from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
+    from .utils.utils import hip_decoder_for, sample_embedding
+    hip = hip_decoder_for(decoder)
+    hb, ob = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
+    mode = GRID_MODES[grid_mode]
+    voxel = 2.0 / (N - 1)
+
+    def first_pass(sample):
+        _, latent, mano, obj = sample
+        hip.set_sample(latent, sample_embedding(specs, mano, obj, hip.combined))
+        return hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)[2]
+
+    def second_pass(bbox):
+        b = bbox.cpu().numpy()                          # waits for pass 1: the zoom cube is data dependent
+        boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
+        nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
+        vh, vo, _ = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=False, hand=hb, obj=ob)
+        return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b}
+
+    def surfaces(r):
+        for part, on in (("hand", hb), ("obj", ob)):
+            r["V_" + part] = r["F_" + part] = 0
+            if on:
+                try:
+                    v, f = marching_cubes_device(r["vol_" + part], 0.0)
+                except (ValueError, RuntimeError) as e:         # the reference logs and skips (utils/mesh.py:353-358)
+                    r["mc_error_" + part] = str(e)
+                    continue
+                r["verts_" + part], r["faces_" + part] = v, f
+                r["V_" + part], r["F_" + part] = v.shape[0], f.shape[0]
+
+    it = iter(samples)
+    cur = next(it, None)
+    if cur is None:
+        return
+    r = second_pass(first_pass(cur))
+    nxt = next(it, None)
+    bbox_next = first_pass(nxt) if nxt is not None else None
+    while True:
+        surfaces(r)                                     # MC of sample k, queued behind pass 1 of sample k+1
+        if nxt is not None:
+            r_next = second_pass(bbox_next)
+            after = next(it, None)
+            bbox_after = first_pass(after) if after is not None else None
+        yield cur[0], r
+        if nxt is None:
+            return
+        cur, r, nxt, bbox_next = nxt, r_next, after, bbox_after
+
+
 def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
                        eval_mode=False, task="obman", scale=None):
     """One sample through the hot path.  Returns a record dict; writes <mesh_filename>_hand.ply / _obj.ply when
@@ -102,14 +162,29 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         decoder = getattr(decoder, attr, decoder)
     if code_source is None:
         code_source = synthetic_code_source("nerf3" if specs["PointFeatSize"] == 3 else "both9", device)
-    records = []
-    with torch.no_grad():
+    def samples():
         for k, path in enumerate(names):
             name = path.split("/")[-1].split(".")[0]                       # reconstruct.py:78
             latent, mano_results, obj_results = code_source(name, int(start_point) + k)
-            rec = reconstruct_sample(decoder, specs, latent, mano_results, obj_results, cube_dim, os.path.join(mesh_dir, name),
-                                     grid_mode, eval_mode, task, scale)
-            rec["index"], rec["name"] = int(start_point) + k, name
+            yield (int(start_point) + k, name), latent, mano_results, obj_results
+
+    records = []
+    with torch.no_grad():
+        t_prev = time.perf_counter()
+        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode):
+            rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
+                   "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
+            for part, sc in (("hand", None), ("obj", scale)):
+                if "verts_" + part in r:
+                    mesh_utils.export_surface(r["verts_" + part], r["faces_" + part], r["origin"], r["voxel_size"],
+                                              os.path.join(mesh_dir, "%s_%s.ply" % (name, part)), None, sc,
+                                              eval_mode and part == "hand", task)
+                elif "mc_error_" + part in r:
+                    import logging
+                    logging.warning("Cannot reconstruct mesh from '{}'".format(os.path.join(mesh_dir, "%s_%s.ply" % (name, part))))
+                    print(r["mc_error_" + part])
+            now = time.perf_counter()
+            rec["seconds"], t_prev = now - t_prev, now
             records.append(rec)
     return records
 

@@ -62,13 +62,9 @@ def get_higher_res_cube(hand_branch, obj_branch, sdf_values_hand, sdf_values_obj
     return zoom_cube_from_bboxes(boxes, N, voxel_size)
 
 
-def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None):
-    """MC + the vertex arithmetic of utils/mesh.py:354-369 (spacing, origin, optional scale / offset).
-    Returns (verts, faces, mesh_points) as host arrays; raises like skimage on failure."""
-    vol = sdf if isinstance(sdf, torch.Tensor) else torch.as_tensor(np.asarray(sdf))
-    if not vol.is_cuda:
-        vol = vol.cuda()
-    verts_d, faces_d = marching_cubes_device(vol, 0.0)
+def place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset=None, scale=None):
+    """Device MC output -> host arrays with the vertex arithmetic of utils/mesh.py:354-369 (spacing, origin, optional
+    scale / offset).  Returns (verts, faces, mesh_points)."""
     verts, faces = verts_d.cpu().numpy(), faces_d.cpu().numpy()
     vs = voxel_size.item() if isinstance(voxel_size, torch.Tensor) else voxel_size
     spacing = [np.float32(vs)] * 3 if isinstance(voxel_size, torch.Tensor) else [vs] * 3
@@ -82,6 +78,28 @@ def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None)
     if offset is not None:
         mesh_points = mesh_points + offset
     return verts, faces, mesh_points
+
+
+def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None):
+    """MC on the device + place_vertices.  Raises like skimage on failure."""
+    vol = sdf if isinstance(sdf, torch.Tensor) else torch.as_tensor(np.asarray(sdf))
+    if not vol.is_cuda:
+        vol = vol.cuda()
+    verts_d, faces_d = marching_cubes_device(vol, 0.0)
+    return place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+
+
+def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
+                   task="obman", largest_component=True):
+    """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397)."""
+    verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+    if eval_mode:
+        logging.warning("eval_mode ICP alignment (utils/mesh.py:385-395) is not part of this build; writing the unaligned mesh")
+    if ply_filename_out:
+        os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
+        out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
+        write_ply(ply_filename_out, out_v, out_f)
+    return verts, faces
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
