@@ -103,11 +103,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks: ASDF_BENCH_BACKEND=gloo and ASDF_BENCH_SHARE_DEVICE=1 let several ranks share one GPU so that the
+    # multi-rank path can be exercised on a single-GPU box; the driver's runs use RCCL with one GPU per rank
+    backend = os.environ.get("ASDF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("ASDF_BENCH_SHARE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from alignsdf_amd.hip_decoder import HipSdfDecoder
     from alignsdf_amd.reconstruct import pipelined_two_pass
@@ -156,7 +160,7 @@ def main():
     records = [dict(index=rank * args.steps + k, V_hand=d[1], F_hand=d[2], V_obj=d[3], F_obj=d[4], milliseconds=0.0)
                for k, d in enumerate(done)]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         from alignsdf_amd.dist_reconstruct import gather_records
