@@ -27,9 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 4;
 constexpr int kLdsRingFloats = kRing * kStageFloats;                 // 64 KiB
-// xyz-feature kernels keep both heads' constants resident; NeRF-feature kernels (KP > 2) hold one head's
-// (larger) block and reload it when they switch heads
-constexpr int lds_bytes(int kp) { return (kLdsRingFloats + (kp == 2 ? kHeads * kCstFloats : cst_offsets(kp).floats)) * 4; }
+// LDS = weight ring + the constants block of the MLP being evaluated
+constexpr int lds_bytes(int kp) { return (kLdsRingFloats + cst_offsets(kp).floats) * 4; }
 constexpr int kLdsBytes = lds_bytes(2);
 
 enum GridMode : int {

@@ -81,7 +81,6 @@ __device__ __forceinline__ float nerf_feature(int f, float x0, float x1, float x
 template <int ABL, int KP, bool TWO_OUT>
 __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
-  constexpr bool kReloadCst = KP > 2;        // one head's constants in LDS at a time
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
   float* cst = smem + kLdsRingFloats;
@@ -94,69 +93,64 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   if ((long long)blockIdx.x >= ntiles) return;
 
-  // per-sample constants -> LDS (once per workgroup)
-  if (!kReloadCst) {
-    // the evaluated MLPs' blocks are packed to the front of the LDS area
-    const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)p.first_mlp * CL::kFloats);
-    for (int i = tid; i < p.num_mlps * CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
-    __syncthreads();
-  }
-
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
 
-  // prologue: stages 0..2 in flight
-#pragma unroll
-  for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
-    const float* src = p.stream + ((size_t)p.first_mlp * kStagesHead + s) * kStageFloats + wave * 1024 + lane * 4;
-    const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
-  }
-  if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0
-  __builtin_amdgcn_s_barrier();                         // everybody's pieces of stage 0
-  f32x4 a0 = (reinterpret_cast<const f32x4*>(ring) + lane)[0];
-  f32x4 a1 = (reinterpret_cast<const f32x4*>(ring) + lane)[64];
-
-  int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1;
-  int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1;
-  int bcnt = 0, ocnt = 0;
-
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
-    const bool valid = pi < p.P;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (p.mode == kPointList) {
-      if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
-    } else {
-      grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+  // Head-outer, tile-inner: one MLP's 2 MiB weight stream is live at a time, so it stays resident in the 4 MiB
+  // per-XCD L2 (both heads interleaved per tile thrash it: ~10 GB of refills per N=256 launch).
+#pragma unroll 1
+  for (int slot = 0; slot < p.num_mlps; ++slot) {
+    const int head = p.first_mlp + slot;                 // which MLP of the decoder this iteration evaluates
+    const float* hc = cst;
+    // negative-voxel bounding box of this MLP's output(s): per-lane accumulators, flushed once per head
+    int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1, bcnt = 0;
+    int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1, ocnt = 0;   // TWO_OUT only
+    // (re)start: every wave is done with the previous head's constants and ring slots, and its own wrapped
+    // prefetches have landed -> load this head's constants, restart the DMA ring on this head's stream
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
+      for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
     }
-    // B operands of the point-feature K-steps: lane half h supplies feature 2 s + h of K-step s
-    float bp[KP];
-    if (KP == 2) {
-      bp[0] = half ? x1 : x0;
-      bp[1] = half ? 0.0f : x2;
-    } else {
+    const float* sbase0 = p.stream + (size_t)head * kStagesHead * kStageFloats;
 #pragma unroll
-      for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
+    for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
+      const float* src = sbase0 + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
+      const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
     }
+    if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0 (and my constants loads)
+    __syncthreads();                                      // everybody's pieces of stage 0, and the constants
+    f32x4 a0 = (reinterpret_cast<const f32x4*>(ring) + lane)[0];
+    f32x4 a1 = (reinterpret_cast<const f32x4*>(ring) + lane)[64];
 
 #pragma unroll 1
-    for (int slot = 0; slot < p.num_mlps; ++slot) {
-      const int head = p.first_mlp + slot;                 // which MLP of the decoder this iteration evaluates
-      const float* hc = cst + (kReloadCst ? 0 : slot * CL::kFloats);
-      if (kReloadCst) {
-        // every wave is done with the previous head's constants -> refill the block -> publish
-        __builtin_amdgcn_s_barrier();
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
-        for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
-        __syncthreads();
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
+      const bool valid = pi < p.P;
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      if (p.mode == kPointList) {
+        if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
+      } else {
+        grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       }
-      // source of stage (s + 3) relative to this MLP's first stage, wrapping to the next MLP in stream order
-      const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
-      const float* swrap = p.stream + (size_t)(slot + 1 == p.num_mlps ? p.first_mlp : head + 1) * kStagesHead * kStageFloats;
-      auto src_of = [&](int s) -> const float* {   // s = stage index within head + 3
-        return s < kStagesHead ? sbase + (size_t)s * kStageFloats : swrap + (size_t)(s - kStagesHead) * kStageFloats;
+      // B operands of the point-feature K-steps: lane half h supplies feature 2 s + h of K-step s
+      float bp[KP];
+      if (KP == 2) {
+        bp[0] = half ? x1 : x0;
+        bp[1] = half ? 0.0f : x2;
+      } else {
+#pragma unroll
+        for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
+      }
+      // source of stage (s + 3) of this head's stream, wrapping to its start for the next tile; the base is made
+      // opaque per tile so that the 128 x 4 per-lane source addresses are not hoisted out of the tile loop (spills)
+      const float* sbase = sbase0;
+      asm volatile("" : "+s"(sbase));
+      auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3
+        return sbase + (size_t)(s < kStagesHead ? s : s - kStagesHead) * kStageFloats;
       };
 
       // ---- layer 0: K = 2 KP point features (xyz + zero pad, or the NeRF encoding), per-sample A fragments from LDS
@@ -272,31 +266,37 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       }
       if (p.bbox && valid && half == 0 && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
-        if (is_hand && sdf < 0.0f) {
+        if (sdf < 0.0f) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
           bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
         }
-        if ((!is_hand && sdf < 0.0f) || (combined && sdfb < 0.0f)) {
+        if (combined && sdfb < 0.0f) {
           omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
           omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
         }
       }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }   // tiles
 
-  if (p.bbox) {
-    if (bcnt) {
-      atomicMin(p.bbox + 0, bmin0); atomicMin(p.bbox + 1, bmin1); atomicMin(p.bbox + 2, bmin2);
-      atomicMax(p.bbox + 3, bmax0); atomicMax(p.bbox + 4, bmax1); atomicMax(p.bbox + 5, bmax2);
-      atomicAdd(p.bbox + 6, bcnt);
+    if (p.bbox) {
+      // one set of atomics per wave: record 0 = hand (MLP 0 / first row), record 1 = object (MLP 1 / second row)
+      auto flush = [&](int* rec, int a0_, int a1_, int a2_, int b0_, int b1_, int b2_, int n) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          a0_ = min(a0_, __shfl_xor(a0_, m)); a1_ = min(a1_, __shfl_xor(a1_, m)); a2_ = min(a2_, __shfl_xor(a2_, m));
+          b0_ = max(b0_, __shfl_xor(b0_, m)); b1_ = max(b1_, __shfl_xor(b1_, m)); b2_ = max(b2_, __shfl_xor(b2_, m));
+          n += __shfl_xor(n, m);
+        }
+        if (lane == 0 && n) {
+          atomicMin(rec + 0, a0_); atomicMin(rec + 1, a1_); atomicMin(rec + 2, a2_);
+          atomicMax(rec + 3, b0_); atomicMax(rec + 4, b1_); atomicMax(rec + 5, b2_);
+          atomicAdd(rec + 6, n);
+        }
+      };
+      flush(p.bbox + (head == 0 ? 0 : 8), bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, bcnt);
+      if (TWO_OUT) flush(p.bbox + 8, omin0, omin1, omin2, omax0, omax1, omax2, ocnt);
     }
-    if (ocnt) {
-      atomicMin(p.bbox + 8, omin0); atomicMin(p.bbox + 9, omin1); atomicMin(p.bbox + 10, omin2);
-      atomicMax(p.bbox + 11, omax0); atomicMax(p.bbox + 12, omax1); atomicMax(p.bbox + 13, omax2);
-      atomicAdd(p.bbox + 14, ocnt);
-    }
-  }
+  }   // MLPs
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false>(p); }

@@ -138,7 +138,7 @@ def main():
     # the product's sample pipeline (alignsdf_amd.reconstruct.pipelined_two_pass): pass 1 of sample k+1 is queued
     # before the host-synchronous marching cubes of sample k; each call below runs `count` whole samples to completion
     def run(first, count):
-        out = []
+        out, last = [], None
         for i, r in pipelined_two_pass(dec, specs, sample_stream(first, count), N):
             out.append((i, r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"]))
             last = r
