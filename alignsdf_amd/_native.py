@@ -22,7 +22,8 @@ ENOSURF = -7
 EXPORTS = (
     "asdf_version", "asdf_strerror", "asdf_last_hip_error", "asdf_device_count", "asdf_decoder_create",
     "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_points", "asdf_neg_bbox",
-    "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_debug_pack_host",
+    "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_icp_workspace_bytes", "asdf_icp_ts",
+    "asdf_debug_pack_host",
 )
 
 
@@ -71,6 +72,9 @@ def lib():
     L.asdf_mc_count.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32),
                                 ctypes.POINTER(ctypes.c_uint32), vp]
     L.asdf_mc_emit.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, vp, vp, vp]
+    L.asdf_icp_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.asdf_icp_ts.argtypes = [vp, i32, vp, i32, i32, ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t,
+                              ctypes.POINTER(ctypes.c_double), vp]
     L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
     _lib = L
     return L

@@ -1,0 +1,91 @@
+"""Eval-mode translate + scale ICP (utils/mesh.py:385-395, deep_sdf/metrics/icp_trans_scale.py) on the GPU.
+
+The reference aligns the predicted hand mesh to the ground-truth mesh before export: 30 000 area-weighted surface
+samples per mesh (`trimesh.sample.sample_surface`, UNSEEDED in the reference - here a seeded counter-based generator,
+so runs are reproducible), normalisation of the source samples onto the target's centroid / RMS radius, then up to
+100 iterations of {nearest target of every source sample, nearest source of every target sample, 4-unknown least
+squares}.  The iteration runs in libalignsdf_hip.so (asdf_icp_ts: fp64 brute-force nearest neighbours, K7); sampling,
+the normalisation and the final vertex transform are O(30k) host numpy.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native, synthetic
+
+
+def load_obj(path):
+    """Minimal Wavefront OBJ reader: (verts float64 [V,3], faces int64 [F,3]); polygons are fan-triangulated."""
+    verts, faces = [], []
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith("v "):
+                verts.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+def sample_surface(verts, faces, count, seed=0):
+    """`count` area-weighted uniform samples of a triangle mesh (the scheme of trimesh.sample.sample_surface: pick faces
+    by cumulative area, reflect barycentric pairs whose sum exceeds 1), driven by the repo's seeded generator."""
+    v = np.asarray(verts, dtype=np.float64)
+    f = np.asarray(faces, dtype=np.int64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    cum = np.cumsum(area)
+    pick = np.searchsorted(cum, synthetic.uniform((count,), 9100 + seed) * cum[-1])
+    pick = np.minimum(pick, len(f) - 1)
+    r = synthetic.uniform((count, 2), 9200 + seed)
+    flip = r.sum(1) > 1.0
+    r[flip] = np.abs(r[flip] - 1.0)
+    return a[pick] + (b[pick] - a[pick]) * r[:, :1] + (c[pick] - a[pick]) * r[:, 1:]
+
+
+def normalise_source(points_source, points_target):
+    """ICP_T_S.sample_mesh's normalisation (icp_trans_scale.py:25-31)."""
+    ps, pt = np.asarray(points_source, np.float64), np.asarray(points_target, np.float64)
+    offset_s = ps.mean(0)
+    scale_s = np.sqrt(((ps - offset_s) ** 2).sum() / len(ps))
+    offset_t = pt.mean(0)
+    scale_t = np.sqrt(((pt - offset_t) ** 2).sum() / len(pt))
+    return (ps - offset_s) / scale_s * scale_t + offset_t, (offset_s, scale_s, offset_t, scale_t)
+
+
+def run_icp_f(points_source, points_target, max_iter=100, stop_error=1e-3, stop_improvement=1e-5, device="cuda"):
+    """ICP_T_S.run_icp_f on normalised source samples, on the GPU.  Returns (scale, trans [3], iterations, last error)."""
+    dev = torch.device(device)
+    src = torch.as_tensor(np.ascontiguousarray(points_source, dtype=np.float64)).to(dev)
+    tgt = torch.as_tensor(np.ascontiguousarray(points_target, dtype=np.float64)).to(dev)
+    L = _native.lib()
+    nbytes = ctypes.c_size_t()
+    _native.check(L.asdf_icp_workspace_bytes(src.shape[0], tgt.shape[0], ctypes.byref(nbytes)), "asdf_icp_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    res = (ctypes.c_double * 8)()
+    with torch.cuda.device(dev):
+        _native.check(L.asdf_icp_ts(src.data_ptr(), src.shape[0], tgt.data_ptr(), tgt.shape[0], int(max_iter), float(stop_error),
+                                    float(stop_improvement), ws.data_ptr(), ws.numel(), res,
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "asdf_icp_ts")
+    return res[0], np.array([res[1], res[2], res[3]]), int(res[4]), res[5]
+
+
+def icp_trans_scale(points_source, points_target, vertices, max_iter=100, device="cuda"):
+    """sample normalisation + run_icp_f + get_trans_scale (:188-191) + the vertex transform of export_source_mesh
+    (:193-196).  Returns a dict with scale, trans, iterations, error, all_scale, all_trans, vertices."""
+    ps, (offset_s, scale_s, offset_t, scale_t) = normalise_source(points_source, points_target)
+    scale, trans, iters, error = run_icp_f(ps, points_target, max_iter, device=device)
+    v = (np.asarray(vertices, np.float64) - offset_s) / scale_s * scale_t + offset_t
+    return dict(scale=scale, trans=trans, iterations=iters, error=error, all_scale=scale_t * scale / scale_s,
+                all_trans=trans + offset_t * scale - offset_s * scale_t * scale / scale_s, vertices=v * scale + trans)
+
+
+def align_to_ground_truth(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=100, seed=0, device="cuda"):
+    """The eval-mode block of utils/mesh.py:385-395: sample both meshes, ICP, return (aligned verts, trans, scale)."""
+    ps = sample_surface(verts, faces, samples, seed)
+    pt = sample_surface(gt_verts, gt_faces, samples, seed + 1)
+    r = icp_trans_scale(ps, pt, verts, max_iter, device)
+    return r["vertices"], r["all_trans"], r["all_scale"], r

@@ -147,7 +147,8 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
 
 
 def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, end_point, task="obman", device="cuda", scale=None,
-                cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference"):
+                cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference",
+                data_root="data"):
     """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
     decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
     Returns the list of per-sample records."""
@@ -176,9 +177,12 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                    "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
             for part, sc in (("hand", None), ("obj", scale)):
                 if "verts_" + part in r:
-                    mesh_utils.export_surface(r["verts_" + part], r["faces_" + part], r["origin"], r["voxel_size"],
-                                              os.path.join(mesh_dir, "%s_%s.ply" % (name, part)), None, sc,
-                                              eval_mode and part == "hand", task)
+                    _, _, trans, icp_scale = mesh_utils.export_surface(
+                        r["verts_" + part], r["faces_" + part], r["origin"], r["voxel_size"],
+                        os.path.join(mesh_dir, "%s_%s.ply" % (name, part)), None, sc, eval_mode and part == "hand", task,
+                        data_root=data_root)
+                    if part == "hand":
+                        rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])
                 elif "mc_error_" + part in r:
                     import logging
                     logging.warning("Cannot reconstruct mesh from '{}'".format(os.path.join(mesh_dir, "%s_%s.ply" % (name, part))))

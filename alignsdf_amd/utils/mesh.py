@@ -89,39 +89,61 @@ def extract_surface(sdf, voxel_grid_origin, voxel_size, offset=None, scale=None)
     return place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
 
 
-def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
-                   task="obman", largest_component=True):
-    """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397)."""
-    verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+def ground_truth_mesh_path(ply_filename_out, task, data_root="data"):
+    """Where the reference looks for the ground-truth mesh of an output file (utils/mesh.py:386-388):
+    <data_root>/<task>/test/mesh_<hand|obj>/<sample id>.obj."""
+    mesh_dir = "mesh_" + ply_filename_out.split("_")[-1].split(".")[0]
+    gt_mesh_name = ply_filename_out.split("/")[-1].split("_")[0] + ".obj"
+    return os.path.join(data_root, task, "test", mesh_dir, gt_mesh_name)
+
+
+def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
+    """utils/mesh.py:371-397 for already placed vertices: keep the largest component, in eval mode align it to the
+    ground-truth mesh with the translate+scale ICP (K7) and export.  Returns (trans [3], scale [1]) like the reference
+    (zeros / one outside eval mode).  A missing ground-truth file is logged and the unaligned mesh is written (the
+    reference would abort the run there)."""
+    out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
+    trans, scale = np.array([0, 0, 0]), np.array([1])
     if eval_mode:
-        logging.warning("eval_mode ICP alignment (utils/mesh.py:385-395) is not part of this build; writing the unaligned mesh")
+        gt_path = ground_truth_mesh_path(ply_filename_out, task, data_root)
+        if os.path.exists(gt_path):
+            from ..icp import align_to_ground_truth, load_obj
+            gt_v, gt_f = load_obj(gt_path)
+            out_v, t, sc, _ = align_to_ground_truth(out_v, out_f, gt_v, gt_f)       # 30 000 samples, <= 100 iterations
+            trans, scale = np.asarray(t).reshape(1, 3), np.asarray(sc).reshape(1)
+        else:
+            logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh" % gt_path)
     if ply_filename_out:
         os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
-        out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
         write_ply(ply_filename_out, out_v, out_f)
-    return verts, faces
+    return trans, scale
+
+
+def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
+                   task="obman", largest_component=True, data_root="data"):
+    """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397).
+    Returns (verts, faces, trans, scale)."""
+    verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+    trans, sc = finish_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
+    return verts, faces, trans, sc
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
-                               scale=None, eval_mode=False, task="obman", largest_component=True):
+                               scale=None, eval_mode=False, task="obman", largest_component=True, data_root="data"):
     """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale) with
     verts / faces the raw marching-cubes output like the reference.  MC failures are logged and skipped exactly
     like the reference (utils/mesh.py:353-358).  The written file holds the largest watertight component when the
-    surface splits into several (utils/mesh.py:371-381, alignsdf_amd.mesh_post); the eval-mode ICP of
-    utils/mesh.py:385-395 needs ground-truth meshes and is not part of this build."""
+    surface splits into several (utils/mesh.py:371-381, alignsdf_amd.mesh_post); in eval mode it is first aligned to
+    the ground-truth mesh by the translate+scale ICP (utils/mesh.py:385-395, alignsdf_amd.icp) and `trans`, `scale`
+    are the ICP's; otherwise they are zeros / one."""
     try:
         verts, faces, mesh_points = extract_surface(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, offset, scale)
     except (ValueError, RuntimeError) as e:
         logging.warning("Cannot reconstruct mesh from '{}'".format(ply_filename_out))
         print(e)
         return None, None, np.array([0, 0, 0]), np.array([1])
-    if eval_mode:
-        logging.warning("eval_mode ICP alignment (utils/mesh.py:385-395) is not part of this build; writing the unaligned mesh")
-    if ply_filename_out:
-        os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
-        out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
-        write_ply(ply_filename_out, out_v, out_f)
-    return verts, faces, np.array([0, 0, 0]), np.array([1])
+    trans, sc = finish_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
+    return verts, faces, trans, sc
 
 
 def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference"):

@@ -123,6 +123,16 @@ int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doub
 int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                  size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
 
+/* ---- Translate + scale ICP of the reference's eval mode: ICP_T_S.run_icp_f (deep_sdf/metrics/icp_trans_scale.py:33-113),
+ * called from utils/mesh.py:385-395.  src_dev [ns][3] are the ALREADY NORMALISED source samples (sample_mesh :25-31),
+ * tgt_dev [nt][3] the target samples, both fp64 on the device.  Runs until the reference's stopping rules fire
+ * (error < stop_error, or improvement < stop_improvement, or max_iter) and writes, on the host,
+ *   result[0] = scale, result[1..3] = trans, result[4] = iterations executed, result[5] = last RMS error.
+ * Synchronises the stream once per iteration (72 B of sums per workgroup are read back). */
+int asdf_icp_workspace_bytes(int32_t ns, int32_t nt, size_t* bytes);
+int asdf_icp_ts(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, double stop_error,
+                double stop_improvement, void* workspace_dev, size_t workspace_bytes, double* result, void* stream);
+
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
  * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */

@@ -127,3 +127,35 @@ def test_pipelined_samples_equal_one_at_a_time(tag):
         for part in ("hand", "obj"):
             assert (r["V_" + part], r["F_" + part]) == (ref["V_" + part], ref["F_" + part])
             assert torch.equal(r["verts_" + part], ref["verts_" + part]) and torch.equal(r["faces_" + part], ref["faces_" + part])
+
+
+def test_eval_mode_icp_in_file_flow(tmp_path):
+    """convert_sdf_samples_to_ply(eval_mode=True): the written hand mesh is aligned to data/<task>/test/mesh_hand/<id>.obj
+    and (trans, scale) are returned like utils/mesh.py:385-395."""
+    from alignsdf_amd.ply import read_ply
+    from alignsdf_amd.utils.mesh import convert_sdf_samples_to_ply, ground_truth_mesh_path
+    n = 48
+    ax = torch.linspace(-1, 1, n)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = torch.sqrt(zz * zz * 1.0 + yy * yy * 2.0 + xx * xx * 3.5) - 0.55
+    vs = 2.0 / (n - 1)
+    out = str(tmp_path / "Eval_obman" / "meshes" / "00001234_hand.ply")
+    # unaligned run gives the "prediction"; the ground truth is that mesh under a known similarity
+    v0, f0, t0, s0 = convert_sdf_samples_to_ply(vol.cuda(), [-1, -1, -1], vs, out)
+    pv, pf = read_ply(out)
+    assert list(t0) == [0, 0, 0] and list(s0) == [1]
+    gt = pv.astype(np.float64) * 1.09 + np.array([0.02, -0.01, 0.03])
+    gt_path = ground_truth_mesh_path(out, "obman", str(tmp_path / "data"))
+    assert gt_path.endswith("data/obman/test/mesh_hand/00001234.obj")
+    os.makedirs(os.path.dirname(gt_path))
+    with open(gt_path, "w") as fh:
+        for p in gt:
+            fh.write("v %.9f %.9f %.9f\n" % tuple(p))
+        for t in pf:
+            fh.write("f %d %d %d\n" % tuple(t + 1))
+    v1, f1, trans, scale = convert_sdf_samples_to_ply(vol.cuda(), [-1, -1, -1], vs, out, eval_mode=True, task="obman",
+                                                      data_root=str(tmp_path / "data"))
+    av, af = read_ply(out)
+    assert np.array_equal(af, pf) and np.array_equal(v1, v0)
+    assert abs(float(scale[0]) - 1.09) < 5e-3 and np.abs(av - gt).max() < 2e-3
+    assert np.abs(np.asarray(trans).reshape(3) - np.array([0.02, -0.01, 0.03])).max() < 5e-3
