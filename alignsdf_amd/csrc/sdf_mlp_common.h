@@ -67,6 +67,22 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// The same with an instruction offset: the immediate is added to BOTH the global address and the LDS address, so the
+// four 1 KiB pieces of a wave's share of a stage (equal 1024-byte strides on both sides) need one base address.
+template <int OFF>
+__device__ __forceinline__ void lds_dma16_off(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off offset:%c3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst), "i"(OFF)
+      : "memory");
+}
+
 // Reference grid coordinates, bit-for-bit (utils/mesh.py:32-40): fp32 true division, fp32 fmod,
 // then separately rounded multiply and add (no FMA contraction).
 __device__ __forceinline__ void grid_point(long long i, int N, int mode, float vs, float o0, float o1, float o2,

@@ -53,7 +53,10 @@ __device__ __forceinline__ void stage(f32x16& acc, const f32x16 (&hin)[KT], cons
       if (g == 8 && !(ABL & 1)) {
         // one DMA piece per MFMA shadow (an LDS-DMA issue costs about one 64-cycle MFMA slot); pinned so the
         // scheduler cannot cluster the four pieces behind a single MFMA
-        lds_dma16(src + j * 256, dst + j * 1024);
+        if (j == 0) lds_dma16_off<0>(src, dst);
+        else if (j == 1) lds_dma16_off<1024>(src, dst);
+        else if (j == 2) lds_dma16_off<2048>(src, dst);
+        else lds_dma16_off<3072>(src, dst);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
