@@ -62,9 +62,12 @@ def run_sharded(num_items, process_range, backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)       # explicit rank -> device binding
+        backend = os.environ.get("ASDF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # explicit rank -> device binding (the reference's thread race on the GPU index, dist_reconstruct.py:21, cannot
+        # happen); ASDF_SHARE_DEVICE=1 folds the ranks onto the available devices for single-GPU testing over gloo
+        n_dev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % n_dev if os.environ.get("ASDF_SHARE_DEVICE") else local_rank)
     created = False
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,8 +90,9 @@ def main(argv=None):
     p.add_argument("--optim", dest="optim", action="store_true")
     p.add_argument("--codes", dest="code_dir", default=None)
     p.add_argument("--cube_dim", type=int, default=128)
+    p.add_argument("--split", dest="split_filename", default=None, help="default: input/<task>.json like the reference")
     args = p.parse_args(argv)
-    split = {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
+    split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     names = json.load(open(split))["filenames"]
     specs, decoder = rc.load_experiment(args.experiment_directory)
     output_dir = os.path.join(args.experiment_directory, "Eval_" + args.task)

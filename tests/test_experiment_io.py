@@ -58,3 +58,24 @@ def test_reconstruct_cli_writes_reference_layout(tmp_path):
     for r in recs:
         v, f = read_ply(os.path.join(mesh_dir, r["name"] + "_hand.ply"))
         assert len(f) > 100 and f.max() < len(v) and r["F_hand"] >= len(f)
+
+
+@pytest.mark.gpu
+def test_dist_reconstruct_cli_two_ranks(tmp_path):
+    """`torchrun -m alignsdf_amd.dist_reconstruct` with 2 ranks (sharing the GPU over gloo on a 1-GPU box): contiguous
+    shards, every sample exactly once, records gathered on rank 0, files in the reference layout."""
+    import subprocess
+    import sys
+    names = ["%08d" % i for i in (3, 14, 15, 92, 65)]
+    specs, split = make_experiment(str(tmp_path), "nerf3", names)
+    env = dict(os.environ, ASDF_DIST_BACKEND="gloo", ASDF_SHARE_DEVICE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", "-m", "alignsdf_amd.dist_reconstruct", "-e", str(tmp_path), "-t", "obman", "--split", split,
+           "--cube_dim", "32"]
+    subprocess.run(cmd, check=True, timeout=600, env=env)
+    summary = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "reconstruct_summary.json")))
+    assert [r["index"] for r in summary] == [0, 1, 2, 3, 4]
+    assert [r["rank"] for r in summary] == [0, 0, 1, 1, 1]                 # len // W per rank, remainder to the last
+    meshes = sorted(os.listdir(os.path.join(str(tmp_path), "Eval_obman", "meshes")))
+    assert meshes == sorted(["%s_%s.ply" % (n, p) for n in names for p in ("hand", "obj")])
+    assert all(r["F_hand"] > 100 and r["F_obj"] > 100 for r in summary)
