@@ -14,15 +14,25 @@ from ..hip_decoder import HipSdfDecoder, kinematic_affine
 _cache = weakref.WeakKeyDictionary()
 
 
+def _param_fingerprint(module):
+    """Changes whenever a parameter tensor is replaced or written in place (optimizer step, load_state_dict)."""
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
 def hip_decoder_for(decoder, device=None):
-    """Packed HIP decoder of an nn.Module, built once per (module, device) and cached."""
+    """Packed HIP decoder of an nn.Module, built once per (module, device) and cached; re-packed when the module's
+    parameters have changed since (the reference reconstructs from inside the training loop, train.py:668)."""
     if isinstance(decoder, HipSdfDecoder):
         return decoder
     dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
     per_mod = _cache.setdefault(decoder, {})
-    if str(dev) not in per_mod:
-        per_mod[str(dev)] = HipSdfDecoder(decoder, device=dev)
-    return per_mod[str(dev)]
+    fp = _param_fingerprint(decoder)
+    hit = per_mod.get(str(dev))
+    if hit is None or hit[0] != fp:
+        if hit is not None:
+            hit[1].close()
+        per_mod[str(dev)] = (fp, HipSdfDecoder(decoder, device=dev))
+    return per_mod[str(dev)][1]
 
 
 def sample_embedding(specs, mano_results, obj_results, combined=False):

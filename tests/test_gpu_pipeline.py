@@ -159,3 +159,22 @@ def test_eval_mode_icp_in_file_flow(tmp_path):
     assert np.array_equal(af, pf) and np.array_equal(v1, v0)
     assert abs(float(scale[0]) - 1.09) < 5e-3 and np.abs(av - gt).max() < 2e-3
     assert np.abs(np.asarray(trans).reshape(3) - np.array([0.02, -0.01, 0.03])).max() < 5e-3
+
+
+def test_packed_weights_follow_parameter_updates():
+    """The per-module cache of packed weights is refreshed after an in-place parameter update."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.utils import decode_sdf_multi_output, hip_decoder_for
+    specs = syn.specs_for("nerf3")
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+    lat = torch.from_numpy(syn.latent_code(0)).cuda()
+    pts = torch.from_numpy(syn.uniform((256, 3), 3, -1, 1).astype(np.float32)).cuda()
+    h0, _, _ = decode_sdf_multi_output(dec, lat, pts, None, None, specs)
+    first = hip_decoder_for(dec)
+    assert hip_decoder_for(dec) is first                       # unchanged parameters: cache hit
+    with torch.no_grad():
+        dec.linh4.bias.add_(0.25)
+    h1, _, _ = decode_sdf_multi_output(dec, lat, pts, None, None, specs)
+    assert hip_decoder_for(dec) is not first
+    expect = torch.tanh(torch.atanh(h0.double()) + 0.25).float()
+    assert (h1 - expect).abs().max().item() <= 2e-6
