@@ -17,6 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
+ABI_VERSION = 103        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -52,9 +53,18 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise NativeError(-100, "libalignsdf_hip.so not found at %s - run `python -m alignsdf_amd.build_native` "
-                                "(there is no CPU fallback)" % LIB_PATH)
+        # build on demand when the toolchain is here (hipcc cross-compiles without a GPU); there is no CPU fallback
+        try:
+            from . import build_native
+            build_native.build()
+        except Exception as e:      # noqa: BLE001
+            raise NativeError(-100, "libalignsdf_hip.so not found at %s and building it failed (%s) - run "
+                                    "`python -m alignsdf_amd.build_native`; there is no CPU fallback" % (LIB_PATH, e))
     L = ctypes.CDLL(LIB_PATH)
+    L.asdf_version.restype = ctypes.c_int
+    if L.asdf_version() != ABI_VERSION:
+        raise NativeError(-101, "libalignsdf_hip.so reports ABI version %d, these bindings need %d - rebuild with "
+                                "`python -m alignsdf_amd.build_native --force`" % (L.asdf_version(), ABI_VERSION))
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     L.asdf_version.restype = ctypes.c_int
     L.asdf_strerror.restype = ctypes.c_char_p

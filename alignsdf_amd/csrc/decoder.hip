@@ -138,7 +138,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 101; }
+int asdf_version(void) { return 103; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
