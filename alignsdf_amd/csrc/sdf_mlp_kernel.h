@@ -234,6 +234,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
             if (TWO_OUT) partb = fmaf(v, wb[r], partb);
           }
         }
+        // keep both chains where they are written: left alone, the scheduler defers the second chain to the head end and
+        // spills every tile's activations and weights to scratch to do so
+        if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
       };
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
