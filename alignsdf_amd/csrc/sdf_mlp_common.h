@@ -8,13 +8,17 @@
 //
 // Structure (see sdf_layout.h for the operand maps):
 //   * one 256-thread workgroup per CU, one wave per SIMD, up to 512 VGPR+AGPR per lane;
-//   * every wave owns 32 query points for BOTH heads and ALL layers: the 512-wide activation
+//   * every wave owns 32 query points through ALL layers of one MLP: the 512-wide activation
 //     of a layer lives in 256 registers per lane and is consumed in place as the MFMA B operand
 //     of the next layer (no LDS / HBM round trip for activations);
+//   * loop order: MLP (head) outer, point tile inner, so one 2 MiB weight stream is live at a time
+//     and stays resident in the 4 MiB per-XCD L2;
 //   * the weights are the MFMA A operand.  They are pre-packed on the host into a linear stream
-//     of 16 KiB stages and flow HBM/L2 -> LDS through a 4-slot ring filled by LDS-DMA
-//     (global_load_lds_dwordx4), shared by the 4 waves; one s_barrier per stage;
-//   * bias / ReLU / final dot-product + tanh are fused epilogues on the accumulator registers.
+//     of 16 KiB stages and flow L2 -> LDS through a 4-slot ring filled by LDS-DMA
+//     (global_load_lds_dwordx4) 2.5 stages ahead, shared by the 4 waves; one s_barrier per stage,
+//     placed mid-stage in the shadow of an MFMA;
+//   * bias / ReLU / final dot-product + tanh are fused epilogues on the accumulator registers,
+//     deferred into the MFMA stream of the next output tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,7 +43,7 @@ enum GridMode : int {
 
 struct DecodeParams {
   const float* stream;      // [kStagesAll][kStageFloats] packed static weights
-  const float* cst;         // [kHeads][kCstFloats] per-sample constants
+  const float* cst;         // [heads][CstLayout<KP>::kFloats] per-sample constants
   float* sdf0;              // [P] hand SDF (may be null)
   float* sdf1;              // [P] object SDF (may be null)
   const float* xyz;         // [P][3] when mode == kPointList
