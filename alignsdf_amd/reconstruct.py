@@ -50,7 +50,7 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
-def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference"):
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False):
     """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
@@ -58,7 +58,11 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference"):
     Per sample the GPU work is  pass 1 -> [64-byte bbox readback, zoom cube on the host] -> pass 2 -> marching cubes,
     and only the bracketed step and the MC size readbacks synchronise with the host.  Pass 1 of sample k+1 is queued
     right behind pass 2 of sample k, i.e. before sample k's marching cubes and before the consumer's host work
-    (D2H copy, component filter, PLY export), so the GPU never waits for the host between samples."""
+    (D2H copy, component filter, PLY export), so the GPU never waits for the host between samples.
+
+    host_copy=True additionally copies every mesh to pinned host memory on a side stream, ordered right behind its
+    marching-cubes kernels (`host_verts_*`, `host_faces_*` CPU tensors, valid after `copy_done_*`.synchronize()): a
+    plain `.cpu()` on the compute stream would wait behind the NEXT sample's queued passes."""
     from .marching_cubes import marching_cubes_device
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
     from .utils.utils import hip_decoder_for, sample_embedding
@@ -66,6 +70,7 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference"):
     hb, ob = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
     mode = GRID_MODES[grid_mode]
     voxel = 2.0 / (N - 1)
+    copy_stream = torch.cuda.Stream(device=hip.device) if host_copy else None
 
     def first_pass(sample):
         _, latent, mano, obj = sample
@@ -90,6 +95,20 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference"):
                     continue
                 r["verts_" + part], r["faces_" + part] = v, f
                 r["V_" + part], r["F_" + part] = v.shape[0], f.shape[0]
+                if host_copy:
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(hip.device))
+                    hv = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    hf = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(ready)
+                        hv.copy_(v, non_blocking=True)
+                        hf.copy_(f, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(copy_stream)
+                    v.record_stream(copy_stream)
+                    f.record_stream(copy_stream)
+                    r["host_verts_" + part], r["host_faces_" + part], r["copy_done_" + part] = hv, hf, done
 
     it = iter(samples)
     cur = next(it, None)
@@ -172,13 +191,14 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     records = []
     with torch.no_grad():
         t_prev = time.perf_counter()
-        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode):
+        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True):
             rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
                    "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
             for part, sc in (("hand", None), ("obj", scale)):
                 if "verts_" + part in r:
+                    r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
                     _, _, trans, icp_scale = mesh_utils.export_surface(
-                        r["verts_" + part], r["faces_" + part], r["origin"], r["voxel_size"],
+                        r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"],
                         os.path.join(mesh_dir, "%s_%s.ply" % (name, part)), None, sc, eval_mode and part == "hand", task,
                         data_root=data_root)
                     if part == "hand":

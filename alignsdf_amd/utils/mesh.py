@@ -63,8 +63,8 @@ def get_higher_res_cube(hand_branch, obj_branch, sdf_values_hand, sdf_values_obj
 
 
 def place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset=None, scale=None):
-    """Device MC output -> host arrays with the vertex arithmetic of utils/mesh.py:354-369 (spacing, origin, optional
-    scale / offset).  Returns (verts, faces, mesh_points)."""
+    """MC output (device or already-copied host tensors) -> host arrays with the vertex arithmetic of
+    utils/mesh.py:354-369 (spacing, origin, optional scale / offset).  Returns (verts, faces, mesh_points)."""
     verts, faces = verts_d.cpu().numpy(), faces_d.cpu().numpy()
     vs = voxel_size.item() if isinstance(voxel_size, torch.Tensor) else voxel_size
     spacing = [np.float32(vs)] * 3 if isinstance(voxel_size, torch.Tensor) else [vs] * 3
