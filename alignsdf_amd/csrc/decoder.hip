@@ -119,6 +119,8 @@ struct asdf_decoder {
   float* cst;       // [heads][cst_offsets(kp).floats]  (static parts written at create time)
   int kp;           // point-feature K-steps: 2 (affine xyz) or ceil(pf / 2) (NeRF encoding)
   float* embed;     // [heads][MAXPF][4]
+  float* cls;       // [kMaxClasses][512 in D-layout order] + [kMaxClasses]; null until asdf_decoder_set_classifier
+  int num_class;
   bool sample_bound;
 };
 
@@ -138,7 +140,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 103; }
+int asdf_version(void) { return 104; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -169,7 +171,7 @@ int asdf_device_count(void) {
 
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
-  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed};
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls};
   for (float* b : bufs) (void)hipFree(b);
   delete d;
 }
@@ -216,6 +218,10 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   for (const void* k : {(const void*)sdf_mlp_nerf9_kernel, (const void*)sdf_mlp_nerf15_kernel,
                         (const void*)sdf_mlp_combined_nerf9_kernel, (const void*)sdf_mlp_combined_nerf15_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kMaxKP));
+  for (const void* k : {(const void*)sdf_mlp_cls_kernel, (const void*)sdf_mlp_combined_cls_kernel,
+                        (const void*)sdf_mlp_nerf9_cls_kernel, (const void*)sdf_mlp_nerf15_cls_kernel,
+                        (const void*)sdf_mlp_combined_nerf9_cls_kernel, (const void*)sdf_mlp_combined_nerf15_cls_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_cls(kMaxKP));
 
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -278,8 +284,9 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
     ASDF_HIP(hipGetLastError());
   }
+  const bool want_cls = p.logits || p.labels;
   if (!two_out) {
-    if (!p.sdf0 && !p.sdf1) return ASDF_OK;
+    if (!p.sdf0 && !p.sdf1 && !want_cls) return ASDF_OK;
     if (!p.sdf1) p.num_mlps = 1;
     else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
   }
@@ -287,6 +294,26 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (ntiles == 0) return ASDF_OK;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   p.pf = d->spec.point_feats[0];
+  if (p.logits || p.labels) {
+    // label pass: the classifier reads MLP 0's last hidden activation, so MLP 0 always runs
+    if (!d->cls) return ASDF_EINVAL;
+    p.cls = d->cls;
+    p.num_class = d->num_class;
+    if (!two_out && p.first_mlp != 0) { p.first_mlp = 0; p.num_mlps = 2; }
+    const int lds = lds_bytes_cls(d->kp);
+    if (d->kp == 2) {
+      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+      else hipLaunchKernelGGL(sdf_mlp_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+    } else if (d->kp == 5) {
+      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf9_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+      else hipLaunchKernelGGL(sdf_mlp_nerf9_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+    } else {
+      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+      else hipLaunchKernelGGL(sdf_mlp_nerf15_cls_kernel, dim3(grid), dim3(256), lds, st, p);
+    }
+    ASDF_HIP(hipGetLastError());
+    return ASDF_OK;
+  }
   if (d->kp == 2) {
     if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
     else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
@@ -319,6 +346,32 @@ int asdf_decode_points(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float
   DecodeParams p;
   std::memset(&p, 0, sizeof(p));
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.xyz = xyz_dev; p.P = M; p.N = 1; p.mode = kPointList;
+  return launch_decode(d, p, (hipStream_t)stream);
+}
+
+int asdf_decoder_set_classifier(asdf_decoder_t* d, const float* w_host, const float* b_host, int32_t num_class) {
+  if (!d || !w_host || !b_host || num_class < 1 || num_class > kMaxClasses) return ASDF_EINVAL;
+  std::vector<float> img(kClsFloats, 0.0f);
+  for (int k = 0; k < num_class; ++k) {
+    for (int row = 0; row < kHidden; ++row) {
+      const int t = row >> 5, rr = row & 31, hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);   // D-layout order
+      img[(size_t)k * kHidden + (t * 2 + hh) * 16 + r] = w_host[(size_t)k * kHidden + row];
+    }
+    img[(size_t)kMaxClasses * kHidden + k] = b_host[k];
+  }
+  if (!d->cls) ASDF_HIP(hipMalloc((void**)&d->cls, img.size() * sizeof(float)));
+  ASDF_HIP(hipMemcpy(d->cls, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  d->num_class = num_class;
+  return ASDF_OK;
+}
+
+int asdf_decode_points_cls(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float* sdf_hand_dev, float* sdf_obj_dev,
+                           float* logits_dev, int32_t* labels_dev, void* stream) {
+  if (!d || M < 0 || (M > 0 && !xyz_dev) || (!logits_dev && !labels_dev)) return ASDF_EINVAL;
+  DecodeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.xyz = xyz_dev; p.P = M; p.N = 1; p.mode = kPointList;
+  p.logits = logits_dev; p.labels = labels_dev;
   return launch_decode(d, p, (hipStream_t)stream);
 }
 

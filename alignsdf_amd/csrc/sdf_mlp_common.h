@@ -34,6 +34,10 @@ constexpr int kLdsRingFloats = kRing * kStageFloats;                 // 64 KiB
 // LDS = weight ring + the constants block of the MLP being evaluated
 constexpr int lds_bytes(int kp) { return (kLdsRingFloats + cst_offsets(kp).floats) * 4; }
 constexpr int kLdsBytes = lds_bytes(2);
+// part classifier of the label pass: up to kMaxClasses rows over the last hidden activation + their biases
+constexpr int kMaxClasses = 8;
+constexpr int kClsFloats = kMaxClasses * kHidden + kMaxClasses;
+constexpr int lds_bytes_cls(int kp) { return lds_bytes(kp) + kClsFloats * 4; }
 
 enum GridMode : int {
   kGridReference = 0,   // true-division ("sheared") indices of utils/mesh.py:33-34
@@ -56,6 +60,11 @@ struct DecodeParams {
   int num_mlps;             // MLPs to evaluate: 2 = both heads of a SeparateDecoder, 1 = one head or a CombinedDecoder
   int first_mlp;            // index of the first MLP to evaluate (1 = object head only)
   int pf;                   // raw point-feature count (NeRF-feature kernels only)
+  // label-pass kernels only
+  const float* cls;         // [kMaxClasses][512 in D-layout order] + [kMaxClasses] biases
+  float* logits;            // [P][num_class] class scores of MLP 0's last hidden activation (may be null)
+  int* labels;              // [P] argmax of the scores (may be null)
+  int num_class;
 };
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {

@@ -81,12 +81,15 @@ __device__ __forceinline__ float nerf_feature(int f, float x0, float x1, float x
 // values out of the tile loop and spills them); TWO_OUT selects, at compile time, whether the second last-layer row
 // is accumulated - it costs the single-output path 3.5 % when merely left in with zero weights.
 // KP = K-steps taken by the point features in layers 0 and 2: 2 = (affine) xyz, 5 / 8 = NeRF encoding of 9 / 15 features.
-template <int ABL, int KP, bool TWO_OUT>
+// CLS adds the part classifier of the label pass (classifier_head = Linear(512, num_class) on the last hidden activation
+// of MLP 0, networks/model.py:134-137,161-162 / :257-259,306-307): kMaxClasses more rows of the fused last layer.
+template <int ABL, int KP, bool TWO_OUT, bool CLS = false>
 __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
   float* cst = smem + kLdsRingFloats;
+  float* clsw = cst + CL::kFloats;         // CLS only: [kMaxClasses][512 in D-layout order] + [kMaxClasses] biases
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,6 +117,10 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
     {
       const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
       for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
+      if (CLS) {
+        const f32x4* c4 = reinterpret_cast<const f32x4*>(p.cls);
+        for (int i = tid; i < kClsFloats / 4; i += 256) reinterpret_cast<f32x4*>(clsw)[i] = c4[i];
+      }
     }
     const float* sbase0 = p.stream + (size_t)head * kStagesHead * kStageFloats;
 #pragma unroll
@@ -217,8 +224,26 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4) and tanh
       float part = 0.0f, partb = 0.0f;      // partb: second output row (CombinedDecoder; its weights are 0 otherwise)
+      float pc[kMaxClasses];                // CLS: classifier logits (rows >= num_class have zero weights)
+#pragma unroll
+      for (int k = 0; k < kMaxClasses; ++k) pc[k] = 0.0f;
       f32x16 acc3[2];
       auto dot_w4 = [&](const f32x16 a, int t) {
+        if (CLS) {
+          const f32x4* wc = reinterpret_cast<const f32x4*>(clsw + (t * 2 + half) * 16);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int k = 0; k < kMaxClasses; ++k) {
+              const f32x4 w = wc[k * (kHidden / 4) + c];
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                pc[k] = fmaf(__int_as_float(max(__float_as_int(a[c * 4 + r]), 0)), w[r], pc[k]);
+            }
+          }
+          // as for partb below: pin the chains to this tile, or they are deferred to the head end through scratch
+          asm volatile("" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4]), "+v"(pc[5]), "+v"(pc[6]), "+v"(pc[7]));
+        }
         // 4 registers at a time: keeps the two weight rows out of long-lived registers
         const f32x4* w4 = reinterpret_cast<const f32x4*>(hc + CL::kW4 + (t * 2 + half) * 16);
         const f32x4* w4b = reinterpret_cast<const f32x4*>(hc + CL::kW4b + (t * 2 + half) * 16);
@@ -270,6 +295,25 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         if (out) out[pi] = sdf;
         if (combined && p.sdf1) p.sdf1[pi] = sdfb;
       }
+      if (CLS) {
+        int best = 0;
+        float best_v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMaxClasses; ++k) {
+          pc[k] += __shfl_xor(pc[k], 32);
+          pc[k] += clsw[kMaxClasses * kHidden + k];
+          if (k == 0) best_v = pc[0];
+          else if (k < p.num_class && pc[k] > best_v) { best_v = pc[k]; best = k; }   // first maximum wins (torch.argmax)
+        }
+        if (valid && half == 0 && is_hand) {
+          if (p.logits) {
+#pragma unroll
+            for (int k = 0; k < kMaxClasses; ++k)
+              if (k < p.num_class) p.logits[pi * p.num_class + k] = pc[k];
+          }
+          if (p.labels) p.labels[pi] = best;
+        }
+      }
       if (p.bbox && valid && half == 0 && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
         if (sdf < 0.0f) {
@@ -312,5 +356,12 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParam
 __global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
+// label pass (utils/mesh.py:137-157): the same sweeps with the part classifier riding in the last-layer epilogue
+__global__ __launch_bounds__(256, 1) void sdf_mlp_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, true, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, false, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true, true>(p); }
 
 }  // namespace asdf

@@ -91,8 +91,6 @@ class HipSdfDecoder:
             latent_size = latent_size if latent_size is not None else getattr(m, "latent_size", 256)
             point_feat_size = point_feat_size if point_feat_size is not None else m.point_feat_size
             encode_style = encode_style if encode_style is not None else m.encode_style
-            if getattr(m, "use_classifier", False):
-                raise NotImplementedError("classifier head is not part of the HIP path yet")
             if getattr(m, "use_tanh", False) or getattr(m, "xyz_in_all", False):
                 raise NotImplementedError("use_tanh / xyz_in_all decoder variants are outside the HIP path")
         else:
@@ -101,8 +99,8 @@ class HipSdfDecoder:
         self.combined = "lin0.bias" in sd and "lin4.bias" in sd
         if not self.combined and ("linh0.bias" not in sd or "lino4.bias" not in sd):
             raise NotImplementedError("HIP path supports SeparateDecoder (linh*/lino*) and CombinedDecoder (lin*) modules")
-        if any(k.startswith(("bn", "classifier_head")) for k in sd):
-            raise NotImplementedError("LayerNorm / classifier variants are outside the HIP path")
+        if any(k.startswith("bn") for k in sd):
+            raise NotImplementedError("the LayerNorm variant is outside the HIP path")
         self.latent_size = int(latent_size)
         self.point_feat_size = int(point_feat_size)
         self.encode_style = encode_style
@@ -141,6 +139,17 @@ class HipSdfDecoder:
             _native.check(L.asdf_decoder_create(ctypes.byref(spec), heads, ctypes.byref(handle)), "asdf_decoder_create")
         self._h = handle
         self._L = L
+        # part classifier on the last hidden activation of the hand / single MLP (specs["ClassifierBranch"])
+        self.num_class = 0
+        if "classifier_head.weight" in sd:
+            cw = sd["classifier_head.weight"].detach().float().cpu().contiguous()
+            cb = sd["classifier_head.bias"].detach().float().cpu().contiguous()
+            if cw.dim() != 2 or cw.shape[1] != 512 or cb.numel() != cw.shape[0] or not 1 <= cw.shape[0] <= _native.MAX_CLASSES:
+                raise NotImplementedError("unsupported classifier_head shape %s" % (tuple(cw.shape),))
+            with torch.cuda.device(self.device):
+                _native.check(L.asdf_decoder_set_classifier(handle, cw.data_ptr(), cb.data_ptr(), int(cw.shape[0])),
+                              "asdf_decoder_set_classifier")
+            self.num_class = int(cw.shape[0])
         self._pf = pf
         self._latent = None
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
@@ -223,3 +232,20 @@ class HipSdfDecoder:
             _native.check(self._L.asdf_decode_points(self._h, xyz.data_ptr(), M, hand.data_ptr(), obj.data_ptr(),
                                                      self._stream()), "asdf_decode_points")
         return hand, obj
+
+    def classify_points(self, xyz, want_sdf=True):
+        """decode_points plus the part classifier: (hand [M], obj [M], scores [M, num_class], labels [M] int64) - the
+        scores are `predicted_class` of the reference forward, labels their argmax (utils/mesh.py:156-157)."""
+        if not self.num_class:
+            raise ValueError("this decoder has no classifier_head (specs['ClassifierBranch'] is off)")
+        xyz = xyz.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        M = xyz.shape[0]
+        hand = torch.empty(M, dtype=torch.float32, device=self.device) if want_sdf else None
+        obj = torch.empty(M, dtype=torch.float32, device=self.device) if want_sdf else None
+        scores = torch.empty((M, self.num_class), dtype=torch.float32, device=self.device)
+        labels = torch.empty(M, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decode_points_cls(
+                self._h, xyz.data_ptr(), M, hand.data_ptr() if want_sdf else None, obj.data_ptr() if want_sdf else None,
+                scores.data_ptr(), labels.data_ptr(), self._stream()), "asdf_decode_points_cls")
+        return hand, obj, scores, labels.long()

@@ -28,14 +28,12 @@ class SeparateDecoder(nn.Module):
                  norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
                  use_classifier=False):
         super().__init__()
-        if use_classifier:
-            raise NotImplementedError("classifier head (ClassifierBranch) is outside the accelerated hot path")
         if not weight_norm and norm_layers:
             raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
         self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
         self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
         self.dropout, self.dropout_prob = dropout, dropout_prob
-        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = False, use_tanh, xyz_in_all, latent_dropout
+        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = use_classifier, use_tanh, xyz_in_all, latent_dropout
         self.num_class = num_class
         widths = {"nerf": (point_feat_size, point_feat_size), "hand": (point_feat_size, 3), "obj": (3, point_feat_size),
                   "both": (point_feat_size - 3, 6)}[encode_style]          # networks/model.py:212-223
@@ -46,6 +44,8 @@ class SeparateDecoder(nn.Module):
             for layer in range(len(sizes) - 1):
                 n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
                 setattr(self, prefix + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+        if use_classifier:      # on the hand head's last hidden activation (networks/model.py:257-259)
+            self.classifier_head = nn.Linear(list(dims)[-1], num_class)
 
     def head_inputs(self, inputs):
         """Per-head input slices (networks/model.py:288-299)."""
@@ -58,10 +58,13 @@ class SeparateDecoder(nn.Module):
             return inputs[:, :L + 3], inputs
         return inputs[:, :-3], torch.cat([inputs[:, :L + 3], inputs[:, -3:]], 1)
 
-    def _head(self, prefix, x0):
+    def _head(self, prefix, x0, classify=False):
         x = x0
         last = self.num_layers - 2
+        scores = None
         for layer in range(self.num_layers - 1):
+            if classify and layer == last:
+                scores = self.classifier_head(x)
             if layer in self.latent_in:
                 x = torch.cat([x, x0], 1)
             x = getattr(self, prefix + str(layer))(x)
@@ -69,11 +72,13 @@ class SeparateDecoder(nn.Module):
                 x = torch.relu(x)
                 if self.training and self.dropout is not None and layer in self.dropout:
                     x = torch.nn.functional.dropout(x, p=self.dropout_prob, training=True)
-        return torch.tanh(x)
+        return torch.tanh(x), scores
 
     def forward(self, inputs):
         xh, xo = self.head_inputs(inputs)
-        return self._head("linh", xh)[:, 0:1], self._head("lino", xo)[:, 0:1], torch.zeros(1, device=inputs.device)
+        hand, scores = self._head("linh", xh, self.use_classifier)
+        obj, _ = self._head("lino", xo)
+        return hand[:, 0:1], obj[:, 0:1], scores if self.use_classifier else torch.zeros(1, device=inputs.device)
 
 
 class CombinedDecoder(nn.Module):
@@ -84,30 +89,36 @@ class CombinedDecoder(nn.Module):
                  norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
                  use_classifier=False):
         super().__init__()
-        if use_classifier or xyz_in_all or use_tanh:
-            raise NotImplementedError("classifier / xyz_in_all / use_tanh variants are outside the accelerated hot path")
+        if xyz_in_all or use_tanh:
+            raise NotImplementedError("xyz_in_all / use_tanh variants are outside the accelerated hot path")
         if not weight_norm and norm_layers:
             raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
         self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
         self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
         self.dropout, self.dropout_prob = dropout, dropout_prob
-        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = False, False, xyz_in_all, latent_dropout
+        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = use_classifier, False, xyz_in_all, latent_dropout
+        self.num_class = num_class
         sizes = [latent_size + point_feat_size] + list(dims) + [2]
         self.num_layers = len(sizes)
         for layer in range(len(sizes) - 1):
             n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
             setattr(self, "lin" + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+        if use_classifier:      # networks/model.py:134-137
+            self.classifier_head = nn.Linear(list(dims)[-1], num_class)
 
     def forward(self, inputs):
         x = inputs
+        scores = torch.zeros(1, device=inputs.device)
         for layer in range(self.num_layers - 1):
+            if self.use_classifier and layer == self.num_layers - 2:
+                scores = self.classifier_head(x)
             if layer in self.latent_in:
                 x = torch.cat([x, inputs], 1)
             x = getattr(self, "lin" + str(layer))(x)
             if layer < self.num_layers - 2:
                 x = torch.relu(x)
         x = torch.tanh(x)
-        return x[:, 0:1], x[:, 1:2], torch.zeros(1, device=inputs.device)
+        return x[:, 0:1], x[:, 1:2], scores
 
 
 def build_decoder(specs, state_dict=None):
@@ -124,7 +135,7 @@ def build_decoder(specs, state_dict=None):
             for pre in ("module.decoder.", "decoder."):
                 if k.startswith(pre):
                     k = k[len(pre):]
-            if k.startswith("lin"):
+            if k.startswith(("lin", "classifier_head")):
                 sd[k] = torch.as_tensor(v)
         dec.load_state_dict(sd)
     return dec.eval()

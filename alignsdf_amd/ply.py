@@ -32,3 +32,24 @@ def read_ply(path):
     verts = np.frombuffer(data, dtype="<f4", count=nv * 3, offset=end).reshape(nv, 3)
     rec = np.frombuffer(data, dtype=[("n", "u1"), ("idx", "<i4", (3,))], count=nf, offset=end + nv * 12)
     return verts.copy(), rec["idx"].copy()
+
+
+def write_ply_ascii(path, verts, faces=None, vertex_colors=None):
+    """ASCII PLY with optional per-vertex RGB(A) colours: the text layout of the reference's customized_export_ply
+    for the (v, f, v_c) combination it is called with (utils/customized_export_ply.py:49-119 - `%f` coordinates,
+    `uchar` red/green/blue/alpha with alpha 255 when only RGB is given, `3 i j k` faces)."""
+    verts = np.asarray(verts).reshape(-1, 3)
+    faces = np.zeros((0, 3), dtype=np.int64) if faces is None else np.asarray(faces).reshape(-1, 3)
+    head = ["ply", "format ascii 1.0", "element vertex %d" % len(verts), "property float x", "property float y", "property float z"]
+    if vertex_colors is not None:
+        vc = np.asarray(vertex_colors)
+        if vc.shape[1] == 3:
+            vc = np.hstack([vc, np.full((len(vc), 1), 255, dtype=np.uint8)])
+        head += ["property uchar red", "property uchar green", "property uchar blue", "property uchar alpha"]
+        body = ["%f %f %f %d %d %d %d" % (v[0], v[1], v[2], c[0], c[1], c[2], c[3]) for v, c in zip(verts.tolist(), vc.tolist())]
+    else:
+        body = ["%f %f %f" % tuple(v) for v in verts.tolist()]
+    head += ["element face %d" % len(faces), "property list uchar int vertex_indices", "end_header"]
+    body += ["3 %d %d %d" % tuple(f) for f in faces.tolist()]
+    with open(path, "w") as f:
+        f.write("\n".join(head + body) + "\n")

@@ -50,7 +50,7 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
-def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False):
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False):
     """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
@@ -62,7 +62,11 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     host_copy=True additionally copies every mesh to pinned host memory on a side stream, ordered right behind its
     marching-cubes kernels (`host_verts_*`, `host_faces_*` CPU tensors, valid after `copy_done_*`.synchronize()): a
-    plain `.cpu()` on the compute stream would wait behind the NEXT sample's queued passes."""
+    plain `.cpu()` on the compute stream would wait behind the NEXT sample's queued passes.
+
+    label_out=True runs the label pass (utils/mesh.py:137-157) over the hand mesh vertices right behind the hand's
+    marching cubes (`labels_hand`, int64 device tensor; `host_labels_hand` with host_copy).  The decoder holds one
+    sample's folded constants at a time, so sample k is re-bound for it and sample k+1 bound again afterwards."""
     from .marching_cubes import marching_cubes_device
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
     from .utils.utils import hip_decoder_for, sample_embedding
@@ -72,9 +76,25 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     voxel = 2.0 / (N - 1)
     copy_stream = torch.cuda.Stream(device=hip.device) if host_copy else None
 
-    def first_pass(sample):
+    def bind(sample):
         _, latent, mano, obj = sample
         hip.set_sample(latent, sample_embedding(specs, mano, obj, hip.combined))
+
+    def to_host(r, key, t):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(hip.device))
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            h.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        t.record_stream(copy_stream)
+        r["host_" + key] = h
+        return done
+
+    def first_pass(sample):
+        bind(sample)
         return hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)[2]
 
     def second_pass(bbox):
@@ -84,7 +104,9 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         vh, vo, _ = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=False, hand=hb, obj=ob)
         return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b}
 
-    def surfaces(r):
+    def surfaces(r, sample):
+        """Marching cubes (and the label pass) of one sample; returns True when the decoder was re-bound to it."""
+        rebound = False
         for part, on in (("hand", hb), ("obj", ob)):
             r["V_" + part] = r["F_" + part] = 0
             if on:
@@ -95,20 +117,19 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     continue
                 r["verts_" + part], r["faces_" + part] = v, f
                 r["V_" + part], r["F_" + part] = v.shape[0], f.shape[0]
+                if label_out and part == "hand":
+                    # the vertex arithmetic of utils/mesh.py:138-141 in fp32, on the device
+                    pts = v * float(r["voxel_size"]) + torch.tensor(r["origin"], dtype=torch.float32, device=v.device)
+                    bind(sample)
+                    rebound = True
+                    r["labels_hand"] = hip.classify_points(pts, want_sdf=False)[3]
                 if host_copy:
-                    ready = torch.cuda.Event()
-                    ready.record(torch.cuda.current_stream(hip.device))
-                    hv = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                    hf = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
-                    with torch.cuda.stream(copy_stream):
-                        copy_stream.wait_event(ready)
-                        hv.copy_(v, non_blocking=True)
-                        hf.copy_(f, non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(copy_stream)
-                    v.record_stream(copy_stream)
-                    f.record_stream(copy_stream)
-                    r["host_verts_" + part], r["host_faces_" + part], r["copy_done_" + part] = hv, hf, done
+                    to_host(r, "verts_" + part, v)
+                    done = to_host(r, "faces_" + part, f)
+                    if "labels_" + part in r:
+                        done = to_host(r, "labels_" + part, r["labels_" + part])
+                    r["copy_done_" + part] = done           # the side stream is in order: the last event covers all
+        return rebound
 
     it = iter(samples)
     cur = next(it, None)
@@ -118,8 +139,10 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     nxt = next(it, None)
     bbox_next = first_pass(nxt) if nxt is not None else None
     while True:
-        surfaces(r)                                     # MC of sample k, queued behind pass 1 of sample k+1
+        rebound = surfaces(r, cur)                      # MC of sample k, queued behind pass 1 of sample k+1
         if nxt is not None:
+            if rebound:
+                bind(nxt)
             r_next = second_pass(bbox_next)
             after = next(it, None)
             bbox_after = first_pass(after) if after is not None else None
@@ -140,13 +163,14 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
     rec = {"V_hand": 0, "F_hand": 0, "V_obj": 0, "F_obj": 0}
     if mesh_filename is not None:
         stats = {}
+        offset = None
         if hand_branch:
-            v, f, _, _ = mesh_utils.convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"],
-                                                                mesh_filename + "_hand.ply", None, None, eval_mode, task)
+            v, f, offset, scale = mesh_utils.convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"],
+                                                                        mesh_filename + "_hand.ply", None, None, eval_mode, task)
             stats["hand"] = (0, 0) if v is None else (len(v), len(f))
         if obj_branch:
             v, f, _, _ = mesh_utils.convert_sdf_samples_to_ply(r["vol_obj"], r["origin"], r["voxel_size"],
-                                                                mesh_filename + "_obj.ply", None, scale, False)
+                                                                mesh_filename + "_obj.ply", offset, scale, False)
             stats["obj"] = (0, 0) if v is None else (len(v), len(f))
         for part, (nv, nf) in stats.items():
             rec["V_" + part], rec["F_" + part] = nv, nf
@@ -171,8 +195,6 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
     decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
     Returns the list of per-sample records."""
-    if label_out or viz:
-        raise NotImplementedError("label / viz outputs (utils/mesh.py:137-184) are outside the accelerated path")
     mesh_dir = os.path.join(output_dir, "meshes")
     os.makedirs(mesh_dir, exist_ok=True)
     with open(split_filename, "r") as f:
@@ -191,18 +213,32 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     records = []
     with torch.no_grad():
         t_prev = time.perf_counter()
-        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True):
+        hand_on = specs.get("HandBranch", True)
+        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
+                                                    label_out=label_out and hand_on):
             rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
                    "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
-            for part, sc in (("hand", None), ("obj", scale)):
+            # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
+            # is on - zeros / one outside eval mode or when the hand has no surface (utils/mesh.py:123-133,186-195)
+            offset, sc = (np.array([0, 0, 0]), np.array([1])) if hand_on else (None, scale)
+            for part in ("hand", "obj"):
                 if "verts_" + part in r:
                     r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
-                    _, _, trans, icp_scale = mesh_utils.export_surface(
-                        r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"],
-                        os.path.join(mesh_dir, "%s_%s.ply" % (name, part)), None, sc, eval_mode and part == "hand", task,
+                    base = os.path.join(mesh_dir, "%s_%s" % (name, part))
+                    verts, faces, trans, icp_scale = mesh_utils.export_surface(
+                        r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"], base + ".ply",
+                        None if part == "hand" else offset, None if part == "hand" else sc, eval_mode and part == "hand", task,
                         data_root=data_root)
                     if part == "hand":
+                        offset, sc = trans, icp_scale
                         rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])
+                        if "host_labels_hand" in r:
+                            vertices = np.array(verts, copy=True)
+                            for a in range(3):
+                                vertices[:, a] = r["origin"][a] + vertices[:, a]
+                            labels = r["host_labels_hand"].float()
+                            mesh_utils.write_label_outputs(vertices, faces, labels, base, offset, sc, viz)
+                            rec["labels_hand"] = np.bincount(labels.long().numpy(), minlength=1).tolist()
                 elif "mc_error_" + part in r:
                     import logging
                     logging.warning("Cannot reconstruct mesh from '{}'".format(os.path.join(mesh_dir, "%s_%s.ply" % (name, part))))

@@ -146,6 +146,59 @@ def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_s
     return verts, faces, trans, sc
 
 
+# colour per part label of the `--viz` output (the table of utils/mesh.py:305-310)
+PART_COLORS = np.array([[13, 212, 128], [250, 70, 42], [131, 66, 37], [78, 137, 54], [187, 246, 163], [67, 220, 74]], dtype=np.uint8)
+
+
+def _host(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def _scaled(points, offset, scale):
+    pts = _host(points)
+    if scale is not None:
+        pts = pts * scale
+    if offset is not None:
+        pts = pts + offset
+    return pts
+
+
+def write_verts_label_to_obj(xyz, labels, obj_filename_out, offset=None, scale=None):
+    """`v x y z g g g` lines with grey level 45 * label (utils/mesh.py:259-277)."""
+    pts, lab = _scaled(xyz, offset, scale), _host(labels)
+    with open(obj_filename_out, "w") as fp:
+        fp.write("".join("v %.4f %.4f %.4f %.2f %.2f %.2f\n" % (v[0], v[1], v[2], c, c, c)
+                         for v, c in zip(pts.tolist(), (lab * 45.0).tolist())))
+
+
+def write_verts_label_to_npz(xyz, labels, npz_filename_out, offset=None, scale=None):
+    """points / labels arrays (utils/mesh.py:280-296)."""
+    np.savez(npz_filename_out, points=_scaled(xyz, offset, scale), labels=_host(labels))
+
+
+def write_color_labeled_ply(xyz, faces, labels, ply_filename_out, offset=None, scale=None):
+    """ASCII PLY coloured by part label (utils/mesh.py:299-326)."""
+    from ..ply import write_ply_ascii
+    pts, lab = _scaled(xyz, offset, scale), _host(labels)
+    write_ply_ascii(ply_filename_out, pts, faces, PART_COLORS[lab.astype(np.int32)])
+
+
+def label_points(decoder, latent_vec, mano_results, obj_results, specs, points):
+    """Part label of every point [V,3] (normalised coordinates, any device): the label pass of utils/mesh.py:137-157
+    in one launch (the reference chunks by max_batch).  Returns a float32 CPU tensor like `out_labels`."""
+    hip = hip_decoder_for(decoder)
+    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, hip.combined))
+    return hip.classify_points(points, want_sdf=False)[3].float().cpu()
+
+
+def write_label_outputs(vertices, faces, labels, ply_filename_hand, offset, scale, viz):
+    """The label files of one hand mesh (utils/mesh.py:160-184)."""
+    if viz:
+        write_verts_label_to_obj(vertices, labels, ply_filename_hand + "_label.obj", offset, scale)
+        write_color_labeled_ply(vertices, faces, labels, ply_filename_hand + "_color.ply", offset, scale)
+    write_verts_label_to_npz(vertices, labels, ply_filename_hand + "_label.npz", offset, scale)
+
+
 def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference"):
     """Pass 1 on [-1,1]^3, zoom cube, pass 2 (utils/mesh.py:21-121) entirely on the device.
     Returns dict(vol_hand, vol_obj device tensors of pass 2, voxel_size 0-dim fp32 tensor, origin list,
@@ -176,16 +229,27 @@ def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, l
     `max_batch` and `device` are accepted for signature compatibility; chunking is internal to the kernel and
     the decoder's device is used.  `grid_mode="reference"` reproduces the true-division lattice of
     utils/mesh.py:33-34 bit for bit; "integer" is the axis-aligned lattice.  Returns a dict of per-surface
-    (V, F) counts (the reference returns None)."""
-    if cls_branch or label_out:
-        raise NotImplementedError("classifier / label pass (utils/mesh.py:137-184) is outside the accelerated path")
+    (V, F) counts (the reference returns None).
+
+    `cls_branch` only makes the reference store a per-voxel class column that nothing reads (utils/mesh.py:59-60,
+    111-112); it is accepted and has no effect.  `label_out` runs the label pass over the hand mesh vertices
+    (utils/mesh.py:137-184) and needs a decoder with a classifier head.  As in the reference, the object mesh is
+    written with the hand mesh's ICP translation / scale as its offset / scale (utils/mesh.py:123-133,186-195)."""
     decoder.eval() if hasattr(decoder, "eval") else None
     r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode)
     stats = {}
     if hand_branch:
-        v, f, _, _ = convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"], filename + "_hand.ply", None, None,
-                                                eval_mode, task)
+        v, f, offset, scale = convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"], filename + "_hand.ply", None,
+                                                         None, eval_mode, task)
         stats["hand"] = (0, 0) if v is None else (len(v), len(f))
+        if label_out and v is not None:
+            vertices = np.array(v, copy=True)
+            for a in range(3):
+                vertices[:, a] = r["origin"][a] + vertices[:, a]
+            vertices = torch.from_numpy(vertices)
+            labels = label_points(decoder, latent_vec, mano_results, obj_results, specs, vertices)
+            write_label_outputs(vertices, f, labels, filename + "_hand", offset, scale, viz)
+            stats["labels"] = labels
     if obj_branch:
         v, f, _, _ = convert_sdf_samples_to_ply(r["vol_obj"], r["origin"], r["voxel_size"], filename + "_obj.ply", offset, scale,
                                                 False)

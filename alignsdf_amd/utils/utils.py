@@ -73,5 +73,8 @@ def decode_sdf_multi_output(decoder, latent_vector, queries, mano_results, cam_i
         raise NotImplementedError("pass raw normalised xyz [M,3]; the pose embedding is folded into the HIP decoder")
     hip = hip_decoder_for(decoder)
     hip.set_sample(latent_vector, sample_embedding(specs, mano_results, obj_results, hip.combined))
+    if hip.num_class:
+        h, o, scores, _ = hip.classify_points(queries)
+        return h.unsqueeze(1), o.unsqueeze(1), scores
     h, o = hip.decode_points(queries)
     return h.unsqueeze(1), o.unsqueeze(1), torch.zeros(1, device=h.device)

@@ -111,6 +111,20 @@ int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int3
 int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, float* sdf_hand_dev,
                        float* sdf_obj_dev, void* stream);
 
+/* ---- Part classifier (specs["ClassifierBranch"]): classifier_head = nn.Linear(512, num_class) applied to the last
+ * hidden activation of the hand MLP (SeparateDecoder, networks/model.py:257-259,306-307) or of the single MLP
+ * (CombinedDecoder, networks/model.py:134-137,161-162).  w_host [num_class][512] / b_host [num_class] are host
+ * fp32; num_class <= ASDF_MAX_CLASSES.  May be called again to replace the weights. */
+#define ASDF_MAX_CLASSES 8
+int asdf_decoder_set_classifier(asdf_decoder_t* dec, const float* w_host, const float* b_host, int32_t num_class);
+
+/* asdf_decode_points plus the classifier: logits_dev [M][num_class] fp32 = `predicted_class` of the reference's
+ * decoder.forward, labels_dev [M] int32 = predicted_class.argmax(dim=1) (first maximum).  Either may be NULL, not
+ * both; the SDF outputs may be NULL.  Replaces one chunk of the label pass over the mesh vertices
+ * (utils/mesh.py:146-157).  ASDF_EINVAL when no classifier was set. */
+int asdf_decode_points_cls(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, float* sdf_hand_dev,
+                           float* sdf_obj_dev, float* logits_dev, int32_t* labels_dev, void* stream);
+
 /* ---- Lewiner marching cubes (replaces skimage.measure.marching_cubes_lewiner as called at
  * utils/mesh.py:354 and deep_sdf/mesh.py:81: level given, step_size 1, allow_degenerate True,
  * use_classic False, gradient_direction 'descent', no mask).  Volume is [n0][n1][n2] fp32 on the

@@ -186,6 +186,29 @@ def decode_points(state_dict, latent, xyz, specs, mano_results=None, obj_results
     return hand, obj
 
 
+def classify_points(state_dict, latent, xyz, specs, mano_results=None, obj_results=None, max_batch=2 ** 18):
+    """The label pass over explicit points (utils/mesh.py:146-157): `predicted_class` = classifier_head applied to the
+    input of the last layer of the hand MLP (SeparateDecoder, networks/model.py:306-307) or of the single MLP
+    (CombinedDecoder, networks/model.py:161-162).  Returns (scores [M, num_class] fp32, labels [M] int64 = argmax)."""
+    params = combined_params(state_dict) if "lin0.bias" in state_dict else effective_head_params(state_dict, "h")
+    wc = torch.as_tensor(state_dict["classifier_head.weight"]).float()
+    bc = torch.as_tensor(state_dict["classifier_head.bias"]).float()
+    latent = torch.as_tensor(latent).float().reshape(1, -1)
+    xyz = torch.as_tensor(xyz).float()
+    scores = torch.zeros(xyz.shape[0], wc.shape[0])
+    with torch.no_grad():
+        for head in range(0, xyz.shape[0], max_batch):
+            sub = xyz[head:head + max_batch]
+            feats = point_features(sub, specs, mano_results, obj_results)
+            inputs = torch.cat([latent.expand(sub.shape[0], -1), feats], 1)        # utils/utils.py:568-569
+            if "lin0.bias" not in state_dict:                                       # the hand head's slice, model.py:288-299
+                style, L = specs["EncodeStyle"], latent.shape[1]
+                inputs = inputs[:, :L + 3] if style == "obj" else (inputs[:, :-3] if style == "both" else inputs)
+            hidden = _run_head(params, inputs, inputs, stop_before_last=True)
+            scores[head:head + max_batch] = F.linear(hidden, wc, bc)
+    return scores, scores.argmax(dim=1)
+
+
 def get_higher_res_cube(hand_branch, obj_branch, vol_hand, vol_obj, N, voxel_size):
     """Zoom cube from the negative voxels (utils/mesh.py:198-256).  Returns (new_voxel_size 0-dim fp32,
     new_origin [3] fp32, bbox int64 [2][6] with -1 where a branch has no negative voxel)."""
