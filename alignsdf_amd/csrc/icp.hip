@@ -2,11 +2,17 @@
 // called from utils/mesh.py:385-395 with 30 000 surface samples per mesh and up to 100 iterations).
 //
 // Per iteration the reference does two exact nearest-neighbour sweeps through static KD-trees and a 4-unknown linear
-// least-squares solve.  Here a sweep is one brute-force kernel in fp64 (same arithmetic type as the reference, so the
-// neighbour assignments are the KD-tree's): one query per thread, the reference set streamed through LDS in tiles, the
-// squared-error and least-squares sums reduced per workgroup.  The host sums the per-workgroup partials in a fixed
-// order, applies the reference's stopping rules and solves the 4 unknowns in closed form.
-// Work per sweep: nq x nr distance evaluations (9e8 at 30k x 30k): VALU-bound, ~1 ms; HBM traffic is negligible.
+// least-squares solve.  Here both sweeps are ONE brute-force launch in fp64 (the reference's arithmetic type, so the
+// neighbour assignments are the KD-tree's) and the whole iteration stays on the device:
+//   K7a icp_nn_kernel      (query tile x reference split) blocks: 2 queries per thread, the split's reference points
+//                          streamed through LDS as SoA tiles (broadcast ds_read_b128), best (distance, index) per
+//                          (query, split).  30k x 30k is only 118 query tiles; the 8-way reference split is what puts
+//                          ~1900 waves on the 1024 SIMDs.
+//   K7b icp_update_kernel  per query: first minimum over the splits, the squared-error and least-squares terms,
+//                          block sums; the last block to finish adds the block sums in a fixed order, applies the
+//                          reference's stopping rules and solves the 4 unknowns in closed form into the device state.
+// The host enqueues iterations in batches and reads the 64-byte state between batches; kernels of iterations past
+// convergence return at once.  VALU-bound (1.8e9 distance evaluations per iteration); HBM traffic is negligible.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -17,40 +23,104 @@
 
 namespace asdf {
 
-constexpr int kIcpThreads = 128;
-constexpr int kIcpTile = 1024;          // reference points per LDS tile (24 KiB of fp64)
+constexpr int kIcpThreads = 256;
+constexpr int kIcpQpt = 2;              // queries per thread
+constexpr int kIcpQBlock = kIcpThreads * kIcpQpt;
+constexpr int kIcpTile = 1024;          // reference points per LDS tile (24 KiB of fp64, SoA)
+constexpr int kIcpSplits = 8;           // reference-set splits per query tile
 constexpr int kIcpSums = 9;             // err, sum X (3), sum Y (3), sum X.Y, sum X.X
+constexpr int kIcpBatch = 8;            // iterations enqueued between two reads of the state
+
+struct IcpState {
+  double scale, t[3];
+  double previous, error;
+  int iters, done;
+  unsigned ticket, pad;
+};
 
 // dir 0: queries = source samples p,  q = p * s + t,      reference set = target;  X = p,        Y = nearest target
 // dir 1: queries = target samples P,  q = (P - t) / s,    reference set = source;  X = nearest p, Y = P
-__global__ __launch_bounds__(kIcpThreads) void icp_sweep_kernel(const double* __restrict__ qpts, int nq,
-                                                                const double* __restrict__ rpts, int nr, int dir, double s,
-                                                                double t0, double t1, double t2, double* __restrict__ partials) {
-  __shared__ double tile[kIcpTile * 3];
-  __shared__ double red[kIcpThreads / 64][kIcpSums];
-  const int i = blockIdx.x * kIcpThreads + threadIdx.x;
-  const bool live = i < nq;
-  double p0 = 0, p1 = 0, p2 = 0;
-  if (live) { p0 = qpts[3 * i]; p1 = qpts[3 * i + 1]; p2 = qpts[3 * i + 2]; }
-  double q0, q1, q2;
-  if (dir == 0) { q0 = p0 * s + t0; q1 = p1 * s + t1; q2 = p2 * s + t2; }
-  else { q0 = (p0 - t0) / s; q1 = (p1 - t1) / s; q2 = (p2 - t2) / s; }
-  double best = INFINITY, b0 = 0, b1 = 0, b2 = 0;
-  for (int base = 0; base < nr; base += kIcpTile) {
-    const int n = min(kIcpTile, nr - base);
+__global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const double* __restrict__ src, int ns,
+                                                             const double* __restrict__ tgt, int nt,
+                                                             const IcpState* __restrict__ state, double* __restrict__ cand_d,
+                                                             int* __restrict__ cand_i) {
+  if (state->done) return;
+  __shared__ __attribute__((aligned(16))) double tx[kIcpTile], ty[kIcpTile], tz[kIcpTile];
+  const int qb_s = (ns + kIcpQBlock - 1) / kIcpQBlock;
+  int b = blockIdx.x;
+  const int dir = b >= qb_s * kIcpSplits;
+  if (dir) b -= qb_s * kIcpSplits;
+  const int split = b % kIcpSplits, qblock = b / kIcpSplits;
+  const double* qpts = dir ? tgt : src;
+  const double* rpts = dir ? src : tgt;
+  const int nq = dir ? nt : ns, nr = dir ? ns : nt;
+  const int chunk = (nr + kIcpSplits - 1) / kIcpSplits;
+  const int r_lo = split * chunk, r_hi = min(nr, r_lo + chunk);
+  const double s = state->scale, t0 = state->t[0], t1 = state->t[1], t2 = state->t[2];
+
+  double q0[kIcpQpt], q1[kIcpQpt], q2[kIcpQpt], best[kIcpQpt];
+  int bidx[kIcpQpt];
+#pragma unroll
+  for (int k = 0; k < kIcpQpt; ++k) {
+    const int i = qblock * kIcpQBlock + k * kIcpThreads + threadIdx.x;
+    double p0 = 0, p1 = 0, p2 = 0;
+    if (i < nq) { p0 = qpts[3 * (size_t)i]; p1 = qpts[3 * (size_t)i + 1]; p2 = qpts[3 * (size_t)i + 2]; }
+    if (dir == 0) { q0[k] = p0 * s + t0; q1[k] = p1 * s + t1; q2[k] = p2 * s + t2; }
+    else { q0[k] = (p0 - t0) / s; q1[k] = (p1 - t1) / s; q2[k] = (p2 - t2) / s; }
+    best[k] = INFINITY;
+    bidx[k] = r_lo;
+  }
+  for (int base = r_lo; base < r_hi; base += kIcpTile) {
+    const int n = min(kIcpTile, r_hi - base);
     __syncthreads();
-    for (int k = threadIdx.x; k < n * 3; k += kIcpThreads) tile[k] = rpts[(size_t)base * 3 + k];
+    for (int k = threadIdx.x; k < n; k += kIcpThreads) {
+      tx[k] = rpts[3 * (size_t)(base + k)]; ty[k] = rpts[3 * (size_t)(base + k) + 1]; tz[k] = rpts[3 * (size_t)(base + k) + 2];
+    }
     __syncthreads();
 #pragma unroll 4
     for (int j = 0; j < n; ++j) {
-      const double r0 = tile[3 * j], r1 = tile[3 * j + 1], r2 = tile[3 * j + 2];
-      const double d0 = q0 - r0, d1 = q1 - r1, d2 = q2 - r2;
-      const double d = d0 * d0 + d1 * d1 + d2 * d2;
-      if (d < best) { best = d; b0 = r0; b1 = r1; b2 = r2; }      // first minimum wins on exact ties
+      const double r0 = tx[j], r1 = ty[j], r2 = tz[j];
+#pragma unroll
+      for (int k = 0; k < kIcpQpt; ++k) {
+        const double d0 = q0[k] - r0, d1 = q1[k] - r1, d2 = q2[k] - r2;
+        const double d = d0 * d0 + d1 * d1 + d2 * d2;
+        if (d < best[k]) { best[k] = d; bidx[k] = base + j; }      // first minimum wins on exact ties
+      }
     }
   }
+  const size_t row = (size_t)split * ((size_t)ns + nt) + (dir ? ns : 0);
+#pragma unroll
+  for (int k = 0; k < kIcpQpt; ++k) {
+    const int i = qblock * kIcpQBlock + k * kIcpThreads + threadIdx.x;
+    if (i < nq) { cand_d[row + i] = best[k]; cand_i[row + i] = bidx[k]; }
+  }
+}
+
+__global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* __restrict__ src, int ns,
+                                                                 const double* __restrict__ tgt, int nt, IcpState* state,
+                                                                 const double* __restrict__ cand_d, const int* __restrict__ cand_i,
+                                                                 double* partials, int iteration, double stop_error,
+                                                                 double stop_improvement) {
+  if (state->done) return;
+  __shared__ double red[kIcpThreads / 64][kIcpSums];
+  __shared__ bool last;
+  const int g = blockIdx.x * kIcpThreads + threadIdx.x;
+  const int total = ns + nt;
+  const double s = state->scale, t0 = state->t[0], t1 = state->t[1], t2 = state->t[2];
   double v[kIcpSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (live) {
+  if (g < total) {
+    const int dir = g >= ns;
+    const int i = dir ? g - ns : g;
+    double best = cand_d[g];
+    int idx = cand_i[g];
+#pragma unroll
+    for (int r = 1; r < kIcpSplits; ++r) {
+      const double d = cand_d[(size_t)r * total + g];
+      if (d < best) { best = d; idx = cand_i[(size_t)r * total + g]; }    // splits are in index order: first minimum
+    }
+    const double* pp = (dir ? tgt : src) + 3 * (size_t)i;
+    const double* bb = (dir ? src : tgt) + 3 * (size_t)idx;
+    const double p0 = pp[0], p1 = pp[1], p2 = pp[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
     if (dir == 0) {
       v[0] = best;                                   // |q - ct|^2
       v[1] = p0; v[2] = p1; v[3] = p2; v[4] = b0; v[5] = b1; v[6] = b2;
@@ -76,59 +146,161 @@ __global__ __launch_bounds__(kIcpThreads) void icp_sweep_kernel(const double* __
     for (int k = 0; k < kIcpThreads / 64; ++k) a += red[k][threadIdx.x];
     partials[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = a;
   }
+  // the last block to arrive closes the iteration
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < kIcpSums) {
+    double a = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b) a += ((volatile double*)partials)[(size_t)b * kIcpSums + threadIdx.x];
+    red[0][threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double* sum = red[0];
+    const double n = (double)ns + (double)nt;
+    const double error = sqrt(sum[0] / n);
+    state->error = error;
+    state->iters = iteration + 1;
+    state->ticket = 0;
+    // stopping rules of run_icp_f (:66-72)
+    if (state->previous - error < stop_improvement) { state->done = 1; return; }
+    state->previous = error;
+    if (error < stop_error) { state->done = 1; return; }
+    // argmin_{s,t} sum |s X + t - Y|^2 over the stacked system (:76-107)
+    const double xm[3] = {sum[1] / n, sum[2] / n, sum[3] / n}, ym[3] = {sum[4] / n, sum[5] / n, sum[6] / n};
+    const double num = sum[7] - n * (xm[0] * ym[0] + xm[1] * ym[1] + xm[2] * ym[2]);
+    const double den = sum[8] - n * (xm[0] * xm[0] + xm[1] * xm[1] + xm[2] * xm[2]);
+    const double scale = num / den;
+    state->scale = scale;
+    for (int k = 0; k < 3; ++k) state->t[k] = ym[k] - scale * xm[k];
+  }
+}
+
+__global__ void icp_init_kernel(IcpState* state, const IcpState init) { *state = init; }
+
+// result layout of the C ABI, written straight into device-accessible host memory
+__global__ void icp_publish_kernel(const IcpState* state, double* out) {
+  out[0] = state->scale; out[1] = state->t[0]; out[2] = state->t[1]; out[3] = state->t[2];
+  out[4] = (double)state->iters; out[5] = state->error;
 }
 
 }  // namespace asdf
 
 using namespace asdf;
 
+namespace {
+struct IcpLayout {
+  size_t state, partials, cand_d, cand_i, bytes;
+  int update_blocks, nn_blocks;
+};
+IcpLayout icp_layout(int ns, int nt) {
+  IcpLayout l;
+  const size_t total = (size_t)ns + nt;
+  l.update_blocks = (int)((total + kIcpThreads - 1) / kIcpThreads);
+  l.nn_blocks = ((ns + kIcpQBlock - 1) / kIcpQBlock + (nt + kIcpQBlock - 1) / kIcpQBlock) * kIcpSplits;
+  l.state = 0;
+  l.partials = 256;
+  l.cand_d = l.partials + (size_t)l.update_blocks * kIcpSums * sizeof(double);
+  l.cand_i = l.cand_d + (size_t)kIcpSplits * total * sizeof(double);
+  l.bytes = l.cand_i + (size_t)kIcpSplits * total * sizeof(int);
+  return l;
+}
+}  // namespace
+
 extern "C" {
 
 int asdf_icp_workspace_bytes(int32_t ns, int32_t nt, size_t* bytes) {
   if (!bytes || ns < 1 || nt < 1) return ASDF_EINVAL;
-  const size_t blocks = (size_t)(ns + kIcpThreads - 1) / kIcpThreads + (size_t)(nt + kIcpThreads - 1) / kIcpThreads;
-  *bytes = blocks * kIcpSums * sizeof(double);
+  *bytes = icp_layout(ns, nt).bytes;
   return ASDF_OK;
 }
 
+namespace {
+struct IcpRun {
+  IcpLayout l;
+  IcpState* state;
+  double* partials;
+  double* cand_d;
+  int* cand_i;
+};
+int icp_begin(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, void* workspace_dev,
+              size_t workspace_bytes, hipStream_t st, IcpRun& r) {
+  if (!src_dev || !tgt_dev || !workspace_dev || ns < 1 || nt < 1 || max_iter < 1) return ASDF_EINVAL;
+  r.l = icp_layout(ns, nt);
+  if (workspace_bytes < r.l.bytes) return ASDF_ENOSPC;
+  char* ws = (char*)workspace_dev;
+  r.state = (IcpState*)(ws + r.l.state);
+  r.partials = (double*)(ws + r.l.partials);
+  r.cand_d = (double*)(ws + r.l.cand_d);
+  r.cand_i = (int*)(ws + r.l.cand_i);
+  // the initial state is a kernel argument of a fill, not a host buffer: nothing the caller must keep alive
+  IcpState h;
+  h.scale = 1.0; h.t[0] = h.t[1] = h.t[2] = 0.0;
+  h.previous = 1e8; h.error = 1e8;
+  h.iters = 0; h.done = 0; h.ticket = 0; h.pad = 0;
+  hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, r.state, h);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
+}
+void icp_iterations(const IcpRun& r, const double* src_dev, int ns, const double* tgt_dev, int nt, int first, int last,
+                    double stop_error, double stop_improvement, hipStream_t st) {
+  for (int it = first; it < last; ++it) {
+    hipLaunchKernelGGL(icp_nn_kernel, dim3(r.l.nn_blocks), dim3(kIcpThreads), 0, st, src_dev, ns, tgt_dev, nt, r.state, r.cand_d,
+                       r.cand_i);
+    hipLaunchKernelGGL(icp_update_kernel, dim3(r.l.update_blocks), dim3(kIcpThreads), 0, st, src_dev, ns, tgt_dev, nt, r.state,
+                       r.cand_d, r.cand_i, r.partials, it, stop_error, stop_improvement);
+  }
+}
+void icp_unpack(const IcpState& h, double* result) {
+  result[0] = h.scale; result[1] = h.t[0]; result[2] = h.t[1]; result[3] = h.t[2];
+  result[4] = (double)h.iters; result[5] = h.error;
+}
+}  // namespace
+
 int asdf_icp_ts(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, double stop_error,
                 double stop_improvement, void* workspace_dev, size_t workspace_bytes, double* result, void* stream) {
-  if (!src_dev || !tgt_dev || !workspace_dev || !result || ns < 1 || nt < 1 || max_iter < 1) return ASDF_EINVAL;
-  size_t need = 0;
-  asdf_icp_workspace_bytes(ns, nt, &need);
-  if (workspace_bytes < need) return ASDF_ENOSPC;
+  if (!result) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int bs = (ns + kIcpThreads - 1) / kIcpThreads, bt = (nt + kIcpThreads - 1) / kIcpThreads;
-  double* part = (double*)workspace_dev;
-  std::vector<double> host((size_t)(bs + bt) * kIcpSums);
-  double scale = 1.0, t[3] = {0, 0, 0};
-  double previous = 1e8, error = 1e8;
-  int it = 0;
-  for (it = 0; it < max_iter; ++it) {
-    hipLaunchKernelGGL(icp_sweep_kernel, dim3(bs), dim3(kIcpThreads), 0, st, src_dev, ns, tgt_dev, nt, 0, scale, t[0], t[1], t[2], part);
-    hipLaunchKernelGGL(icp_sweep_kernel, dim3(bt), dim3(kIcpThreads), 0, st, tgt_dev, nt, src_dev, ns, 1, scale, t[0], t[1], t[2],
-                       part + (size_t)bs * kIcpSums);
+  IcpRun r;
+  const int rc = icp_begin(src_dev, ns, tgt_dev, nt, max_iter, workspace_dev, workspace_bytes, st, r);
+  if (rc != ASDF_OK) return rc;
+  IcpState h;
+  h.done = 0;
+  for (int it = 0; it < max_iter && !h.done;) {
+    const int stop = it + kIcpBatch < max_iter ? it + kIcpBatch : max_iter;
+    icp_iterations(r, src_dev, ns, tgt_dev, nt, it, stop, stop_error, stop_improvement, st);
+    it = stop;
     ASDF_HIP(hipGetLastError());
-    ASDF_HIP(hipMemcpyAsync(host.data(), part, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    ASDF_HIP(hipMemcpyAsync(&h, r.state, sizeof(h), hipMemcpyDeviceToHost, st));
     ASDF_HIP(hipStreamSynchronize(st));
-    double sum[kIcpSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < bs + bt; ++b)
-      for (int k = 0; k < kIcpSums; ++k) sum[k] += host[(size_t)b * kIcpSums + k];
-    const double n = (double)ns + (double)nt;
-    error = std::sqrt(sum[0] / n);
-    // stopping rules of run_icp_f (:66-72)
-    if (previous - error < stop_improvement) { ++it; break; }
-    previous = error;
-    if (error < stop_error) { ++it; break; }
-    // argmin_{s,t} sum |s X + t - Y|^2 over the stacked system (:76-107)
-    const double xm[3] = {sum[1] / n, sum[2] / n, sum[3] / n}, ym[3] = {sum[4] / n, sum[5] / n, sum[6] / n};
-    const double num = sum[7] - n * (xm[0] * ym[0] + xm[1] * ym[1] + xm[2] * ym[2]);
-    const double den = sum[8] - n * (xm[0] * xm[0] + xm[1] * xm[1] + xm[2] * xm[2]);
-    scale = num / den;
-    for (int k = 0; k < 3; ++k) t[k] = ym[k] - scale * xm[k];
   }
-  result[0] = scale; result[1] = t[0]; result[2] = t[1]; result[3] = t[2];
-  result[4] = (double)(it > max_iter ? max_iter : it); result[5] = error;
+  icp_unpack(h, result);
+  return ASDF_OK;
+}
+
+int asdf_icp_ts_enqueue(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter,
+                        double stop_error, double stop_improvement, void* workspace_dev, size_t workspace_bytes,
+                        double* result_mapped, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IcpRun r;
+  const int rc = icp_begin(src_dev, ns, tgt_dev, nt, max_iter, workspace_dev, workspace_bytes, st, r);
+  if (rc != ASDF_OK) return rc;
+  icp_iterations(r, src_dev, ns, tgt_dev, nt, 0, max_iter, stop_error, stop_improvement, st);
+  if (result_mapped) hipLaunchKernelGGL(icp_publish_kernel, dim3(1), dim3(1), 0, st, r.state, result_mapped);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
+}
+
+int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream) {
+  if (!workspace_dev || !result) return ASDF_EINVAL;
+  IcpState h;
+  ASDF_HIP(hipMemcpyAsync(&h, workspace_dev, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ASDF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  icp_unpack(h, result);
   return ASDF_OK;
 }
 

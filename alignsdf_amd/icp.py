@@ -76,16 +76,63 @@ def run_icp_f(points_source, points_target, max_iter=100, stop_error=1e-3, stop_
 def icp_trans_scale(points_source, points_target, vertices, max_iter=100, device="cuda"):
     """sample normalisation + run_icp_f + get_trans_scale (:188-191) + the vertex transform of export_source_mesh
     (:193-196).  Returns a dict with scale, trans, iterations, error, all_scale, all_trans, vertices."""
-    ps, (offset_s, scale_s, offset_t, scale_t) = normalise_source(points_source, points_target)
-    scale, trans, iters, error = run_icp_f(ps, points_target, max_iter, device=device)
+    return finish_icp(start_icp(points_source, points_target, max_iter, device), vertices)
+
+
+class IcpJob:
+    """An ICP run in flight on the device (start_icp); finish_icp waits for it."""
+    __slots__ = ("src", "tgt", "ws", "host", "norm", "stream", "device", "done", "result")
+
+
+
+
+
+def start_icp(points_source, points_target, max_iter=100, device="cuda", stop_error=1e-3, stop_improvement=1e-5):
+    """Normalise the source samples and enqueue the whole ICP on the current stream without synchronising: pinned
+    staging + asynchronous uploads + asdf_icp_ts_enqueue.  The caller may queue other work behind it."""
+    dev = torch.device(device)
+    ps, norm = normalise_source(points_source, points_target)
+    job = IcpJob()
+    job.norm, job.device = norm, dev
+    job.stream = torch.cuda.current_stream(dev)
+    job.host = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).pin_memory() for a in (ps, points_target)]
+    job.src, job.tgt = (h.to(dev, non_blocking=True) for h in job.host)
+    L = _native.lib()
+    nbytes = ctypes.c_size_t()
+    _native.check(L.asdf_icp_workspace_bytes(job.src.shape[0], job.tgt.shape[0], ctypes.byref(nbytes)), "asdf_icp_workspace_bytes")
+    job.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    # the run publishes its outcome into pinned (device-accessible) host memory itself: any read-back copy would be a
+    # blit kernel, which cannot start while a decoder pass (one wave per SIMD holding the whole register file) is on
+    # the machine - the caller would wait for whatever it queued behind the ICP
+    job.result = torch.zeros(8, dtype=torch.float64).pin_memory()
+    with torch.cuda.device(dev):
+        _native.check(L.asdf_icp_ts_enqueue(job.src.data_ptr(), job.src.shape[0], job.tgt.data_ptr(), job.tgt.shape[0], int(max_iter),
+                                            float(stop_error), float(stop_improvement), job.ws.data_ptr(), job.ws.numel(),
+                                            job.result.data_ptr(), ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_ts_enqueue")
+        job.done = torch.cuda.Event()
+        job.done.record(job.stream)
+    return job
+
+
+def finish_icp(job, vertices):
+    """Wait for a start_icp job; returns the dict of icp_trans_scale for `vertices`."""
+    job.done.synchronize()            # the ICP only - not whatever was queued behind it
+    res = job.result.tolist()
+    scale, trans, iters, error = res[0], np.array([res[1], res[2], res[3]]), int(res[4]), res[5]
+    offset_s, scale_s, offset_t, scale_t = job.norm
     v = (np.asarray(vertices, np.float64) - offset_s) / scale_s * scale_t + offset_t
     return dict(scale=scale, trans=trans, iterations=iters, error=error, all_scale=scale_t * scale / scale_s,
                 all_trans=trans + offset_t * scale - offset_s * scale_t * scale / scale_s, vertices=v * scale + trans)
 
 
-def align_to_ground_truth(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=100, seed=0, device="cuda"):
-    """The eval-mode block of utils/mesh.py:385-395: sample both meshes, ICP, return (aligned verts, trans, scale)."""
+def start_alignment(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=100, seed=0, device="cuda"):
+    """First half of the eval-mode block of utils/mesh.py:385-395: sample both meshes, enqueue the ICP."""
     ps = sample_surface(verts, faces, samples, seed)
     pt = sample_surface(gt_verts, gt_faces, samples, seed + 1)
-    r = icp_trans_scale(ps, pt, verts, max_iter, device)
+    return start_icp(ps, pt, max_iter, device)
+
+
+def align_to_ground_truth(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=100, seed=0, device="cuda"):
+    """The eval-mode block of utils/mesh.py:385-395: sample both meshes, ICP, return (aligned verts, trans, scale)."""
+    r = finish_icp(start_alignment(verts, faces, gt_verts, gt_faces, samples, max_iter, seed, device), verts)
     return r["vertices"], r["all_trans"], r["all_scale"], r

@@ -50,7 +50,7 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
-def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False):
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False, midpoint=None):
     """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
@@ -66,7 +66,11 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     label_out=True runs the label pass (utils/mesh.py:137-157) over the hand mesh vertices right behind the hand's
     marching cubes (`labels_hand`, int64 device tensor; `host_labels_hand` with host_copy).  The decoder holds one
-    sample's folded constants at a time, so sample k is re-bound for it and sample k+1 bound again afterwards."""
+    sample's folded constants at a time, so sample k is re-bound for it and sample k+1 bound again afterwards.
+
+    midpoint(key, result), if given, is called for sample k between queuing pass 2 of sample k+1 and pass 1 of sample
+    k+2: GPU work it enqueues (the eval-mode ICP of sample k's hand mesh) lands between two decoder passes instead of
+    behind both, and its host part is covered by the pass that is already running."""
     from .marching_cubes import marching_cubes_device
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
     from .utils.utils import hip_decoder_for, sample_embedding
@@ -141,11 +145,17 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     while True:
         rebound = surfaces(r, cur)                      # MC of sample k, queued behind pass 1 of sample k+1
         if nxt is not None:
+            # fetch sample k+2 while the queue is short: a source that uploads its codes with a blocking copy would
+            # otherwise sit behind pass 2 of sample k+1 and hold the consumer back for a whole pass
+            after = next(it, None)
             if rebound:
                 bind(nxt)
             r_next = second_pass(bbox_next)
-            after = next(it, None)
+            if midpoint is not None:
+                midpoint(cur[0], r)
             bbox_after = first_pass(after) if after is not None else None
+        elif midpoint is not None:
+            midpoint(cur[0], r)
         yield cur[0], r
         if nxt is None:
             return
@@ -214,8 +224,21 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     with torch.no_grad():
         t_prev = time.perf_counter()
         hand_on = specs.get("HandBranch", True)
+
+        def hand_path(name):
+            return os.path.join(mesh_dir, "%s_hand" % name)
+
+        def begin_hand(key, r):
+            """Eval mode: component filter, surface sampling and the ICP launch of the hand mesh, slotted between two
+            decoder passes (see pipelined_two_pass); the consumer below only waits for the result."""
+            if "verts_hand" in r:
+                r["copy_done_hand"].synchronize()
+                r["pending_hand"] = mesh_utils.begin_export_surface(
+                    r["host_verts_hand"], r["host_faces_hand"], r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None,
+                    True, task, data_root=data_root)
+
         for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
-                                                    label_out=label_out and hand_on):
+                                                    label_out=label_out and hand_on, midpoint=begin_hand if eval_mode else None):
             rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
                    "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
             # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
@@ -225,10 +248,13 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                 if "verts_" + part in r:
                     r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
                     base = os.path.join(mesh_dir, "%s_%s" % (name, part))
-                    verts, faces, trans, icp_scale = mesh_utils.export_surface(
-                        r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"], base + ".ply",
-                        None if part == "hand" else offset, None if part == "hand" else sc, eval_mode and part == "hand", task,
-                        data_root=data_root)
+                    if part == "hand" and "pending_hand" in r:
+                        verts, faces, trans, icp_scale = mesh_utils.end_export_surface(r.pop("pending_hand"))
+                    else:
+                        verts, faces, trans, icp_scale = mesh_utils.export_surface(
+                            r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"], base + ".ply",
+                            None if part == "hand" else offset, None if part == "hand" else sc, False, task,
+                            data_root=data_root)
                     if part == "hand":
                         offset, sc = trans, icp_scale
                         rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])

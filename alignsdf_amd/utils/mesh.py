@@ -97,35 +97,66 @@ def ground_truth_mesh_path(ply_filename_out, task, data_root="data"):
     return os.path.join(data_root, task, "test", mesh_dir, gt_mesh_name)
 
 
-def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
-    """utils/mesh.py:371-397 for already placed vertices: keep the largest component, in eval mode align it to the
-    ground-truth mesh with the translate+scale ICP (K7) and export.  Returns (trans [3], scale [1]) like the reference
-    (zeros / one outside eval mode).  A missing ground-truth file is logged and the unaligned mesh is written (the
+def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
+    """First half of utils/mesh.py:371-397 for already placed vertices: keep the largest component and, in eval mode,
+    sample both meshes and ENQUEUE the translate+scale ICP (K7) against the ground-truth mesh without waiting for it.
+    Returns a ticket for end_mesh.  A missing ground-truth file is logged and the unaligned mesh is written (the
     reference would abort the run there)."""
     out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
-    trans, scale = np.array([0, 0, 0]), np.array([1])
+    job = None
     if eval_mode:
         gt_path = ground_truth_mesh_path(ply_filename_out, task, data_root)
         if os.path.exists(gt_path):
-            from ..icp import align_to_ground_truth, load_obj
+            from ..icp import load_obj, start_alignment
             gt_v, gt_f = load_obj(gt_path)
-            out_v, t, sc, _ = align_to_ground_truth(out_v, out_f, gt_v, gt_f)       # 30 000 samples, <= 100 iterations
-            trans, scale = np.asarray(t).reshape(1, 3), np.asarray(sc).reshape(1)
+            job = start_alignment(out_v, out_f, gt_v, gt_f)                         # 30 000 samples, <= 100 iterations
         else:
             logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh" % gt_path)
+    return out_v, out_f, job, ply_filename_out
+
+
+def end_mesh(ticket):
+    """Second half: wait for the ICP (if any), apply it, export.  Returns (trans [3], scale [1]) like the reference
+    (zeros / one outside eval mode)."""
+    out_v, out_f, job, ply_filename_out = ticket
+    trans, scale = np.array([0, 0, 0]), np.array([1])
+    if job is not None:
+        from ..icp import finish_icp
+        r = finish_icp(job, out_v)
+        out_v = r["vertices"]
+        trans, scale = np.asarray(r["all_trans"]).reshape(1, 3), np.asarray(r["all_scale"]).reshape(1)
     if ply_filename_out:
         os.makedirs(os.path.dirname(os.path.abspath(ply_filename_out)), exist_ok=True)
         write_ply(ply_filename_out, out_v, out_f)
     return trans, scale
 
 
+def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
+    """utils/mesh.py:371-397 for already placed vertices: keep the largest component, in eval mode align it to the
+    ground-truth mesh with the translate+scale ICP (K7) and export.  Returns (trans [3], scale [1])."""
+    return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root))
+
+
+def begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None,
+                         eval_mode=False, task="obman", largest_component=True, data_root="data"):
+    """place_vertices + begin_mesh: everything of the host tail up to (and including) enqueuing the eval-mode ICP."""
+    verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+    return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
+
+
+def end_export_surface(pending):
+    """Wait for the ICP of begin_export_surface (if any), write the file.  Returns (verts, faces, trans, scale)."""
+    verts, faces, ticket = pending
+    trans, sc = end_mesh(ticket)
+    return verts, faces, trans, sc
+
+
 def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
                    task="obman", largest_component=True, data_root="data"):
     """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397).
     Returns (verts, faces, trans, scale)."""
-    verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
-    trans, sc = finish_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
-    return verts, faces, trans, sc
+    return end_export_surface(begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset,
+                                                   scale, eval_mode, task, largest_component, data_root))
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,

@@ -142,10 +142,23 @@ int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doubl
  * tgt_dev [nt][3] the target samples, both fp64 on the device.  Runs until the reference's stopping rules fire
  * (error < stop_error, or improvement < stop_improvement, or max_iter) and writes, on the host,
  *   result[0] = scale, result[1..3] = trans, result[4] = iterations executed, result[5] = last RMS error.
- * Synchronises the stream once per iteration (72 B of sums per workgroup are read back). */
+ * The iteration (both nearest-neighbour sweeps, the sums, the stopping rules and the solve) stays on the device;
+ * asdf_icp_ts enqueues 8 iterations at a time and synchronises the stream between batches to read the 64-byte state. */
 int asdf_icp_workspace_bytes(int32_t ns, int32_t nt, size_t* bytes);
 int asdf_icp_ts(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, double stop_error,
                 double stop_improvement, void* workspace_dev, size_t workspace_bytes, double* result, void* stream);
+
+/* The same run without any host synchronisation: every one of the max_iter iterations is enqueued (iterations past
+ * convergence return at once), the outcome stays in the workspace.  asdf_icp_ts_result copies it to result[6] (layout
+ * above) and synchronises the stream; the workspace and both point sets must stay alive until then.
+ * result_mapped (optional) is device-accessible HOST memory (hipHostMalloc / hipHostRegister, 6 doubles) that the last
+ * kernel of the run fills: a caller that has queued further work behind the ICP waits on an event recorded after this
+ * call and reads it - any copy, even from a side stream, would be a kernel that cannot start while a decoder pass
+ * holds the whole register file of every SIMD. */
+int asdf_icp_ts_enqueue(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter,
+                        double stop_error, double stop_improvement, void* workspace_dev, size_t workspace_bytes,
+                        double* result_mapped, void* stream);
+int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream);
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,

@@ -9,18 +9,46 @@ from alignsdf_amd.utils import mesh as mu
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+EVAL = len(sys.argv) > 3 and sys.argv[3] == "eval"      # eval mode: translate+scale ICP of every hand mesh to a ground truth
 specs = syn.specs_for("nerf3")
 dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
 tmp = tempfile.mkdtemp()
 split = os.path.join(tmp, "split.json")
 json.dump({"filenames": ["x/%08d.jpg" % i for i in range(n_samples + 1)]}, open(split, "w"))
-rc.reconstruct(dec, specs, split, tmp, 0, 1, cube_dim=N)          # warm-up
+if EVAL:
+    # synthetic ground truth: a UV sphere near the hand surface (the analytic target, scaled and shifted so the ICP has work)
+    gt_dir = os.path.join(tmp, "data", "obman", "test", "mesh_hand")
+    os.makedirs(gt_dir)
+    nu, nv = 96, 48
+    th, ph = np.meshgrid(np.arange(nu) * 2 * np.pi / nu, (np.arange(nv) + 0.5) * np.pi / nv, indexing="ij")
+    P = np.stack([np.sin(ph) * np.cos(th), np.sin(ph) * np.sin(th), np.cos(ph)], -1).reshape(-1, 3)
+    P = (P * 0.35 + np.array([-0.25, 0, 0])) * 1.08 + np.array([0.03, -0.02, 0.015])
+    idx = lambda i, j: (i % nu) * nv + j
+    F = [(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)) for i in range(nu) for j in range(nv - 1)] + \
+        [(idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(nu) for j in range(nv - 1)]
+    for i in range(n_samples + 1):
+        with open(os.path.join(gt_dir, "%08d.obj" % i), "w") as f:
+            f.write("".join("v %.6f %.6f %.6f\n" % tuple(p) for p in P) + "".join("f %d %d %d\n" % (a + 1, b + 1, c + 1) for a, b, c in F))
+kw = dict(eval_mode=True, data_root=os.path.join(tmp, "data")) if EVAL else {}
+rc.reconstruct(dec, specs, split, tmp, 0, 1, cube_dim=N, **kw)          # warm-up
 torch.cuda.synchronize()
 t = time.perf_counter()
-recs = rc.reconstruct(dec, specs, split, tmp, 1, n_samples + 1, cube_dim=N)
+recs = rc.reconstruct(dec, specs, split, tmp, 1, n_samples + 1, cube_dim=N, **kw)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
-print("reconstruct() with PLY export: %d samples, %.1f ms/sample (N=%d), F_hand %d F_obj %d" % (n_samples, 1e3 * dt / n_samples, N, recs[-1]["F_hand"], recs[-1]["F_obj"]))
+print("reconstruct(%s) with PLY export: %d samples, %.1f ms/sample (N=%d), F_hand %d F_obj %d" % ("eval_mode" if EVAL else "", n_samples, 1e3 * dt / n_samples, N, recs[-1]["F_hand"], recs[-1]["F_obj"]))
+if EVAL:
+    from alignsdf_amd import icp
+    from alignsdf_amd.ply import read_ply
+    print("icp scale / trans of the last sample:", recs[-1]["icp_scale"], recs[-1]["icp_trans"])
+    gv, gf = icp.load_obj(os.path.join(gt_dir, "%08d.obj" % 1))
+    hv, hf = read_ply(os.path.join(tmp, "meshes", "%08d_obj.ply" % 1))
+    src, tgt = icp.sample_surface(np.asarray(hv, np.float64), hf, 30000, 0), icp.sample_surface(gv, gf, 30000, 1)
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = icp.icp_trans_scale(src, tgt, src)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+    print("stand-alone ICP 30k x 30k: %d iterations, %.1f ms total, %.2f ms / iteration" % (out["iterations"], 1e3 * (t1 - t0), 1e3 * (t1 - t0) / out["iterations"]))
 # host tail breakdown on the last sample's hand mesh
 from alignsdf_amd.ply import read_ply
 r = next(iter(rc.pipelined_two_pass(dec, specs, [(0, torch.from_numpy(syn.latent_code(1)).cuda(), None, None)], N)))[1]
