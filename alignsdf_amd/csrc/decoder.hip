@@ -140,7 +140,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 105; }
+int asdf_version(void) { return 106; }
 
 const char* asdf_strerror(int code) {
   switch (code) {

@@ -180,6 +180,50 @@ __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* _
   }
 }
 
+// Symmetric Chamfer distance of compute_trimesh_chamfer (deep_sdf/metrics/chamfer.py:217-229) on top of K7a's
+// candidates (identity transform): mean squared nearest-neighbour distance per direction.  Blocks [0, blocks_a) own the
+// a -> b queries, the rest the b -> a queries; the last block adds the block sums in a fixed order.
+__global__ __launch_bounds__(kIcpThreads) void chamfer_reduce_kernel(int na, int nb, IcpState* state,
+                                                                     const double* __restrict__ cand_d, double* partials,
+                                                                     double* out) {
+  __shared__ double red[kIcpThreads / 64];
+  __shared__ bool last;
+  const int blocks_a = (na + kIcpThreads - 1) / kIcpThreads;
+  const int dir = (int)blockIdx.x >= blocks_a;
+  const int i = (dir ? (int)blockIdx.x - blocks_a : (int)blockIdx.x) * kIcpThreads + threadIdx.x;
+  const int total = na + nb;
+  double v = 0.0;
+  if (i < (dir ? nb : na)) {
+    const int g = dir ? na + i : i;
+    double best = cand_d[g];
+#pragma unroll
+    for (int r = 1; r < kIcpSplits; ++r) best = fmin(best, cand_d[(size_t)r * total + g]);
+    v = best;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0;
+    for (int k = 0; k < kIcpThreads / 64; ++k) a += red[k];
+    partials[blockIdx.x] = a;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 2) {
+    const int lo = threadIdx.x ? blocks_a : 0, hi = threadIdx.x ? (int)gridDim.x : blocks_a;
+    double a = 0;
+    for (int b = lo; b < hi; ++b) a += ((volatile double*)partials)[b];
+    out[threadIdx.x] = a / (double)(threadIdx.x ? nb : na);
+    if (threadIdx.x == 0) state->ticket = 0;
+  }
+}
+
 __global__ void icp_init_kernel(IcpState* state, const IcpState init) { *state = init; }
 
 // result layout of the C ABI, written straight into device-accessible host memory
@@ -301,6 +345,23 @@ int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream) 
   ASDF_HIP(hipMemcpyAsync(&h, workspace_dev, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ASDF_HIP(hipStreamSynchronize((hipStream_t)stream));
   icp_unpack(h, result);
+  return ASDF_OK;
+}
+
+int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t nb, void* workspace_dev, size_t workspace_bytes,
+                 double* result, void* stream) {
+  if (!result) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  IcpRun r;
+  const int rc = icp_begin(a_dev, na, b_dev, nb, 1, workspace_dev, workspace_bytes, st, r);     // identity transform
+  if (rc != ASDF_OK) return rc;
+  hipLaunchKernelGGL(icp_nn_kernel, dim3(r.l.nn_blocks), dim3(kIcpThreads), 0, st, a_dev, na, b_dev, nb, r.state, r.cand_d, r.cand_i);
+  const int blocks = (na + kIcpThreads - 1) / kIcpThreads + (nb + kIcpThreads - 1) / kIcpThreads;   // <= update_blocks + 1
+  double* out = (double*)((char*)workspace_dev + 128);     // inside the 256-byte state slot
+  hipLaunchKernelGGL(chamfer_reduce_kernel, dim3(blocks), dim3(kIcpThreads), 0, st, na, nb, r.state, r.cand_d, r.partials, out);
+  ASDF_HIP(hipGetLastError());
+  ASDF_HIP(hipMemcpyAsync(result, out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  ASDF_HIP(hipStreamSynchronize(st));
   return ASDF_OK;
 }
 

@@ -160,6 +160,13 @@ int asdf_icp_ts_enqueue(const double* src_dev, int32_t ns, const double* tgt_dev
                         double* result_mapped, void* stream);
 int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream);
 
+/* Symmetric Chamfer distance of the reference's evaluation (compute_trimesh_chamfer, deep_sdf/metrics/chamfer.py:217-229):
+ * exact nearest neighbours both ways between a_dev [na][3] and b_dev [nb][3] (fp64, device), result[0] = mean squared
+ * distance a -> b (`gen_to_gt_chamfer` when a is the generated mesh's samples), result[1] = mean squared distance b -> a;
+ * the metric is their sum.  Workspace: asdf_icp_workspace_bytes(na, nb).  Synchronises the stream. */
+int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t nb, void* workspace_dev,
+                 size_t workspace_bytes, double* result, void* stream);
+
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
  * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */

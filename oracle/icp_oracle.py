@@ -61,3 +61,14 @@ def icp_trans_scale(points_source, points_target, vertices, max_iter=100):
     v = (np.asarray(vertices, np.float64) - n["offset_source"]) / n["scale_source"] * n["scale_target"] + n["offset_target"]
     return dict(scale=scale, trans=trans, iterations=iters, errors=errors, all_scale=all_scale, all_trans=all_trans,
                 vertices=v * scale + trans)
+
+
+def chamfer_sum(points_source, points_target):
+    """The distance part of compute_trimesh_chamfer (deep_sdf/metrics/chamfer.py:217-229) with the same scipy cKDTree
+    the reference imports: (gt_to_gen, gen_to_gt) mean squared nearest-neighbour distances; the metric is their sum."""
+    ps, pt = np.asarray(points_source, np.float64), np.asarray(points_target, np.float64)
+    one_distances, _ = cKDTree(ps).query(pt)
+    gt_to_gen = np.mean(np.square(one_distances))
+    two_distances, _ = cKDTree(pt).query(ps)
+    gen_to_gt = np.mean(np.square(two_distances))
+    return gt_to_gen, gen_to_gt
