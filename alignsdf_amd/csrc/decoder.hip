@@ -10,6 +10,7 @@
 #include "../../include/alignsdf_hip.h"
 #include "common.h"
 #include "pack.h"
+#include "sdf_mlp_f16_kernel.h"
 #include "sdf_mlp_kernel.h"
 
 namespace asdf {
@@ -33,6 +34,7 @@ struct FoldParams {
   float* cst;            // [heads][cst_offsets(kp).floats]
   int pf[ASDF_MAX_HEADS];
   int kp;                // point-feature K-steps (2 = affine xyz: the A fragments are folded here; > 2 = NeRF: static)
+  float s2[ASDF_MAX_HEADS];   // scale of the layer-2 constants: 1 for the fp32 image, S_w2 S_x for the split-half image
 };
 
 __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
@@ -60,14 +62,15 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
   const CstOffsets co = cst_offsets(p.kp);
   float* cst = p.cst + (size_t)head * co.floats;
   const int t = row >> 5, rr = row & 31;
+  const float sc = layer ? p.s2[head] : 1.0f;      // a power of two: the scaled values are exact
   if (lane == 0) {
     const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + (p.kp == 2 ? a3 : 0.0f);
     const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
-    cst[(layer ? co.c2 : co.c0) + (t * 2 + hh) * 16 + r] = c;
+    cst[(layer ? co.c2 : co.c0) + (t * 2 + hh) * 16 + r] = c * sc;
   }
   if (lane < 4 && p.kp == 2) {
     const int step = lane >> 1, hh = lane & 1;
-    cst[(layer ? co.a2 : co.a0) + (t * 2 + step) * 64 + hh * 32 + rr] = (lane < 3) ? a : 0.0f;
+    cst[(layer ? co.a2 : co.a0) + (t * 2 + step) * 64 + hh * 32 + rr] = (lane < 3) ? a * sc : 0.0f;
   }
 }
 
@@ -121,6 +124,11 @@ struct asdf_decoder {
   float* embed;     // [heads][MAXPF][4]
   float* cls;       // [kMaxClasses][512 in D-layout order] + [kMaxClasses]; null until asdf_decoder_set_classifier
   int num_class;
+  // split-half image (pack_decoder_f16; kp == 2 only, null otherwise) and the arithmetic in use
+  float* stream16;
+  float* cst16;
+  float s2[ASDF_MAX_HEADS];
+  int math;
   bool sample_bound;
 };
 
@@ -140,7 +148,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 106; }
+int asdf_version(void) { return 107; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -171,7 +179,7 @@ int asdf_device_count(void) {
 
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
-  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls};
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16};
   for (float* b : bufs) (void)hipFree(b);
   delete d;
 }
@@ -211,6 +219,16 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     if (e == hipSuccess) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
   };
   up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
+  d->math = ASDF_MATH_F32;
+  if (hp.kp == 2 && e == hipSuccess) {
+    if (!pack_decoder_f16(*spec, heads, hp)) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
+    up(&d->cst16, hp.cst16);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    for (int h = 0; h < kHeads; ++h) d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
+    for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel})
+      if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  }
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   if (e == hipSuccess)
@@ -263,9 +281,14 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
   }
   FoldParams fp;
   fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
-  for (int h = 0; h < kHeads; ++h) fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0;
+  for (int h = 0; h < kHeads; ++h) { fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0; fp.s2[h] = 1.0f; }
   fp.kp = d->kp;
   hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+  if (d->cst16) {      // the same fold into the split-half image, layer-2 constants scaled
+    fp.cst = d->cst16;
+    for (int h = 0; h < kHeads; ++h) fp.s2[h] = d->s2[h];
+    hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+  }
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
   return ASDF_OK;
@@ -314,7 +337,12 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
     ASDF_HIP(hipGetLastError());
     return ASDF_OK;
   }
-  if (d->kp == 2) {
+  if (d->math == ASDF_MATH_F16X3 && d->stream16) {
+    p.stream = d->stream16;
+    p.cst = d->cst16;
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_f16_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  } else if (d->kp == 2) {
     if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
     else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
   } else if (d->kp == 5) {
@@ -348,6 +376,15 @@ int asdf_decode_points(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.xyz = xyz_dev; p.P = M; p.N = 1; p.mode = kPointList;
   return launch_decode(d, p, (hipStream_t)stream);
 }
+
+int asdf_decoder_set_math(asdf_decoder_t* d, int32_t math) {
+  if (!d || (math != ASDF_MATH_F32 && math != ASDF_MATH_F16X3)) return ASDF_EINVAL;
+  if (math == ASDF_MATH_F16X3 && !d->stream16) return ASDF_EINVAL;      // NeRF-encoded decoders: fp32 MFMA only
+  d->math = math;
+  return ASDF_OK;
+}
+
+int asdf_decoder_get_math(const asdf_decoder_t* d) { return d ? d->math : ASDF_EINVAL; }
 
 int asdf_decoder_set_classifier(asdf_decoder_t* d, const float* w_host, const float* b_host, int32_t num_class) {
   if (!d || !w_host || !b_host || num_class < 1 || num_class > kMaxClasses) return ASDF_EINVAL;

@@ -1,5 +1,7 @@
 // Host-only packing of decoder weights into the layouts of sdf_layout.h (no device calls).
 #pragma once
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "../../include/alignsdf_hip.h"
@@ -15,7 +17,90 @@ struct HostPack {
   std::vector<float> cst;      // [heads][cst_offsets(kp).floats]  static parts filled, per-sample parts zero
   int kp;                      // point-feature K-steps of layers 0 / 2
   std::vector<float> emb;      // [heads][ASDF_MAX_POINT_FEATS][4]  identity-on-xyz default
+  // split-half image (ASDF_MATH_F16X3, kp == 2 only; see sdf_mlp_f16_kernel.h)
+  std::vector<uint16_t> stream16;   // [kStagesAll][kStageFloats * 2] fp16 bits: stage = [kblock 8][plane 2][lane 64][8]
+  std::vector<float> cst16;         // the constants block with the scaled entries of the split-half kernel
+  float s2[kHeads];                 // scale of the layer-2 accumulator (K0 applies it to c2 / A2)
 };
+
+constexpr float kActScale = 8.0f;   // S_x: activations are carried as x * S_x in the fp16 planes
+
+inline uint16_t f16_bits(float x) {
+  const _Float16 h = (_Float16)x;   // round to nearest even
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+inline float f16_round(float x) { return (float)(_Float16)x; }
+
+// weight scale of a layer ([rows][cols] with leading dimension ld): the power of two that puts max |w| * S in [512, 1024)
+inline float weight_scale(const float* w, int rows, int cols, int ld) {
+  float m = 0.0f;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) m = std::fmax(m, std::fabs(w[(size_t)r * ld + c]));
+  if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
+  return std::exp2(std::floor(std::log2(1000.0f / m)));
+}
+
+// Split-half image of the hidden layers: every weight w of layers 1-3 is carried as two fp16 planes of w * S_w
+// (hi = fp16(w S_w), lo = fp16(w S_w - hi)); the activations are carried the same way as x * S_x.  Three fp16 MFMAs
+// (hi.lo + lo.hi + hi.hi, the lo.lo term is below fp32 resolution) accumulate S_w S_x (W x) in fp32; biases and the
+// fp32 point-feature products enter the same accumulator pre-multiplied by S_w S_x, and the (exact, power-of-two)
+// rescale happens when the accumulator is turned into the next layer's planes.
+inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_params_t* heads, HostPack& hp) {
+  if (hp.kp != 2) return false;
+  const CstOffsets co = cst_offsets(2);
+  try {
+    hp.stream16.assign((size_t)kStagesAll * kStageFloats * 2, 0);
+    hp.cst16 = hp.cst;
+  } catch (...) {
+    return false;
+  }
+  for (int h = 0; h < spec.num_heads; ++h) {
+    const int in = kLatent + spec.point_feats[h];
+    const int n1 = kHidden - in;
+    const float* W1 = heads[h].w[1]; const float* W2 = heads[h].w[2]; const float* W3 = heads[h].w[3]; const float* W4 = heads[h].w[4];
+    const float sw1 = weight_scale(W1, n1, kHidden, kHidden), sw2 = weight_scale(W2, kHidden, n1, kHidden),
+                sw3 = weight_scale(W3, kHidden, kHidden, kHidden);
+    uint16_t* sp = &hp.stream16[(size_t)h * kStagesHead * kStageFloats * 2];
+    auto pack = [&](int ntiles, int stages_per_tile, float sw, auto weight_at) {
+      for (int t = 0; t < ntiles; ++t)
+        for (int q = 0; q < stages_per_tile; ++q) {
+          for (int kb = 0; kb < 8; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                // K-block kbg of the input = half of input tile kbg >> 1: D registers 8 (kbg & 1) + e of that tile
+                const int kbg = q * 8 + kb;
+                const int feat = 32 * (kbg >> 1) + tile_row(8 * (kbg & 1) + e, lane >> 5);
+                const int row = 32 * t + (lane & 31);
+                const float w = weight_at(row, feat) * sw;
+                const float hi = f16_round(w);
+                sp[((kb * 2 + 0) * 64 + lane) * 8 + e] = f16_bits(hi);
+                sp[((kb * 2 + 1) * 64 + lane) * 8 + e] = f16_bits(w - hi);
+              }
+          sp += kStageFloats * 2;
+        }
+    };
+    pack(kTilesL1, 4, sw1, [&](int row, int feat) { return row < n1 ? W1[(size_t)row * kHidden + feat] : 0.0f; });
+    pack(kTilesHidden, 2, sw2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
+    pack(kTilesHidden, 4, sw3, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
+    const float s1 = sw1 * kActScale, s3 = sw3 * kActScale;
+    hp.s2[h] = sw2 * kActScale;
+    float* c = &hp.cst16[(size_t)h * co.floats];
+    for (int t = 0; t < kTilesHidden; ++t)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * t + tile_row(r, hh);
+          if (t < kTilesL1) c[co.b1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] * s1 : 0.0f;
+          c[co.b3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row] * s3;
+          c[co.w4 + (t * 2 + hh) * 16 + r] = W4[row] / s3;
+          c[co.w4b + (t * 2 + hh) * 16 + r] = spec.outputs[h] > 1 ? W4[kHidden + row] / s3 : 0.0f;
+        }
+    c[co.b4 + 2] = 1.0f / sw1;      // accumulator -> next planes: relu(acc) / S_w (the S_x factor stays in)
+    c[co.b4 + 3] = 1.0f / sw2;
+  }
+  return true;
+}
 
 // K-steps the point features occupy in layers 0 and 2: 2 for (affine) xyz, ceil(pf / 2) for the NeRF encoding
 inline int point_ksteps(const asdf_decoder_spec_t& spec) {

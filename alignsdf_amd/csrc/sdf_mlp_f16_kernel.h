@@ -1,0 +1,286 @@
+// K1h: the fused SDF decoder with split-half arithmetic - the structure of sdf_mlp_kernel.h (register-resident
+// activations, head-outer / tile-inner loop, 16 KiB weight stages through a 4-slot LDS-DMA ring, deferred epilogues),
+// but the three hidden GEMMs run on v_mfma_f32_32x32x16_f16 instead of v_mfma_f32_32x32x2_f32:
+//
+//   every operand x is carried as two fp16 planes of x * S (S a power of two):  hi = fp16(x S),  lo = fp16(x S - hi),
+//   i.e. 22 significand bits, and a product sum is three MFMAs into ONE fp32 accumulator:
+//       acc += W_hi . x_lo + W_lo . x_hi + W_hi . x_hi          (the lo.lo term is < 2^-22 of the product)
+//   fp16 x fp16 products are exact in fp32 and the accumulation is fp32, so the result is fp32-class (measured on the
+//   synthetic decoders: max |error| vs fp64 2.8e-7, the same as the fp32 MFMA chain) at 3/16 of the MFMA time of the
+//   fp32 instruction.  Scales: weights S_w per layer (max |w| S_w in [512, 1024)), activations S_x = 8; biases and the
+//   fp32 point-feature products enter the accumulator pre-multiplied by S_w S_x (pack.h, K0), and the accumulator is
+//   rescaled by the exact power of two 1 / S_w when it is split into the next layer's planes.  fp16 subnormal inputs
+//   are honoured by the MFMA (tools/mfma_f16_probe.hip), so small low planes degrade gracefully.
+//
+// Operand maps (tools/mfma_f16_probe.hip): A lane l holds A[i = l & 31][k = 8 (l >> 5) + e], B lane l holds
+// B[k = 8 (l >> 5) + e][j = l & 31], e = 0..7 packed in 4 VGPRs; D as the fp32 form.  Registers 8 s .. 8 s + 7 of an
+// output tile are therefore, after the split, the B operand of K-block 2 tile + s of the next layer (the host packs
+// the weight columns in that order).
+#pragma once
+#include "sdf_mlp_kernel.h"
+
+namespace asdf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
+
+// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer
+__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
+    const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
+    const _Float16 a = (_Float16)t0, b = (_Float16)t1;
+    hi0[e] = a;
+    hi1[e] = b;
+    lo0[e] = (_Float16)(t0 - (float)a);
+    lo1[e] = (_Float16)(t1 - (float)b);
+  }
+}
+
+// One stage = 8 K-blocks (K = 128) of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
+// On entry (ah, al) hold the A fragments of K-block 0 of THIS stage; on exit those of the next stage in stream order.
+template <int KB, int Q, int SLOT, class Epi>
+__device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
+                                        const float* next_src, unsigned lds_ring_base, int lane, int wave, h8& ah, h8& al,
+                                        Epi&& epi) {
+  constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
+  const float* src = next_src + wave * 1024 + lane * 4;
+  const unsigned dst = lds_ring_base + (nslot * kStageFloats + wave * 1024) * 4;
+  const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * kStageFloats) + lane;
+  const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * kStageFloats) + lane;
+  h8 bufh[9], bufl[9];
+  bufh[0] = ah;
+  bufl[0] = al;
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    if (kb == 4) {
+      // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    bufh[kb + 1] = kb + 1 < 8 ? cur[((kb + 1) * 2 + 0) * 64] : nxt[0];
+    bufl[kb + 1] = kb + 1 < 8 ? cur[((kb + 1) * 2 + 1) * 64] : nxt[64];
+    constexpr int base = Q * 8;
+    acc = ASDF_MFMA16(bufh[kb], xl[base + kb], acc);
+    if (kb == 4) { lds_dma16_off<0>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    acc = ASDF_MFMA16(bufl[kb], xh[base + kb], acc);
+    if (kb == 4) { lds_dma16_off<1024>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
+    if (kb == 4) { lds_dma16_off<2048>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (kb == 5) { lds_dma16_off<3072>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (kb == 0) epi();
+  }
+  ah = bufh[8];
+  al = bufl[8];
+}
+
+// p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = 2 (affine xyz features) only.
+template <bool TWO_OUT>
+__device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
+  using CL = CstLayout<2>;
+  constexpr int KP = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ring = smem;
+  float* cst = smem + kLdsRingFloats;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+
+  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  if ((long long)blockIdx.x >= ntiles) return;
+
+  const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+
+#pragma unroll 1
+  for (int slot = 0; slot < p.num_mlps; ++slot) {
+    const int head = p.first_mlp + slot;
+    const float* hc = cst;
+    int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1, bcnt = 0;
+    int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1, ocnt = 0;   // TWO_OUT only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
+      for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
+    }
+    const float* sbase0 = p.stream + (size_t)head * kStagesHead * kStageFloats;
+#pragma unroll
+    for (int s = 0; s < kRing - 1; ++s) {
+      const float* src = sbase0 + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
+      const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0 (and my constants loads)
+    __syncthreads();                                      // everybody's pieces of stage 0, and the constants
+    h8 ah = (reinterpret_cast<const h8*>(ring) + lane)[0];
+    h8 al = (reinterpret_cast<const h8*>(ring) + lane)[64];
+    const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3];      // 1 / S_w of layers 1 and 2
+
+#pragma unroll 1
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
+      const bool valid = pi < p.P;
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      if (p.mode == kPointList) {
+        if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
+      } else {
+        grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+      }
+      float bp[KP];
+      bp[0] = half ? x1 : x0;
+      bp[1] = half ? 0.0f : x2;
+      const float* sbase = sbase0;
+      asm volatile("" : "+s"(sbase));
+      auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3
+        return sbase + (size_t)(s < kStagesHead ? s : s - kStagesHead) * kStageFloats;
+      };
+
+      // ---- layer 0 (fp32 MFMA, K = 4 point features): planes of relu(.) * S_x
+      h8 h0h[2 * kTilesHidden], h0l[2 * kTilesHidden];
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+#pragma unroll
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
+        split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1]);
+      }
+
+#define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, EPI) \
+  stage16<KB, Q, SLOT>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, EPI)
+
+      // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
+      h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
+      f32x16 acc1[2];
+#pragma unroll
+      for (int t = 0; t < kTilesL1; ++t) {
+        f32x16& acc = acc1[t & 1];
+        acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
+        auto epi = [&]() {
+          if (t == 0) return;
+          split_tile(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1]);
+        };
+        ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, epi);
+        ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue());
+        ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoEpilogue());
+        ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, NoEpilogue());
+      }
+
+      // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
+      h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
+      f32x16 acc2[2];
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16& acc = acc2[t & 1];
+        acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
+#pragma unroll
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
+        auto epi = [&]() {
+          if (t > 0) split_tile(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1]);
+          else split_tile(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
+                          h1l[2 * kTilesL1 - 1]);          // K-blocks 14, 15: consumed by the second stage of this tile
+        };
+        constexpr int S0 = kStagesL1;
+        if (t & 1) {
+          ASDF_STAGE16(16, 0, 2, acc, h1h, h1l, S0 + t * 2 + 0, epi);
+          ASDF_STAGE16(16, 1, 3, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
+        } else {
+          ASDF_STAGE16(16, 0, 0, acc, h1h, h1l, S0 + t * 2 + 0, epi);
+          ASDF_STAGE16(16, 1, 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
+        }
+      }
+
+      // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
+      float part = 0.0f, partb = 0.0f;
+      f32x16 acc3[2];
+      auto dot_w4 = [&](const f32x16 a, int t) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(hc + CL::kW4 + (t * 2 + half) * 16);
+        const f32x4* w4b = reinterpret_cast<const f32x4*>(hc + CL::kW4b + (t * 2 + half) * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 w = w4[c];
+          f32x4 wb = w;
+          if (TWO_OUT) wb = w4b[c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = __int_as_float(max(__float_as_int(a[c * 4 + r]), 0));
+            part = fmaf(v, w[r], part);
+            if (TWO_OUT) partb = fmaf(v, wb[r], partb);
+          }
+        }
+        if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
+      };
+#pragma unroll
+      for (int t = 0; t < kTilesHidden; ++t) {
+        f32x16& acc = acc3[t & 1];
+        acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
+        auto epi = [&]() {
+          if (t > 0) dot_w4(acc3[(t - 1) & 1], t - 1);
+          else split_tile(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
+                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1]);     // K-blocks 30, 31: fourth stage of this tile
+        };
+        constexpr int S0 = kStagesL1 + kStagesL2;
+        ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, epi);
+        ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoEpilogue());
+        ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoEpilogue());
+        ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, NoEpilogue());
+      }
+      dot_w4(acc3[(kTilesHidden - 1) & 1], kTilesHidden - 1);
+#undef ASDF_STAGE16
+      part += __shfl_xor(part, 32);
+      const float sdf = tanhf(part + hc[CL::kB4]);
+      float sdfb = 1.0f;
+      if (TWO_OUT) {
+        partb += __shfl_xor(partb, 32);
+        sdfb = tanhf(partb + hc[CL::kB4 + 1]);
+      }
+      const bool is_hand = head == 0;
+      if (valid && half == 0) {
+        float* out = is_hand ? p.sdf0 : p.sdf1;
+        if (out) out[pi] = sdf;
+        if (TWO_OUT && p.sdf1) p.sdf1[pi] = sdfb;
+      }
+      if (p.bbox && valid && half == 0 && p.mode != kPointList) {
+        const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
+        if (sdf < 0.0f) {
+          bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
+          bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
+        }
+        if (TWO_OUT && sdfb < 0.0f) {
+          omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
+          omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
+        }
+      }
+    }   // tiles
+
+    if (p.bbox) {
+      auto flush = [&](int* rec, int a0_, int a1_, int a2_, int b0_, int b1_, int b2_, int n) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          a0_ = min(a0_, __shfl_xor(a0_, m)); a1_ = min(a1_, __shfl_xor(a1_, m)); a2_ = min(a2_, __shfl_xor(a2_, m));
+          b0_ = max(b0_, __shfl_xor(b0_, m)); b1_ = max(b1_, __shfl_xor(b1_, m)); b2_ = max(b2_, __shfl_xor(b2_, m));
+          n += __shfl_xor(n, m);
+        }
+        if (lane == 0 && n) {
+          atomicMin(rec + 0, a0_); atomicMin(rec + 1, a1_); atomicMin(rec + 2, a2_);
+          atomicMax(rec + 3, b0_); atomicMax(rec + 4, b1_); atomicMax(rec + 5, b2_);
+          atomicAdd(rec + 6, n);
+        }
+      };
+      flush(p.bbox + (head == 0 ? 0 : 8), bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, bcnt);
+      if (TWO_OUT) flush(p.bbox + 8, omin0, omin1, omin2, omax0, omax1, omax2, ocnt);
+    }
+  }   // MLPs
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams p) { sdf_mlp_f16_body<false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
+
+}  // namespace asdf

@@ -7,11 +7,15 @@ state-dict layout of networks/model.py:191-282) and attributes (`latent_size`, `
 libalignsdf_hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from . import _native
+
+
+DEFAULT_MATH = "f16x3"
 
 
 def _effective(module_sd, name):
@@ -151,8 +155,22 @@ class HipSdfDecoder:
                               "asdf_decoder_set_classifier")
             self.num_class = int(cw.shape[0])
         self._pf = pf
+        # arithmetic of the hidden GEMMs: "f32" (fp32 MFMA chain) or "f16x3" (split-half fp16 MFMA, fp32-class results);
+        # ASDF_MATH overrides the default
+        self.math = "f32"
+        want = os.environ.get("ASDF_MATH", DEFAULT_MATH)
+        if want == "f16x3" and not self.nerf_features:
+            self.set_math("f16x3")
+        elif want not in ("f32", "f16x3"):
+            raise ValueError("ASDF_MATH must be 'f32' or 'f16x3', not %r" % want)
         self._latent = None
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
+
+    def set_math(self, math):
+        """Select the arithmetic of the hidden GEMMs ("f32" / "f16x3"); raises for NeRF-encoded decoders and f16x3."""
+        code = {"f32": _native.MATH_F32, "f16x3": _native.MATH_F16X3}[math]
+        _native.check(self._L.asdf_decoder_set_math(self._h, code), "asdf_decoder_set_math")
+        self.math = math
 
     def close(self):
         if getattr(self, "_h", None):

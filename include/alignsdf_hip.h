@@ -111,6 +111,19 @@ int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int3
 int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, float* sdf_hand_dev,
                        float* sdf_obj_dev, void* stream);
 
+/* ---- Arithmetic of the three hidden GEMMs of the decoder sweeps (asdf_decode_grid / asdf_decode_points):
+ *   ASDF_MATH_F32    v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain (the default after create);
+ *   ASDF_MATH_F16X3  split-half: every operand carried as two fp16 planes (22 significand bits) of a power-of-two
+ *                    scaled value, a product sum = three v_mfma_f32_32x32x16_f16 into one fp32 accumulator.  fp32-class
+ *                    results (same error against fp64 as the fp32 chain on the test decoders, well inside the 1e-5 bar)
+ *                    at 3/16 of the matrix-pipe time.  Available for xyz / pose-aligned (affine) point features;
+ *                    ASDF_EINVAL for NeRF-encoded decoders.  The label pass (asdf_decode_points_cls) always runs fp32.
+ * May be switched at any time between launches. */
+#define ASDF_MATH_F32 0
+#define ASDF_MATH_F16X3 1
+int asdf_decoder_set_math(asdf_decoder_t* dec, int32_t math);
+int asdf_decoder_get_math(const asdf_decoder_t* dec);
+
 /* ---- Part classifier (specs["ClassifierBranch"]): classifier_head = nn.Linear(512, num_class) applied to the last
  * hidden activation of the hand MLP (SeparateDecoder, networks/model.py:257-259,306-307) or of the single MLP
  * (CombinedDecoder, networks/model.py:134-137,161-162).  w_host [num_class][512] / b_host [num_class] are host
