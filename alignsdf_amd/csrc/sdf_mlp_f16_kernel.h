@@ -26,60 +26,80 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
+// LDS: ring + constants + one 8-int negative-voxel record per thread (the register file has no room for them)
+constexpr int kLdsBytesF16 = kLdsBytes + 256 * 8 * 4;
 
-// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer
-__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
+// schedule knobs (tools/k1h_ablate.hip sweeps them; the values here are the shipped ones)
+#ifndef ASDF16_PREFETCH
+#define ASDF16_PREFETCH 1        // A fragments are read from LDS this many K-blocks ahead of their MFMAs
+#endif
+#ifndef ASDF16_BARRIER_KB
+#define ASDF16_BARRIER_KB 4      // K-block in front of which the stage's wait + barrier sit
+#endif
+
+// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer; amax tracks the largest value
+// handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it, sdf_layout / alignsdf_hip.h)
+__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
     const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
+#ifndef ASDF16_NO_RANGE_CHECK
+    amax = fmaxf(amax, fmaxf(t0, t1));
+#endif
     const _Float16 a = (_Float16)t0, b = (_Float16)t1;
     hi0[e] = a;
     hi1[e] = b;
     lo0[e] = (_Float16)(t0 - (float)a);
     lo1[e] = (_Float16)(t1 - (float)b);
   }
+#ifndef ASDF16_NO_RANGE_CHECK
+  asm volatile("" : "+v"(amax));      // keep the running maximum where it is computed (see dot_w4's pin in sdf_mlp_kernel.h)
+#endif
 }
 
 // One stage = 8 K-blocks (K = 128) of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
-// On entry (ah, al) hold the A fragments of K-block 0 of THIS stage; on exit those of the next stage in stream order.
-template <int KB, int Q, int SLOT, class Epi>
+// On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
+// stage in stream order.  ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier.
+template <int KB, int Q, int SLOT, int ABL, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
-                                        const float* next_src, unsigned lds_ring_base, int lane, int wave, h8& ah, h8& al,
-                                        Epi&& epi) {
+                                        const float* next_src, unsigned lds_ring_base, int lane, int wave,
+                                        h8 (&ah)[ASDF16_PREFETCH], h8 (&al)[ASDF16_PREFETCH], Epi&& epi) {
+  constexpr int PF = ASDF16_PREFETCH;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
   const float* src = next_src + wave * 1024 + lane * 4;
   const unsigned dst = lds_ring_base + (nslot * kStageFloats + wave * 1024) * 4;
   const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * kStageFloats) + lane;
   const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * kStageFloats) + lane;
-  h8 bufh[9], bufl[9];
-  bufh[0] = ah;
-  bufl[0] = al;
+  h8 bufh[8 + PF], bufl[8 + PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) { bufh[i] = ah[i]; bufl[i] = al[i]; }
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) {
-    if (kb == 4) {
+    if (kb == ASDF16_BARRIER_KB && !(ABL & 1)) {
       // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     }
-    bufh[kb + 1] = kb + 1 < 8 ? cur[((kb + 1) * 2 + 0) * 64] : nxt[0];
-    bufl[kb + 1] = kb + 1 < 8 ? cur[((kb + 1) * 2 + 1) * 64] : nxt[64];
+    bufh[kb + PF] = kb + PF < 8 ? cur[((kb + PF) * 2 + 0) * 64] : nxt[((kb + PF - 8) * 2 + 0) * 64];
+    bufl[kb + PF] = kb + PF < 8 ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - 8) * 2 + 1) * 64];
     constexpr int base = Q * 8;
+    const bool dma = !(ABL & 1);
     acc = ASDF_MFMA16(bufh[kb], xl[base + kb], acc);
-    if (kb == 4) { lds_dma16_off<0>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<0>(src, dst); __builtin_amdgcn_sched_barrier(0); }
     acc = ASDF_MFMA16(bufl[kb], xh[base + kb], acc);
-    if (kb == 4) { lds_dma16_off<1024>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<1024>(src, dst); __builtin_amdgcn_sched_barrier(0); }
     acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
-    if (kb == 4) { lds_dma16_off<2048>(src, dst); __builtin_amdgcn_sched_barrier(0); }
-    if (kb == 5) { lds_dma16_off<3072>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<2048>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    if (dma && kb == ASDF16_BARRIER_KB + 1) { lds_dma16_off<3072>(src, dst); __builtin_amdgcn_sched_barrier(0); }
     if (kb == 0) epi();
   }
-  ah = bufh[8];
-  al = bufl[8];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) { ah[i] = bufh[8 + i]; al[i] = bufl[8 + i]; }
 }
 
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = 2 (affine xyz features) only.
-template <bool TWO_OUT>
+template <bool TWO_OUT, int ABL = 0>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using CL = CstLayout<2>;
   constexpr int KP = 2;
@@ -101,8 +121,14 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   for (int slot = 0; slot < p.num_mlps; ++slot) {
     const int head = p.first_mlp + slot;
     const float* hc = cst;
-    int bmin0 = 0x7fffffff, bmin1 = 0x7fffffff, bmin2 = 0x7fffffff, bmax0 = -1, bmax1 = -1, bmax2 = -1, bcnt = 0;
+    // negative-voxel bounding box of this MLP's output(s) + the out-of-range count, per thread, in LDS:
+    // rec[0..2] min index, rec[3..5] max index, rec[6] count, rec[7] points whose activations left the fp16 range (or
+    // whose output is not in [-1, 1]); second output of a CombinedDecoder in orec (count only shares rec[7])
+    int* rec = reinterpret_cast<int*>(cst + CL::kFloats) + tid * 8;
     int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1, ocnt = 0;   // TWO_OUT only
+    rec[0] = rec[1] = rec[2] = 0x7fffffff;
+    rec[3] = rec[4] = rec[5] = -1;
+    rec[6] = rec[7] = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
@@ -111,16 +137,21 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     }
     const float* sbase0 = p.stream + (size_t)head * kStagesHead * kStageFloats;
 #pragma unroll
-    for (int s = 0; s < kRing - 1; ++s) {
+    for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
       const float* src = sbase0 + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
       const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
 #pragma unroll
       for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
     }
+    if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0 (and my constants loads)
     __syncthreads();                                      // everybody's pieces of stage 0, and the constants
-    h8 ah = (reinterpret_cast<const h8*>(ring) + lane)[0];
-    h8 al = (reinterpret_cast<const h8*>(ring) + lane)[64];
+    h8 ah[ASDF16_PREFETCH], al[ASDF16_PREFETCH];
+#pragma unroll
+    for (int i = 0; i < ASDF16_PREFETCH; ++i) {
+      ah[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 0) * 64];
+      al[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 1) * 64];
+    }
     const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3];      // 1 / S_w of layers 1 and 2
 
 #pragma unroll 1
@@ -133,6 +164,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       } else {
         grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       }
+      float amax = 0.0f;                        // largest activation plane value of this tile
       float bp[KP];
       bp[0] = half ? x1 : x0;
       bp[1] = half ? 0.0f : x2;
@@ -149,14 +181,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
-        split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1]);
+        split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, EPI) \
-  stage16<KB, Q, SLOT>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, EPI)
+  stage16<KB, Q, SLOT, ABL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, EPI)
 
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
       h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
+      if (ABL & 4) for (int t = 0; t < 2 * kTilesL1; ++t) { h1h[t] = h0h[t]; h1l[t] = h0l[t]; }
       f32x16 acc1[2];
 #pragma unroll
       for (int t = 0; t < kTilesL1; ++t) {
@@ -164,7 +197,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
         auto epi = [&]() {
           if (t == 0) return;
-          split_tile(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1]);
+          if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
+          split_tile(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax);
         };
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, epi);
         ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue());
@@ -174,6 +208,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
+      if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
       f32x16 acc2[2];
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
@@ -182,9 +217,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
         auto epi = [&]() {
-          if (t > 0) split_tile(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1]);
+          if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
+          if (t > 0) split_tile(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax);
           else split_tile(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                          h1l[2 * kTilesL1 - 1]);          // K-blocks 14, 15: consumed by the second stage of this tile
+                          h1l[2 * kTilesL1 - 1], amax);          // K-blocks 14, 15: consumed by the second stage of this tile
         };
         constexpr int S0 = kStagesL1;
         if (t & 1) {
@@ -221,9 +257,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         f32x16& acc = acc3[t & 1];
         acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
         auto epi = [&]() {
+          if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) dot_w4(acc3[(t - 1) & 1], t - 1);
           else split_tile(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
-                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1]);     // K-blocks 30, 31: fourth stage of this tile
+                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax);     // K-blocks 30, 31: fourth stage of this tile
         };
         constexpr int S0 = kStagesL1 + kStagesL2;
         ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, epi);
@@ -248,9 +285,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
       if (p.bbox && valid && half == 0 && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
+        if (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f))) rec[7] += 1;
         if (sdf < 0.0f) {
-          bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
-          bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;
+          rec[0] = min(rec[0], i0); rec[1] = min(rec[1], i1); rec[2] = min(rec[2], i2);
+          rec[3] = max(rec[3], i0); rec[4] = max(rec[4], i1); rec[5] = max(rec[5], i2); rec[6] += 1;
         }
         if (TWO_OUT && sdfb < 0.0f) {
           omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
@@ -273,8 +311,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           atomicAdd(rec + 6, n);
         }
       };
-      flush(p.bbox + (head == 0 ? 0 : 8), bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, bcnt);
+      flush(p.bbox + (head == 0 ? 0 : 8), rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6]);
       if (TWO_OUT) flush(p.bbox + 8, omin0, omin1, omin2, omax0, omax1, omax2, ocnt);
+      // record word 7: points out of range (0 unless the fp16 planes overflowed; the host then falls back to fp32)
+      int bad = rec[7];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) bad += __shfl_xor(bad, m);
+      if (lane == 0 && bad) atomicAdd(p.bbox + (head == 0 ? 7 : 15), bad);
     }
   }   // MLPs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

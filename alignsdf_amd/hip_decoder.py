@@ -172,6 +172,18 @@ class HipSdfDecoder:
         _native.check(self._L.asdf_decoder_set_math(self._h, code), "asdf_decoder_set_math")
         self.math = math
 
+    def fall_back_if_overflowed(self, bbox_host):
+        """bbox words 7 / 15 count outputs outside [-1, 1]: non-zero only if an activation overflowed the fp16 planes of
+        the split-half arithmetic.  Switches this decoder to the fp32 MFMA chain (for good) and returns True; the caller
+        repeats the pass."""
+        if self.math == "f16x3" and (int(bbox_host[7]) or int(bbox_host[15])):
+            import logging
+            logging.warning("split-half decoder: %d outputs out of range (an activation left the fp16 range); "
+                            "falling back to the fp32 MFMA kernel", int(bbox_host[7]) + int(bbox_host[15]))
+            self.set_math("f32")
+            return True
+        return False
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.asdf_decoder_destroy(self._h)

@@ -103,6 +103,9 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     def second_pass(bbox):
         b = bbox.cpu().numpy()                          # waits for pass 1: the zoom cube is data dependent
+        if hip.fall_back_if_overflowed(b):              # split-half arithmetic out of fp16 range: the decoder is still
+            # bound to this sample and now on the fp32 kernel - repeat its pass 1
+            b = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)[2].cpu().numpy()
         boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
         nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
         vh, vo, _ = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=False, hand=hb, obj=ob)

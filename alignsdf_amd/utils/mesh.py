@@ -242,6 +242,9 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     # head is not evaluated at all (the reference computes and discards it)
     _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
     b = bbox.cpu().numpy()
+    if hip.fall_back_if_overflowed(b):          # split-half arithmetic out of fp16 range: repeat on the fp32 kernel
+        _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
+        b = bbox.cpu().numpy()
     boxes = []
     if hand_branch:
         boxes.append((b[0:3], b[3:6], int(b[6])))

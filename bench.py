@@ -32,6 +32,12 @@ from alignsdf_amd import synthetic as syn  # noqa: E402
 FLOP_PER_POINT_HEAD = 1_573_888      # dense formulation the reference executes
 EXEC_FLOP_PER_POINT_HEAD = 2 * (4 * 512 + 512 * 256 + 260 * 512 + 512 * 512 + 512)   # after folding the latent columns
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense BF16/F16 MFMA (v_mfma_f32_32x32x16_f16: 32 cycles/SIMD at 2.4 GHz)
+# split-half kernel: the three hidden GEMMs issue 3 fp16 MFMAs per product sum (padded shapes), layers 0 / 2's point
+# features stay on the fp32 MFMA
+EXEC_F16_FLOP_PER_POINT_HEAD = 3 * 2 * (512 * 256 + 256 * 512 + 512 * 512)
+EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD = 2 * (4 * 512 + 4 * 512 + 512)
+MEASURED_F16_MFMA_CEILING_TFLOPS = 1700.0   # tools/mfma_f16_probe.hip: 1639-1732 TFLOP/s sustained (32.4 cycles/MFMA at the clock the chip holds under that load)
 
 
 def cpu_baseline(tag, N, vol_hand, vol_obj, budget_chunks=3):
@@ -96,6 +102,8 @@ def main():
     ap.add_argument("--grid", type=int, default=256, help="grid resolution N (BASELINE metric is quoted at 256)")
     ap.add_argument("--tag", default="nerf3", choices=["nerf3", "both9"], help="nerf3 = ObMan config, both9 = DexYCB MANO-aligned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", default=None, choices=["f32", "f16x3"],
+                    help="arithmetic of the hidden GEMMs (default: the product's default, split-half fp16 MFMA)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,6 +127,8 @@ def main():
     N = args.grid
     specs = syn.specs_for(args.tag)
     dec = HipSdfDecoder(syn.full_state_dict(args.tag), 256, specs["PointFeatSize"], specs["EncodeStyle"], device=dev)
+    if args.math is not None:
+        dec.set_math(args.math)
     # 64 distinct synthetic samples, resident on the device before timing
     codes = []
     for s in range(64):
@@ -168,19 +178,34 @@ def main():
     else:
         merged = records
 
-    # dominant kernel: sdf_mlp_kernel (2 launches per step), timed with HIP events on the launch stream
+    # dominant kernel: the fused decoder (2 launches per step), timed with HIP events on the launch stream
     k1_ms = [e[0].elapsed_time(e[1]) for e in k1_events]
     k1_avg_s = float(np.mean(k1_ms)) * 1e-3
     alg_flop = N ** 3 * 2 * FLOP_PER_POINT_HEAD
-    exec_flop = N ** 3 * 2 * EXEC_FLOP_PER_POINT_HEAD
+    split = dec.math == "f16x3"
+    kernel_name = "sdf_mlp_f16_kernel" if split else "sdf_mlp_kernel"
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    exec_flop = N ** 3 * 2 * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
+
+    # the other arithmetic, outside the timed region: one sample for the record
+    other = None
+    if world == 1:
+        dec.set_math("f32" if split else "f16x3")
+        run(0, 1)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run(1, 2)
+        torch.cuda.synchronize(dev)
+        other = {"math": dec.math, "ms_per_step": 1e3 * (time.perf_counter() - t1) / 2}
+        dec.set_math("f16x3" if split else "f32")
 
     # HBM traffic of the dominant kernel comes from PMC passes (rocprofv3 cannot run inside the timed region);
     # the committed summary of the last collection is reported when it matches this grid
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_f16.json" if split else "r01_hbm_traffic.json")) as f:
             t = json.load(f)
-        if t.get("grid") == N:
+        if t.get("grid") == N and t.get("kernel") == kernel_name:
             traffic = t["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -198,7 +223,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 as 2 x f16 planes (3 x v_mfma_f32_32x32x16_f16 per product sum, fp32 accumulate)" if split else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "single sample, hand+object dual SDF decoder, N=%d grid, 2 passes (coarse + zoom cube) + HIP "
@@ -210,20 +235,34 @@ def main():
                 "mesh_sizes_last_sample": merged[-1] if merged else None,
             },
             "roofline": {
-                "bound": "mfma", "kernel": "sdf_mlp_kernel",
-                "achieved": alg_flop / k1_avg_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": alg_flop / k1_avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                "bound": "mfma", "kernel": kernel_name,
+                "achieved": alg_flop / k1_avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg_flop / k1_avg_s / 1e12 / peak, "traffic": traffic,
+                "traffic_source": "profiles/r01_hbm_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" % (
+                    "_f16" if split else ""),
                 "launch_ms": 1e3 * k1_avg_s, "launches_timed": len(k1_ms),
                 "algorithmic_flop_per_launch": alg_flop,
                 "executed_flop_per_launch": exec_flop,
                 "achieved_executed": exec_flop / k1_avg_s / 1e12,
-                "frac_executed": exec_flop / k1_avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "note": "achieved counts the reference's dense FLOPs (1,573,888 per point per head); the kernel folds the "
-                        "per-sample-constant latent columns into a bias and issues %d, so frac can exceed 1; "
-                        "frac_executed is the MFMA pipe utilisation" % EXEC_FLOP_PER_POINT_HEAD,
+                "frac_executed": exec_flop / k1_avg_s / 1e12 / peak,
+                "note": ("achieved counts the reference's dense fp32 FLOPs (1,573,888 per point per head) against the fp16 MFMA "
+                         "peak, because that is the instruction issued: each fp32 product sum is carried as two fp16 planes per "
+                         "operand and costs three v_mfma_f32_32x32x16_f16 (%d MFMA FLOPs per point per head, plus %d on the fp32 "
+                         "MFMA for the point features); frac_executed is the matrix-pipe utilisation against the 2.5 PFLOP/s "
+                         "spec, frac_of_measured_ceiling against what a bare MFMA loop sustains on this chip" % (
+                             EXEC_F16_FLOP_PER_POINT_HEAD, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD)) if split else (
+                    "achieved counts the reference's dense FLOPs (1,573,888 per point per head); the kernel folds the "
+                    "per-sample-constant latent columns into a bias and issues %d, so frac can exceed 1; "
+                    "frac_executed is the MFMA pipe utilisation" % EXEC_FLOP_PER_POINT_HEAD),
             },
         }
+        if split:
+            result["roofline"]["frac_of_measured_ceiling"] = exec_flop / k1_avg_s / 1e12 / MEASURED_F16_MFMA_CEILING_TFLOPS
+            result["roofline"]["fp32_mfma_equivalent"] = {
+                "note": "the same algorithmic FLOPs against the fp32 MFMA peak the reference arithmetic would be priced at",
+                "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg_flop / k1_avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        if other is not None:
+            result["other_math"] = other
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.tag, N, vh.cpu().numpy(), vo.cpu().numpy())
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]

@@ -93,7 +93,9 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
  * writing sdf_hand[N^3], sdf_obj[N^3] (device; either may be NULL - a SeparateDecoder head whose output is NULL is
  * not evaluated, and its bbox record stays empty) and, if bbox_dev != NULL, the
  * per-head bounding box of negative voxels as int32[16]:
- *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels.
+ *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels,
+ *   [h*8 + 7] = #points whose hidden activations left the fp16 range of the split-half planes (|x| >= 8188) - always
+ *   0 under ASDF_MATH_F32; if non-zero under ASDF_MATH_F16X3 the caller should switch to ASDF_MATH_F32 and repeat.
  * Replaces one pass of utils/mesh.py:27-63 (or :82-115) plus the nonzero/min/max of
  * get_higher_res_cube (utils/mesh.py:208-237); deep_sdf/mesh.py:24-54 for the legacy entry point. */
 int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,

@@ -1,0 +1,127 @@
+"""Both arithmetic modes of the decoder sweeps against the reference goldens: the fp32 MFMA chain ("f32") and the
+split-half fp16 MFMA kernel ("f16x3", the default).  Everything else in the GPU suite runs on the default."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _decoder(tag):
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.utils import hip_decoder_for, sample_embedding
+    specs = syn.specs_for(tag)
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()})
+    hip = hip_decoder_for(dec)
+    lat = torch.from_numpy(syn.latent_code(0)).cuda()
+    mano = obj = None
+    if specs["PointFeatSize"] == 9 and specs["EncodeStyle"] != "nerf":
+        m, o = syn.pose_inputs(0)
+        mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()}
+        obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
+    hip.set_sample(lat, sample_embedding(specs, mano, obj, hip.combined))
+    return hip
+
+
+def test_default_is_split_half():
+    assert _decoder("nerf3").math == "f16x3"
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+def test_both_modes_match_reference_points_and_grids(tag, golden_dir):
+    g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
+    hip = _decoder(tag)
+    pts = torch.from_numpy(g["rand_pts"]).cuda()
+    out = {}
+    for math in ("f32", "f16x3"):
+        hip.set_math(math)
+        assert hip.math == math
+        h, o = hip.decode_points(pts)
+        assert np.abs(h.cpu().numpy() - g["rand_hand"]).max() <= TOL and np.abs(o.cpu().numpy() - g["rand_obj"]).max() <= TOL
+        for N in (32, 64):
+            vh, vo, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+            sel = g["probe_sel_%d" % N]
+            assert np.abs(vh.cpu().numpy().reshape(-1)[sel] - g["p1_hand_%d" % N]).max() <= TOL
+            assert np.abs(vo.cpu().numpy().reshape(-1)[sel] - g["p1_obj_%d" % N]).max() <= TOL
+            b = bbox.cpu().numpy()
+            assert np.array_equal(np.stack([b[0:6], b[8:14]]), g["bbox_%d" % N])
+            out[(math, N)] = (vh, vo)
+        out[math] = (h, o)
+    # the two arithmetics agree far inside the bar (both are fp32-class)
+    assert (out["f32"][0] - out["f16x3"][0]).abs().max().item() <= 2e-6
+    assert (out["f32"][1] - out["f16x3"][1]).abs().max().item() <= 2e-6
+    assert (out[("f32", 64)][0] - out[("f16x3", 64)][0]).abs().max().item() <= 2e-6
+
+
+def test_split_half_layer_scales_vs_oracle():
+    """The same network re-parametrised so that its layers have very different weight magnitudes (layer 1 scaled by g,
+    its consumers' columns by 1/g: ReLU is positively homogeneous, the function is unchanged) - the per-layer power-of-two
+    scales of the split-half image then differ by orders of magnitude.  Ragged point counts, against the CPU oracle."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from oracle import sdf_oracle as orc
+    specs = syn.specs_for("nerf3")
+    base = syn.full_state_dict("nerf3")
+    lat = syn.latent_code(2)
+    for gain in (1.0, 1.0 / 64.0, 48.0):
+        sd = {}
+        for head in "ho":
+            for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
+                sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
+            n1 = sd["lin%s1.weight" % head].shape[0]
+            sd["lin%s1.weight" % head] *= np.float32(gain)
+            sd["lin%s1.bias" % head] *= np.float32(gain)
+            sd["lin%s2.weight" % head][:, :n1] /= np.float32(gain)
+        hip = HipSdfDecoder(sd, 256, 3, "nerf")
+        assert hip.math == "f16x3"
+        hip.set_sample(torch.from_numpy(lat).cuda())
+        for M in (1, 33, 5000):
+            pts = syn.uniform((M, 3), 900 + M, -1.0, 1.0).astype(np.float32)
+            h, o = hip.decode_points(torch.from_numpy(pts).cuda())
+            wh, wo = orc.decode_points(sd, lat, pts, specs)
+            assert np.abs(h.cpu().numpy() - wh.numpy()).max() <= TOL, (gain, M)
+            assert np.abs(o.cpu().numpy() - wo.numpy()).max() <= TOL, (gain, M)
+        hip.close()
+
+
+def test_fp16_overflow_is_detected_and_falls_back(tmp_path):
+    """Activations beyond the fp16 range (|x| >= 8188) cannot be carried by the split-half planes: the kernel counts the
+    resulting out-of-range outputs in bbox words 7 / 15 and the two-pass drivers repeat the pass on the fp32 kernel."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from oracle import sdf_oracle as orc
+    specs = syn.specs_for("nerf3")
+    base = syn.full_state_dict("nerf3")
+    sd = {}
+    for head in "ho":
+        for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
+            sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
+        # blow layer 0's outputs up by 4096 and undo it in layer 1: same function, activations of order 1e4
+        sd["lin%s0.weight" % head] *= np.float32(4096.0)
+        sd["lin%s0.bias" % head] *= np.float32(4096.0)
+        sd["lin%s1.weight" % head] /= np.float32(4096.0)
+    hip = HipSdfDecoder(sd, 256, 3, "nerf")
+    lat = torch.from_numpy(syn.latent_code(0)).cuda()
+    hip.set_sample(lat)
+    _, _, bbox = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
+    b = bbox.cpu().numpy()
+    assert b[7] > 0 and b[15] > 0 and hip.math == "f16x3"
+    r = decode_two_pass(True, True, hip, lat, None, None, specs, 32)
+    assert hip.math == "f32" and r["bbox"][7] == 0 and r["bbox"][15] == 0
+    g = np.load(str(__import__("pathlib").Path(__file__).parent / "golden" / "ref_decoder_nerf3.npz"))
+    assert np.array_equal(np.stack([r["bbox"][0:6], r["bbox"][8:14]]), g["bbox_32"])
+    hip.close()
+
+
+def test_nerf_encoded_decoder_stays_on_fp32(native_lib):
+    hip = _decoder("nerf9")
+    assert hip.math == "f32"                      # the default falls back: split-half covers affine point features only
+    assert native_lib.asdf_decoder_set_math(hip._h, 1) == -1
+    assert native_lib.asdf_decoder_set_math(hip._h, 7) == -1
+    assert native_lib.asdf_decoder_get_math(hip._h) == 0
+    with pytest.raises(Exception):
+        hip.set_math("f16x3")
