@@ -10,13 +10,20 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alignsdf_
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_main_decoder_kernel_has_no_scratch(tmp_path):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", "decoder.hip",
-                          "-o", str(tmp_path / "d.o"), "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True,
-                         text=True, timeout=900)
+@pytest.fixture(scope="module")
+def compiled(tmp_path_factory):
+    """One device-only compile of decoder.hip: (resource-usage remarks, ISA text)."""
+    asm = tmp_path_factory.mktemp("isa") / "decoder.s"
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                          "--cuda-device-only", "decoder.hip", "-o", str(asm), "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC,
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    text = out.stderr
+    return out.stderr, asm.read_text()
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_main_decoder_kernel_has_no_scratch(compiled):
+    text = compiled[0]
     blocks = re.split(r"remark: Function Name: ", text)
     stats = {}
     for b in blocks[1:]:
@@ -41,14 +48,10 @@ def test_main_decoder_kernel_has_no_scratch(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_no_scratch_traffic_inside_the_mfma_stream(tmp_path):
+def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
     """In the ISA of the shipped decoder kernels every scratch load / store must come before the first MFMA of the kernel
     body (kernel / head-loop prologue) - a spill between MFMAs costs whole percents and no parity test sees it."""
-    asm = tmp_path / "decoder.s"
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                          "--cuda-device-only", "decoder.hip", "-o", str(asm)], cwd=CSRC, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    text = asm.read_text()
+    text = compiled[1]
     for mangled in ("_ZN4asdf14sdf_mlp_kernelENS_12DecodeParamsE", "_ZN4asdf18sdf_mlp_f16_kernelENS_12DecodeParamsE"):
         body = text[text.index(mangled + ":"):]
         body = body[:body.index("s_endpgm")].splitlines()
