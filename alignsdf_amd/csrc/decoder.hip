@@ -337,7 +337,9 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
     ASDF_HIP(hipGetLastError());
     return ASDF_OK;
   }
-  if (d->math == ASDF_MATH_F16X3 && d->stream16) {
+  // split-half arithmetic: grid sweeps only - they carry the fp16 range report in the bbox record (word 7 / 15) that the
+  // caller reads back anyway; explicit point lists (no record to report through) stay on the fp32 chain
+  if (d->math == ASDF_MATH_F16X3 && d->stream16 && p.mode != kPointList) {
     p.stream = d->stream16;
     p.cst = d->cst16;
     if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);

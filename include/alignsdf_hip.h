@@ -113,13 +113,17 @@ int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int3
 int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, float* sdf_hand_dev,
                        float* sdf_obj_dev, void* stream);
 
-/* ---- Arithmetic of the three hidden GEMMs of the decoder sweeps (asdf_decode_grid / asdf_decode_points):
+/* ---- Arithmetic of the three hidden GEMMs of the grid sweeps (asdf_decode_grid; explicit point lists always run
+ * ASDF_MATH_F32 - they have no bbox record to carry the range report below):
  *   ASDF_MATH_F32    v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain (the default after create);
  *   ASDF_MATH_F16X3  split-half: every operand carried as two fp16 planes (22 significand bits) of a power-of-two
  *                    scaled value, a product sum = three v_mfma_f32_32x32x16_f16 into one fp32 accumulator.  fp32-class
  *                    results (same error against fp64 as the fp32 chain on the test decoders, well inside the 1e-5 bar)
  *                    at 3/16 of the matrix-pipe time.  Available for xyz / pose-aligned (affine) point features;
- *                    ASDF_EINVAL for NeRF-encoded decoders.  The label pass (asdf_decode_points_cls) always runs fp32.
+ *                    ASDF_EINVAL for NeRF-encoded decoders.  Operands must stay inside the fp16 range (hidden
+ *                    activations |x| < 8188): violations are counted in word 7 of the bbox record of asdf_decode_grid,
+ *                    and a caller that sees a non-zero count switches to ASDF_MATH_F32 and repeats the sweep (pass a
+ *                    bbox buffer to every sweep whose range is not known to be safe).
  * May be switched at any time between launches. */
 #define ASDF_MATH_F32 0
 #define ASDF_MATH_F16X3 1

@@ -105,16 +105,25 @@ def test_grid_modes_and_odd_sizes():
 
 
 def test_linearity_of_lattice_full_size():
-    """Size-independent property at N=128: the grid sweep equals the point-list sweep on the same coordinates."""
+    """Size-independent property at N=128: the grid sweep equals the point-list sweep on the same coordinates - bit for bit
+    on the fp32 chain (the same kernel either way), within 2e-6 for the split-half grid sweep (point lists stay fp32)."""
     from oracle import sdf_oracle as orc
     dec, specs, sd, lat, *_ = _setup("nerf3")
     N = 128
-    h, o, bbox = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
     c = orc.grid_coords(N, 2.0 / (N - 1), [-1, -1, -1])
     sel = torch.from_numpy(np.sort((syn.splitmix64(np.arange(50000, dtype=np.uint64), 5) % np.uint64(N ** 3)).astype(np.int64)))
     hp, op = dec.decode_points(c[sel])
-    assert torch.equal(h.reshape(-1)[sel.cuda()], hp) and torch.equal(o.reshape(-1)[sel.cuda()], op)
-    assert int(bbox[6]) == int((h < 0).sum()) and int(bbox[14]) == int((o < 0).sum())
+    default = dec.math
+    for math in ("f32", "f16x3"):
+        dec.set_math(math)
+        h, o, bbox = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+        if math == "f32":
+            assert torch.equal(h.reshape(-1)[sel.cuda()], hp) and torch.equal(o.reshape(-1)[sel.cuda()], op)
+        else:
+            assert (h.reshape(-1)[sel.cuda()] - hp).abs().max().item() <= 2e-6 and (o.reshape(-1)[sel.cuda()] - op).abs().max().item() <= 2e-6
+        assert int(bbox[6]) == int((h < 0).sum()) and int(bbox[14]) == int((o < 0).sum())
+        assert int(bbox[7]) == 0 and int(bbox[15]) == 0
+    dec.set_math(default)
 
 
 @pytest.mark.parametrize("tag", ["nerf3", "both9", "nerf9"])

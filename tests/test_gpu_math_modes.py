@@ -1,11 +1,10 @@
 """Both arithmetic modes of the decoder sweeps against the reference goldens: the fp32 MFMA chain ("f32") and the
 split-half fp16 MFMA kernel ("f16x3", the default).  Everything else in the GPU suite runs on the default."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
 
+from alignsdf_amd import _native
 from alignsdf_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +40,7 @@ def test_both_modes_match_reference_points_and_grids(tag, golden_dir):
     for math in ("f32", "f16x3"):
         hip.set_math(math)
         assert hip.math == math
-        h, o = hip.decode_points(pts)
+        h, o = hip.decode_points(pts)             # point lists run the fp32 chain in either mode
         assert np.abs(h.cpu().numpy() - g["rand_hand"]).max() <= TOL and np.abs(o.cpu().numpy() - g["rand_obj"]).max() <= TOL
         for N in (32, 64):
             vh, vo, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
@@ -52,10 +51,12 @@ def test_both_modes_match_reference_points_and_grids(tag, golden_dir):
             assert np.array_equal(np.stack([b[0:6], b[8:14]]), g["bbox_%d" % N])
             out[(math, N)] = (vh, vo)
         out[math] = (h, o)
-    # the two arithmetics agree far inside the bar (both are fp32-class)
-    assert (out["f32"][0] - out["f16x3"][0]).abs().max().item() <= 2e-6
-    assert (out["f32"][1] - out["f16x3"][1]).abs().max().item() <= 2e-6
-    assert (out[("f32", 64)][0] - out[("f16x3", 64)][0]).abs().max().item() <= 2e-6
+    # the two arithmetics agree far inside the bar (both are fp32-class) - and they are two different kernels
+    assert torch.equal(out["f32"][0], out["f16x3"][0])
+    for N in (32, 64):
+        for k in (0, 1):
+            d = (out[("f32", N)][k] - out[("f16x3", N)][k]).abs().max().item()
+            assert 0.0 < d <= 2e-6, (N, k, d)
 
 
 def test_split_half_layer_scales_vs_oracle():
@@ -79,12 +80,14 @@ def test_split_half_layer_scales_vs_oracle():
         hip = HipSdfDecoder(sd, 256, 3, "nerf")
         assert hip.math == "f16x3"
         hip.set_sample(torch.from_numpy(lat).cuda())
-        for M in (1, 33, 5000):
-            pts = syn.uniform((M, 3), 900 + M, -1.0, 1.0).astype(np.float32)
-            h, o = hip.decode_points(torch.from_numpy(pts).cuda())
+        for N, origin, vs in ((8, [-1.0, -1.0, -1.0], 2.0 / 7), (21, [-0.6, -0.4, -0.35], 0.031)):
+            vh, vo, bbox = hip.decode_grid(N, origin, vs, _native.GRID_INTEGER)
+            assert bbox.cpu().numpy()[7] == 0 and bbox.cpu().numpy()[15] == 0
+            idx = np.stack(np.meshgrid(np.arange(N), np.arange(N), np.arange(N), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+            pts = idx * np.float32(vs) + np.array(origin, np.float32)
             wh, wo = orc.decode_points(sd, lat, pts, specs)
-            assert np.abs(h.cpu().numpy() - wh.numpy()).max() <= TOL, (gain, M)
-            assert np.abs(o.cpu().numpy() - wo.numpy()).max() <= TOL, (gain, M)
+            assert np.abs(vh.cpu().numpy().reshape(-1) - wh.numpy()).max() <= TOL, (gain, N)
+            assert np.abs(vo.cpu().numpy().reshape(-1) - wo.numpy()).max() <= TOL, (gain, N)
         hip.close()
 
 
