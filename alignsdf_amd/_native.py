@@ -26,7 +26,7 @@ EXPORTS = (
     "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_icp_workspace_bytes", "asdf_icp_ts",
     "asdf_debug_pack_host", "asdf_decoder_set_classifier", "asdf_decode_points_cls",
     "asdf_icp_ts_enqueue", "asdf_icp_ts_result", "asdf_chamfer",
-    "asdf_decoder_set_math", "asdf_decoder_get_math",
+    "asdf_decoder_set_math", "asdf_decoder_get_math", "asdf_debug_pack_host_f16",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -96,6 +96,7 @@ def lib():
     L.asdf_decoder_set_math.argtypes = [vp, i32]
     L.asdf_decoder_get_math.argtypes = [vp]
     L.asdf_chamfer.argtypes = [vp, i32, vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), vp]
+    L.asdf_debug_pack_host_f16.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams), vp, vp, vp]
     L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
     _lib = L
     return L

@@ -271,6 +271,19 @@ int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params
   return ASDF_OK;
 }
 
+int asdf_debug_pack_host_f16(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16, float* cst16,
+                             float* s2) {
+  if (!spec || !heads || !spec_supported(spec)) return ASDF_EINVAL;
+  HostPack hp;
+  if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
+  if (hp.kp != 2) return ASDF_EINVAL;
+  if (!pack_decoder_f16(*spec, heads, hp)) return ASDF_ENOMEM;
+  if (stream16) std::memcpy(stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t));
+  if (cst16) std::memcpy(cst16, hp.cst16.data(), hp.cst16.size() * sizeof(float));
+  if (s2) for (int h = 0; h < kHeads; ++h) s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
+  return ASDF_OK;
+}
+
 int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const float* embed_host, void* stream) {
   if (!d || !latent_dev) return ASDF_EINVAL;
   if (embed_host && d->spec.feature_mode != ASDF_FEATURES_AFFINE) return ASDF_EINVAL;

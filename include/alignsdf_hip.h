@@ -191,6 +191,11 @@ int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t n
  * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed);
+/* The split-half image of the same decoder (ASDF_MATH_F16X3; affine point features only): stream16 2*128*8192 fp16 bit
+ * patterns (stage = [kblock 8][plane hi/lo][lane 64][8]), cst16 = the constants block with the scaled entries,
+ * s2[2] = the layer-2 accumulator scale per head that K0 applies to the per-sample constants. */
+int asdf_debug_pack_host_f16(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16,
+                             float* cst16, float* s2);
 
 #ifdef __cplusplus
 }

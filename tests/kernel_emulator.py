@@ -66,6 +66,12 @@ def pack_host(sd, point_feat_size, encode_style):
     out["combined"] = combined
     out["kp"] = kp
     out["nerf"] = nerf
+    if not nerf:      # split-half image (sdf_mlp_f16_kernel.h)
+        out["stream16"] = np.zeros(256 * STAGE * 2, np.uint16)
+        out["cst16"] = np.zeros(2 * offsets(kp)["FLOATS"], np.float32)
+        out["s2"] = np.zeros(2, np.float32)
+        _native.check(L.asdf_debug_pack_host_f16(ctypes.byref(spec), heads, ptr(out["stream16"]), ptr(out["cst16"]), ptr(out["s2"])),
+                      "asdf_debug_pack_host_f16")
     return out
 
 
@@ -180,4 +186,102 @@ def run_wave(pk, cst, xyz32):
                     partb = (np.maximum(h3[t][r], 0) * w[r] + partb).astype(np.float32)
             totb = partb + partb[LANE ^ 32]
             outs.append(np.tanh(totb + c[OFF["B4"] + 1])[:32].astype(np.float32))
+    return outs[0], outs[1]
+
+
+# ---------------------------------------------------------------- split-half kernel (sdf_mlp_f16_kernel.h)
+ACT_SCALE = np.float32(8.0)
+
+
+def fold16(pk, latent, embed=None):
+    """K0 into the split-half constants image: the fp32 fold with the layer-2 constants (c2, A2) times s2[head]."""
+    OFF = offsets(pk["kp"])
+    plain = fold(pk, latent, embed)
+    cst = pk["cst16"].copy().reshape(2, OFF["FLOATS"])
+    for head in range(len(pk["pf"])):
+        cst[head, OFF["A0"]:OFF["A2"]] = plain[head, OFF["A0"]:OFF["A2"]]
+        cst[head, OFF["C0"]:OFF["C0"] + 512] = plain[head, OFF["C0"]:OFF["C0"] + 512]
+        cst[head, OFF["A2"]:OFF["C0"]] = plain[head, OFF["A2"]:OFF["C0"]] * pk["s2"][head]
+        cst[head, OFF["C2"]:OFF["C2"] + 512] = plain[head, OFF["C2"]:OFF["C2"] + 512] * pk["s2"][head]
+    return cst
+
+
+def split_tile(acc, mul):
+    """split_tile(): relu(acc) * mul -> (hi, lo) fp16 planes of the two K-blocks of a tile, each [8][64]."""
+    t = (np.maximum(acc, 0) * np.float32(mul)).astype(np.float32)
+    hi = t.astype(np.float16)
+    lo = (t - hi.astype(np.float32)).astype(np.float16)
+    return (hi[:8], lo[:8]), (hi[8:], lo[8:])
+
+
+def mfma16(a, b, acc):
+    """v_mfma_f32_32x32x16_f16: a, b [64][8] fp16 (lane, element): A[i = lane & 31][k = 8 (lane >> 5) + e],
+    B[k = 8 (lane >> 5) + e][j = lane & 31]; products exact in fp32, fp32 accumulation."""
+    A = np.zeros((32, 16), np.float32)
+    B = np.zeros((16, 32), np.float32)
+    for h in range(2):
+        A[:, 8 * h:8 * h + 8] = a[32 * h:32 * h + 32].astype(np.float32)
+        B[8 * h:8 * h + 8, :] = b[32 * h:32 * h + 32].astype(np.float32).T
+    D = (A @ B).astype(np.float32)
+    rows = ROW[:, HALF]
+    cols = (LANE & 31)[None, :].repeat(16, 0)
+    return (acc + D[rows, cols]).astype(np.float32)
+
+
+def run_wave16(pk, cst, xyz32):
+    """K1h emulation for one wave: xyz32 [32,3] -> per-output SDF values (hand, obj)."""
+    OFF = offsets(2)
+    x = np.asarray(xyz32, np.float32)
+    pt = LANE & 31
+    bp = [np.where(HALF == 1, x[pt, 1], x[pt, 0]).astype(np.float32), np.where(HALF == 1, 0.0, x[pt, 2]).astype(np.float32)]
+    stream = pk["stream16"].view(np.float16).reshape(256, 8, 2, 64, 8)       # [stage][kblock][plane][lane][e]
+    outs = []
+    for head in range(len(pk["pf"])):
+        c = cst[head]
+        sbase = head * 128
+        mul1, mul2 = c[OFF["B4"] + 2], c[OFF["B4"] + 3]
+
+        def planes(accs, mul):
+            """list of per-K-block (hi, lo) operand planes [64][8] from a layer's output tiles"""
+            out = []
+            for acc in accs:
+                for hi, lo in split_tile(acc, mul):
+                    out.append((hi.T.copy(), lo.T.copy()))          # [e][lane] -> [lane][e]
+            return out
+
+        def layer(ntiles, stages_per_tile, s0, xin, bias_off, extra=None):
+            res = []
+            for t in range(ntiles):
+                acc = bias16(c, bias_off, t)
+                if extra is not None:
+                    for s in range(2):
+                        acc = mfma(c[extra + (t * 2 + s) * 64: extra + (t * 2 + s) * 64 + 64], bp[s], acc)
+                for q in range(stages_per_tile):
+                    st = stream[sbase + s0 + t * stages_per_tile + q]
+                    for kb in range(8):
+                        xh, xl = xin[q * 8 + kb]
+                        acc = mfma16(st[kb, 0], xl, acc)
+                        acc = mfma16(st[kb, 1], xh, acc)
+                        acc = mfma16(st[kb, 0], xh, acc)
+                res.append(acc)
+            return res
+
+        l0 = []
+        for t in range(16):
+            acc = bias16(c, OFF["C0"], t)
+            for s in range(2):
+                acc = mfma(c[OFF["A0"] + (t * 2 + s) * 64: OFF["A0"] + (t * 2 + s) * 64 + 64], bp[s], acc)
+            l0.append(acc)
+        h0 = planes(l0, ACT_SCALE)
+        h1 = planes(layer(8, 4, 0, h0, OFF["B1"]), mul1)
+        h2 = planes(layer(16, 2, 32, h1, OFF["C2"], OFF["A2"]), mul2)
+        h3 = layer(16, 4, 64, h2, OFF["B3"])
+        for woff, boff in ((OFF["W4"], OFF["B4"]),) + (((OFF["W4B"], OFF["B4"] + 1),) if pk["combined"] else ()):
+            part = np.zeros(64, np.float32)
+            for t in range(16):
+                w = bias16(c, woff, t)
+                for r in range(16):
+                    part = (np.maximum(h3[t][r], 0) * w[r] + part).astype(np.float32)
+            tot = part + part[LANE ^ 32]
+            outs.append(np.tanh(tot + c[boff])[:32].astype(np.float32))
     return outs[0], outs[1]

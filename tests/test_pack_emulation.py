@@ -28,6 +28,32 @@ def test_packed_stream_emulation_matches_oracle(tag, native_lib):
     assert np.abs(h - rh.numpy()).max() <= 2e-6 and np.abs(o - ro.numpy()).max() <= 2e-6
 
 
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+def test_split_half_image_emulation_matches_oracle(tag, native_lib):
+    """The split-half image (two fp16 planes per weight, per-layer power-of-two scales, pre-scaled constants) through an
+    emulation of sdf_mlp_f16_kernel.h's data flow: fp32-class agreement with the oracle, and the scales are exact."""
+    specs, sd = syn.specs_for(tag), syn.full_state_dict(tag)
+    pk = emu.pack_host(sd, specs["PointFeatSize"], specs["EncodeStyle"])
+    lat = syn.latent_code(0)
+    mano = obj = emb = None
+    if tag == "both9":
+        m, o = syn.pose_inputs(0)
+        mano = {k: torch.from_numpy(v) for k, v in m.items()}
+        obj = {k: torch.from_numpy(v) for k, v in o.items()}
+        emb = kinematic_affine(9, "both", specs["SdfScaleFactor"], mano, obj)
+    for s2 in pk["s2"][:len(pk["pf"])]:
+        assert s2 > 0 and np.log2(s2) == np.round(np.log2(s2))                  # powers of two
+    planes = pk["stream16"].view(np.float16).astype(np.float32).reshape(256, 8, 2, 64, 8)
+    used = planes[:128 * len(pk["pf"])]
+    assert 512.0 <= np.abs(used[:, :, 0]).max() < 1024.0                          # hi planes: max |w| S_w in [512, 1024)
+    assert np.abs(used[:, :, 1]).max() <= 0.25 + 1e-6                            # lo planes: at most half an ulp of the hi plane
+    cst = emu.fold16(pk, lat, emb)
+    pts = syn.uniform((32, 3), 5, -1, 1).astype(np.float32)
+    h, o = emu.run_wave16(pk, cst, pts)
+    rh, ro = orc.decode_points(sd, lat, pts, specs, mano, obj)
+    assert np.abs(h - rh.numpy()).max() <= 2e-6 and np.abs(o - ro.numpy()).max() <= 2e-6
+
+
 def test_kinematic_affine_matches_oracle_embedding():
     specs = syn.specs_for("both9")
     m, o = syn.pose_inputs(3)
