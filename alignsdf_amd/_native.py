@@ -64,6 +64,9 @@ def lib():
         except Exception as e:      # noqa: BLE001
             raise NativeError(-100, "libalignsdf_hip.so not found at %s and building it failed (%s) - run "
                                     "`python -m alignsdf_amd.build_native`; there is no CPU fallback" % (LIB_PATH, e))
+    # PyTorch ships its own HIP runtime (same soname as /opt/rocm's): it must be the one already in the process when this
+    # library is loaded, or two runtimes end up side by side and the one behind this library sees no device
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.asdf_version.restype = ctypes.c_int
     if L.asdf_version() != ABI_VERSION:
