@@ -148,7 +148,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 107; }
+int asdf_version(void) { return 108; }
 
 const char* asdf_strerror(int code) {
   switch (code) {

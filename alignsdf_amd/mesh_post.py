@@ -11,6 +11,8 @@ dependency that is not installable in this environment, so this module re-states
 PARITY UNPINNED: there is no trimesh here to check against (trimesh 3.x additionally tries `fill_holes` on
 open components before dropping them; that repair step is not reproduced).
 """
+import ctypes
+
 import numpy as np
 from scipy.sparse import coo_matrix
 from scipy.sparse.csgraph import connected_components
@@ -65,3 +67,30 @@ def keep_largest_component(verts, faces):
     remap = np.full(len(verts), -1, dtype=np.int64)
     remap[used] = np.arange(len(used))
     return np.asarray(verts)[used], remap[sub].astype(np.asarray(faces).dtype)
+
+
+def keep_largest_component_device(verts_d, faces_d, voxel_size, origin):
+    """The same filter on the device (K8, csrc/mesh_cc.hip), enqueued on the current stream without synchronising.
+    verts_d [V,3] fp32 lattice-unit marching-cubes vertices, faces_d [F,3] int32; the component areas are measured on
+    origin + voxel_size * v like the reference's.  Returns device tensors (out_verts [V,3], out_faces [F,3], counts int32[4]):
+    the first counts[0] rows of out_verts / counts[1] rows of out_faces are the kept mesh; counts[2] = number of
+    qualifying components, counts[3] = first face of the kept one."""
+    import torch
+    from . import _native
+    L = _native.lib()
+    V, F = int(verts_d.shape[0]), int(faces_d.shape[0])
+    dev = verts_d.device
+    nbytes = ctypes.c_size_t()
+    _native.check(L.asdf_mesh_cc_workspace_bytes(V, F, ctypes.byref(nbytes)), "asdf_mesh_cc_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out_v = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    out_f = torch.empty((F, 3), dtype=torch.int32, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin])
+    vs = float(voxel_size.item()) if hasattr(voxel_size, "item") else float(np.float32(voxel_size))
+    with torch.cuda.device(dev):
+        _native.check(L.asdf_mesh_largest_component(
+            verts_d.contiguous().data_ptr(), V, faces_d.contiguous().data_ptr(), F, ctypes.c_float(vs), org, ws.data_ptr(), ws.numel(),
+            out_v.data_ptr(), out_f.data_ptr(), counts.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "asdf_mesh_largest_component")
+    return out_v, out_f, counts

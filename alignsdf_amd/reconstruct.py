@@ -60,9 +60,11 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     right behind pass 2 of sample k, i.e. before sample k's marching cubes and before the consumer's host work
     (D2H copy, component filter, PLY export), so the GPU never waits for the host between samples.
 
-    host_copy=True additionally copies every mesh to pinned host memory on a side stream, ordered right behind its
-    marching-cubes kernels (`host_verts_*`, `host_faces_*` CPU tensors, valid after `copy_done_*`.synchronize()): a
-    plain `.cpu()` on the compute stream would wait behind the NEXT sample's queued passes.
+    host_copy=True additionally runs the largest-component filter (K8) behind each marching cubes and copies its result
+    to pinned host memory on a side stream (`host_kept_verts_*`, `host_kept_faces_*` at input capacity, `host_kept_counts_*`
+    = kept vertices / faces, valid after `copy_done_*`.synchronize(); with label_out also the whole surface as
+    `host_verts_hand` / `host_faces_hand`): a plain `.cpu()` on the compute stream would wait behind the NEXT sample's
+    queued passes.
 
     label_out=True runs the label pass (utils/mesh.py:137-157) over the hand mesh vertices right behind the hand's
     marching cubes (`labels_hand`, int64 device tensor; `host_labels_hand` with host_copy).  The decoder holds one
@@ -131,9 +133,16 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     rebound = True
                     r["labels_hand"] = hip.classify_points(pts, want_sdf=False)[3]
                 if host_copy:
-                    to_host(r, "verts_" + part, v)
-                    done = to_host(r, "faces_" + part, f)
+                    # K8 right behind marching cubes: only the largest component (what the file holds) crosses to the
+                    # host, plus the whole surface when the label pass needs every vertex
+                    from .mesh_post import keep_largest_component_device
+                    kv, kf, counts = keep_largest_component_device(v, f, r["voxel_size"], r["origin"])
+                    to_host(r, "kept_verts_" + part, kv)
+                    to_host(r, "kept_faces_" + part, kf)
+                    done = to_host(r, "kept_counts_" + part, counts)
                     if "labels_" + part in r:
+                        to_host(r, "verts_" + part, v)
+                        to_host(r, "faces_" + part, f)
                         done = to_host(r, "labels_" + part, r["labels_" + part])
                     r["copy_done_" + part] = done           # the side stream is in order: the last event covers all
         return rebound
@@ -231,14 +240,18 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         def hand_path(name):
             return os.path.join(mesh_dir, "%s_hand" % name)
 
+        def kept(r, part):
+            c = r["host_kept_counts_" + part].numpy()
+            return r["host_kept_verts_" + part][:c[0]], r["host_kept_faces_" + part][:c[1]]
+
         def begin_hand(key, r):
-            """Eval mode: component filter, surface sampling and the ICP launch of the hand mesh, slotted between two
-            decoder passes (see pipelined_two_pass); the consumer below only waits for the result."""
+            """Eval mode: surface sampling and the ICP launch of the hand mesh, slotted between two decoder passes (see
+            pipelined_two_pass); the consumer below only waits for the result."""
             if "verts_hand" in r:
                 r["copy_done_hand"].synchronize()
+                kv, kf = kept(r, "hand")
                 r["pending_hand"] = mesh_utils.begin_export_surface(
-                    r["host_verts_hand"], r["host_faces_hand"], r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None,
-                    True, task, data_root=data_root)
+                    kv, kf, r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None, True, task, False, data_root)
 
         for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
                                                     label_out=label_out and hand_on, midpoint=begin_hand if eval_mode else None):
@@ -252,19 +265,18 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                     r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
                     base = os.path.join(mesh_dir, "%s_%s" % (name, part))
                     if part == "hand" and "pending_hand" in r:
-                        verts, faces, trans, icp_scale = mesh_utils.end_export_surface(r.pop("pending_hand"))
+                        _, _, trans, icp_scale = mesh_utils.end_export_surface(r.pop("pending_hand"))
                     else:
-                        verts, faces, trans, icp_scale = mesh_utils.export_surface(
-                            r["host_verts_" + part], r["host_faces_" + part], r["origin"], r["voxel_size"], base + ".ply",
-                            None if part == "hand" else offset, None if part == "hand" else sc, False, task,
-                            data_root=data_root)
+                        kv, kf = kept(r, part)
+                        _, _, trans, icp_scale = mesh_utils.export_surface(
+                            kv, kf, r["origin"], r["voxel_size"], base + ".ply", None if part == "hand" else offset,
+                            None if part == "hand" else sc, False, task, False, data_root)
                     if part == "hand":
                         offset, sc = trans, icp_scale
                         rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])
                         if "host_labels_hand" in r:
-                            vertices = np.array(verts, copy=True)
-                            for a in range(3):
-                                vertices[:, a] = r["origin"][a] + vertices[:, a]
+                            verts, faces, vertices = mesh_utils.place_vertices(r["host_verts_hand"], r["host_faces_hand"], r["origin"],
+                                                                               r["voxel_size"])
                             labels = r["host_labels_hand"].float()
                             mesh_utils.write_label_outputs(vertices, faces, labels, base, offset, sc, viz)
                             rec["labels_hand"] = np.bincount(labels.long().numpy(), minlength=1).tolist()

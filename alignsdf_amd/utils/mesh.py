@@ -14,7 +14,7 @@ import torch
 
 from .. import _native
 from ..marching_cubes import marching_cubes_device
-from ..mesh_post import keep_largest_component
+from ..mesh_post import keep_largest_component, keep_largest_component_device
 from ..ply import write_ply
 from .utils import hip_decoder_for, sample_embedding
 
@@ -137,10 +137,25 @@ def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obm
     return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root))
 
 
+def filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size):
+    """K8 on a device surface: (kept lattice verts, kept faces) as device tensors.  Synchronises (it reads the counts)."""
+    kv, kf, counts = keep_largest_component_device(verts_d, faces_d, voxel_size, voxel_grid_origin)
+    c = counts.cpu().numpy()
+    return kv[:c[0]], kf[:c[1]]
+
+
 def begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None,
-                         eval_mode=False, task="obman", largest_component=True, data_root="data"):
-    """place_vertices + begin_mesh: everything of the host tail up to (and including) enqueuing the eval-mode ICP."""
+                         eval_mode=False, task="obman", largest_component=True, data_root="data", kept=None):
+    """place_vertices + begin_mesh: everything of the host tail up to (and including) enqueuing the eval-mode ICP.
+    `kept` = (verts, faces) of the largest component in lattice units when the caller has already run the device filter
+    (the sample pipeline does, right behind marching cubes); a device surface is filtered here (K8); host arrays without
+    `kept` go through the host restatement in alignsdf_amd.mesh_post."""
+    if kept is None and largest_component and isinstance(verts_d, torch.Tensor) and verts_d.is_cuda:
+        kept = filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size)
     verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
+    if kept is not None:
+        _, kept_faces, kept_points = place_vertices(kept[0], kept[1], voxel_grid_origin, voxel_size, offset, scale)
+        return verts, faces, begin_mesh(kept_points, kept_faces, ply_filename_out, eval_mode, task, False, data_root)
     return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
 
 
@@ -152,11 +167,11 @@ def end_export_surface(pending):
 
 
 def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
-                   task="obman", largest_component=True, data_root="data"):
+                   task="obman", largest_component=True, data_root="data", kept=None):
     """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397).
     Returns (verts, faces, trans, scale)."""
     return end_export_surface(begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset,
-                                                   scale, eval_mode, task, largest_component, data_root))
+                                                   scale, eval_mode, task, largest_component, data_root, kept))
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
@@ -167,14 +182,17 @@ def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_s
     surface splits into several (utils/mesh.py:371-381, alignsdf_amd.mesh_post); in eval mode it is first aligned to
     the ground-truth mesh by the translate+scale ICP (utils/mesh.py:385-395, alignsdf_amd.icp) and `trans`, `scale`
     are the ICP's; otherwise they are zeros / one."""
+    vol = pytorch_3d_sdf_tensor if isinstance(pytorch_3d_sdf_tensor, torch.Tensor) else torch.as_tensor(np.asarray(pytorch_3d_sdf_tensor))
+    if not vol.is_cuda:
+        vol = vol.cuda()
     try:
-        verts, faces, mesh_points = extract_surface(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, offset, scale)
+        verts_d, faces_d = marching_cubes_device(vol, 0.0)
     except (ValueError, RuntimeError) as e:
         logging.warning("Cannot reconstruct mesh from '{}'".format(ply_filename_out))
         print(e)
         return None, None, np.array([0, 0, 0]), np.array([1])
-    trans, sc = finish_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
-    return verts, faces, trans, sc
+    return export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset, scale, eval_mode, task,
+                          largest_component, data_root)
 
 
 # colour per part label of the `--viz` output (the table of utils/mesh.py:305-310)

@@ -156,6 +156,19 @@ int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doub
 int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                  size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
 
+/* ---- Largest-component filter of utils/mesh.py:371-381 (trimesh.graph.split(only_watertight=True) + largest area) on
+ * a marching-cubes surface: verts_dev [V][3] fp32 lattice-unit vertices, faces_dev [F][3] int32.  Faces are adjacent when
+ * they share an edge that belongs to exactly two faces; a component qualifies with >= 4 faces and no edge shared by a
+ * number of faces other than two; with fewer than two qualifying components the mesh comes back unchanged, otherwise the
+ * qualifying component of largest area - measured, like the reference, on origin + voxel_size * v - with its vertices
+ * compacted in ascending original order and its faces in original order.  Outputs (device): out_verts_dev [V][3],
+ * out_faces_dev [F][3] (capacity of the input), counts_dev int32[4] = kept vertices, kept faces, qualifying components,
+ * first face of the kept component.  No host synchronisation.  Workspace: asdf_mesh_cc_workspace_bytes(V, F). */
+int asdf_mesh_cc_workspace_bytes(int32_t num_verts, int32_t num_faces, size_t* bytes);
+int asdf_mesh_largest_component(const float* verts_dev, int32_t num_verts, const int32_t* faces_dev, int32_t num_faces,
+                                float voxel_size, const float origin[3], void* workspace_dev, size_t workspace_bytes,
+                                float* out_verts_dev, int32_t* out_faces_dev, int32_t* counts_dev, void* stream);
+
 /* ---- Translate + scale ICP of the reference's eval mode: ICP_T_S.run_icp_f (deep_sdf/metrics/icp_trans_scale.py:33-113),
  * called from utils/mesh.py:385-395.  src_dev [ns][3] are the ALREADY NORMALISED source samples (sample_mesh :25-31),
  * tgt_dev [nt][3] the target samples, both fp64 on the device.  Runs until the reference's stopping rules fire

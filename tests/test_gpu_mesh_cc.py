@@ -1,0 +1,84 @@
+"""K8 (device largest-component filter, csrc/mesh_cc.hip) against the host restatement of the reference semantics
+(alignsdf_amd/mesh_post.py): identical kept vertices and faces, element for element."""
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import mesh_post, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _volume(N, blobs, extra=None):
+    ax = np.linspace(-1, 1, N, dtype=np.float32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    vol = np.full((N, N, N), 10.0, np.float32)
+    for (cx, cy, cz, r) in blobs:
+        vol = np.minimum(vol, np.sqrt((X - cx) ** 2 + (Y - cy) ** 2 + (Z - cz) ** 2) - r)
+    if extra is not None:
+        vol = extra(vol, X, Y, Z)
+    return vol.astype(np.float32)
+
+
+def _check(vol, vs=0.013, origin=(-0.6, -0.35, -0.3)):
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.utils.mesh import place_vertices
+    v, f = marching_cubes_device(torch.from_numpy(vol).cuda(), 0.0)
+    ov, of, counts = mesh_post.keep_largest_component_device(v, f, torch.tensor(vs, dtype=torch.float32), list(origin))
+    c = counts.cpu().numpy()
+    got_v, got_f = ov[:c[0]].cpu().numpy(), of[:c[1]].cpu().numpy()
+    # host path: place the vertices like the exporter does, filter there, and compare raw lattice vertices by index
+    _, faces, mesh_points = place_vertices(v, f, list(origin), torch.tensor(vs, dtype=torch.float32))
+    comps = mesh_post.split_watertight(mesh_points, faces)
+    hv, hf = mesh_post.keep_largest_component(mesh_points, faces)
+    assert c[2] == len(comps)
+    assert got_f.shape == hf.shape and np.array_equal(got_f, hf)
+    # kept vertices: the placed versions of the device's lattice vertices are the host's kept vertices
+    placed = place_vertices(torch.from_numpy(got_v), torch.from_numpy(got_f), list(origin), torch.tensor(vs, dtype=torch.float32))[2]
+    assert placed.shape == hv.shape and np.array_equal(placed, hv)
+    return c, len(v), len(f)
+
+
+def test_two_closed_surfaces_keep_the_larger():
+    c, V, F = _check(_volume(64, [(-0.3, 0.0, 0.0, 0.35), (0.55, 0.1, 0.0, 0.15)]))
+    assert c[2] == 2 and c[0] < V and c[1] < F
+
+
+def test_order_independent_of_which_component_comes_first():
+    c, V, F = _check(_volume(64, [(-0.6, 0.0, 0.0, 0.12), (0.3, 0.1, 0.0, 0.4), (0.0, -0.7, 0.6, 0.1)]))
+    assert c[2] == 3 and c[3] > 0                       # the kept component does not start at face 0
+
+
+def test_single_component_and_open_surfaces_return_the_mesh_unchanged():
+    c, V, F = _check(_volume(48, [(0.0, 0.0, 0.0, 0.5)]))
+    assert c[2] == 1 and (c[0], c[1]) == (V, F)
+    # a sphere cut by the volume boundary is not watertight: no qualifying component at all
+    c, V, F = _check(_volume(48, [(0.9, 0.0, 0.0, 0.4)]))
+    assert c[2] == 0 and (c[0], c[1]) == (V, F)
+    # one closed + one open: a single qualifying component -> unchanged as well (the reference's `len(split) > 1`)
+    c, V, F = _check(_volume(48, [(0.9, 0.0, 0.0, 0.3), (-0.3, 0.0, 0.0, 0.3)]))
+    assert c[2] == 1 and (c[0], c[1]) == (V, F)
+
+
+def test_many_small_components_and_tiny_ones():
+    blobs = [(-0.8 + 0.2 * i, -0.8 + 0.2 * j, 0.1 * ((i + j) % 3) - 0.1, 0.04 + 0.01 * ((i * 3 + j) % 5)) for i in range(9) for j in range(9)]
+    c, V, F = _check(_volume(96, blobs))
+    assert c[2] >= 60
+
+
+def test_noise_volume_with_non_manifold_contacts():
+    """Random volumes produce components that touch along non-manifold edges and many 1-3 face fragments at exact zeros."""
+    vol = (syn.uniform((40, 40, 40), 77, -1.0, 1.0)).astype(np.float32)
+    vol[::5, ::7, ::3] = 0.0
+    _check(vol)
+
+
+def test_full_size_decoder_surface(golden_dir):
+    """N=256 pass-2 volume of the synthetic decoder: the filter on ~200 k faces."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    specs = syn.specs_for("nerf3")
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+    r = decode_two_pass(True, True, dec, torch.from_numpy(syn.latent_code(3)).cuda(), None, None, specs, 256)
+    for part in ("hand", "obj"):
+        _check(r["vol_" + part].cpu().numpy(), float(r["voxel_size"]), r["origin"])
