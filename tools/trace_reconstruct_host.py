@@ -31,7 +31,6 @@ def timed(mod, name, label=None):
 timed(mu, "export_surface")
 timed(mu, "begin_export_surface")
 timed(mu, "end_export_surface")
-timed(mu, "keep_largest_component")
 timed(mu, "write_ply")
 timed(mu, "place_vertices")
 timed(icp, "run_icp_f")
