@@ -110,12 +110,20 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
             b = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)[2].cpu().numpy()
         boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
         nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
-        vh, vo, _ = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=False, hand=hb, obj=ob)
-        return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b}
+        # under the split-half arithmetic pass 2 carries a bbox record too: its word 7 / 15 is the fp16 range report,
+        # read (for free) behind the marching-cubes size read-back in surfaces()
+        vh, vo, bbox2 = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=hip.math == "f16x3", hand=hb, obj=ob)
+        return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b, "bbox2": bbox2}
 
     def surfaces(r, sample):
         """Marching cubes (and the label pass) of one sample; returns True when the decoder was re-bound to it."""
         rebound = False
+        bbox2 = r.pop("bbox2", None)
+        if bbox2 is not None and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
+            # pass 2 left the fp16 range: the decoder is on the fp32 kernel from here on; repeat this sample's pass 2
+            bind(sample)
+            rebound = True
+            r["vol_hand"], r["vol_obj"], _ = hip.decode_grid(N, r["origin"], float(r["voxel_size"]), mode, want_bbox=False, hand=hb, obj=ob)
         for part, on in (("hand", hb), ("obj", ob)):
             r["V_" + part] = r["F_" + part] = 0
             if on:

@@ -271,8 +271,13 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     if obj_branch:
         boxes.append((b[8:11], b[11:14], int(b[14])))
     new_voxel_size, new_origin = zoom_cube_from_bboxes(boxes, N, voxel_size)
-    vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False,
-                                           hand=hand_branch, obj=obj_branch)
+    # the split-half arithmetic reports fp16 range violations through the bbox record: ask for it in pass 2 as well
+    guard = hip.math == "f16x3"
+    vol_hand, vol_obj, bbox2 = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=guard,
+                                               hand=hand_branch, obj=obj_branch)
+    if guard and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
+        vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False,
+                                               hand=hand_branch, obj=obj_branch)
     return {"vol_hand": vol_hand, "vol_obj": vol_obj, "voxel_size": new_voxel_size, "origin": new_origin.tolist(), "bbox": b}
 
 

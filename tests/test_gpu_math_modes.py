@@ -120,6 +120,33 @@ def test_fp16_overflow_is_detected_and_falls_back(tmp_path):
     hip.close()
 
 
+def test_fp16_overflow_in_the_sample_pipeline(golden_dir):
+    """The same decoder through pipelined_two_pass: the first sample trips the range report in pass 1, the pipeline
+    repeats the pass on the fp32 kernel and every sample comes out as the reference's volumes."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass
+    from oracle import sdf_oracle as orc
+    specs = syn.specs_for("nerf3")
+    base = syn.full_state_dict("nerf3")
+    sd = {}
+    for head in "ho":
+        for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
+            sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
+        sd["lin%s0.weight" % head] *= np.float32(4096.0)
+        sd["lin%s0.bias" % head] *= np.float32(4096.0)
+        sd["lin%s1.weight" % head] /= np.float32(4096.0)
+    hip = HipSdfDecoder(sd, 256, 3, "nerf")
+    lat = torch.from_numpy(syn.latent_code(0)).cuda()
+    out = list(pipelined_two_pass(hip, specs, [(k, lat, None, None) for k in range(3)], 32))
+    assert hip.math == "f32" and len(out) == 3
+    g = np.load(golden_dir + "/ref_decoder_nerf3.npz")
+    for _, r in out:
+        assert np.abs(r["vol_hand"].cpu().numpy() - g["vol2_hand_32"]).max() <= TOL
+        assert np.abs(r["vol_obj"].cpu().numpy() - g["vol2_obj_32"]).max() <= TOL
+        assert r["V_hand"] > 0 and r["V_obj"] > 0
+    hip.close()
+
+
 def test_nerf_encoded_decoder_stays_on_fp32(native_lib):
     hip = _decoder("nerf9")
     assert hip.math == "f32"                      # the default falls back: split-half covers affine point features only
