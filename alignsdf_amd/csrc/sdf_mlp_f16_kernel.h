@@ -17,6 +17,8 @@
 // output tile are therefore, after the split, the B operand of K-block 2 tile + s of the next layer (the host packs
 // the weight columns in that order).
 #pragma once
+#include <type_traits>
+
 #include "sdf_mlp_kernel.h"
 
 namespace asdf {
@@ -26,16 +28,30 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
-// LDS: ring + constants + one 8-int negative-voxel record per thread (the register file has no room for them)
-constexpr int kLdsBytesF16 = kLdsBytes + 256 * 8 * 4;
 
 // schedule knobs (tools/k1h_ablate.hip sweeps them; the values here are the shipped ones)
+#ifndef ASDF16_STAGE_KB
+#define ASDF16_STAGE_KB 16       // K-blocks per stage: 16 = 32 KiB stages (one barrier per 48 MFMAs), 8 = 16 KiB stages
+#endif
 #ifndef ASDF16_PREFETCH
 #define ASDF16_PREFETCH 1        // A fragments are read from LDS this many K-blocks ahead of their MFMAs
 #endif
 #ifndef ASDF16_BARRIER_KB
-#define ASDF16_BARRIER_KB 4      // K-block in front of which the stage's wait + barrier sit
+#define ASDF16_BARRIER_KB (ASDF16_STAGE_KB / 2)      // K-block in front of which the stage's wait + barrier sit
 #endif
+
+// The split-half stream of a head is a flat sequence of (tile, K-block) records of 2 KiB ([plane hi / lo][lane][8 halves]),
+// 1024 of them; a stage is ASDF16_STAGE_KB consecutive records of one tile, so the stage size is the kernel's choice.
+constexpr int kS16Kb = ASDF16_STAGE_KB;
+constexpr int kS16Floats = kS16Kb * 512;             // floats per stage
+constexpr int kS16Head = 1024 / kS16Kb;              // stages per head
+constexpr int kS16Pieces = kS16Kb / 2;               // 1 KiB LDS-DMA pieces per wave per stage
+constexpr int kS16WaveFloats = kS16Floats / kWaves;  // a wave's share of a stage
+constexpr int kRing16Floats = kRing * kS16Floats;
+// LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
+constexpr int kLdsBytesF16 = (kRing16Floats + kCstFloats) * 4 + kWaves * 16 * 4;
+static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
+static_assert(kLdsBytesF16 <= 160 * 1024, "LDS budget");
 
 // relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer; amax tracks the largest value
 // handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it, sdf_layout / alignsdf_hip.h)
@@ -58,7 +74,13 @@ __device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0
 #endif
 }
 
-// One stage = 8 K-blocks (K = 128) of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
+// One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
+template <int P>
+__device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
+  lds_dma16_off<(P & 3) * 1024>(src + (P >> 2) * 1024, dst + (P >> 2) * 4096);
+}
+
+// One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
 // stage in stream order.  ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier.
 template <int KB, int Q, int SLOT, int ABL, class Epi>
@@ -66,36 +88,49 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
                                         h8 (&ah)[ASDF16_PREFETCH], h8 (&al)[ASDF16_PREFETCH], Epi&& epi) {
   constexpr int PF = ASDF16_PREFETCH;
+  constexpr int BKB = ASDF16_BARRIER_KB;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
-  const float* src = next_src + wave * 1024 + lane * 4;
-  const unsigned dst = lds_ring_base + (nslot * kStageFloats + wave * 1024) * 4;
-  const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * kStageFloats) + lane;
-  const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * kStageFloats) + lane;
-  h8 bufh[8 + PF], bufl[8 + PF];
+  const float* src = next_src + wave * kS16WaveFloats + lane * 4;
+  const unsigned dst = lds_ring_base + (nslot * kS16Floats + wave * kS16WaveFloats) * 4;
+  const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * kS16Floats) + lane;
+  const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * kS16Floats) + lane;
+  h8 bufh[kS16Kb + PF], bufl[kS16Kb + PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) { bufh[i] = ah[i]; bufl[i] = al[i]; }
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
-    if (kb == ASDF16_BARRIER_KB && !(ABL & 1)) {
+  for (int kb = 0; kb < kS16Kb; ++kb) {
+    if (kb == BKB && !(ABL & 1)) {
       // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (kS16Pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     }
-    bufh[kb + PF] = kb + PF < 8 ? cur[((kb + PF) * 2 + 0) * 64] : nxt[((kb + PF - 8) * 2 + 0) * 64];
-    bufl[kb + PF] = kb + PF < 8 ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - 8) * 2 + 1) * 64];
-    constexpr int base = Q * 8;
-    const bool dma = !(ABL & 1);
-    acc = ASDF_MFMA16(bufh[kb], xl[base + kb], acc);
-    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<0>(src, dst); __builtin_amdgcn_sched_barrier(0); }
-    acc = ASDF_MFMA16(bufl[kb], xh[base + kb], acc);
-    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<1024>(src, dst); __builtin_amdgcn_sched_barrier(0); }
-    acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
-    if (dma && kb == ASDF16_BARRIER_KB) { lds_dma16_off<2048>(src, dst); __builtin_amdgcn_sched_barrier(0); }
-    if (dma && kb == ASDF16_BARRIER_KB + 1) { lds_dma16_off<3072>(src, dst); __builtin_amdgcn_sched_barrier(0); }
+    bufh[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 0) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 0) * 64];
+    bufl[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 1) * 64];
+    constexpr int base = Q * kS16Kb;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
+      acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
+      const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier
+      if (!(ABL & 1) && m >= 0 && m < kS16Pieces) {
+        if (m == 0) dma_piece<0>(src, dst);
+        else if (m == 1) dma_piece<1>(src, dst);
+        else if (m == 2) dma_piece<2>(src, dst);
+        else if (m == 3) dma_piece<3>(src, dst);
+        else if (m == 4) dma_piece<4>(src, dst);
+        else if (m == 5) dma_piece<5>(src, dst);
+        else if (m == 6) dma_piece<6>(src, dst);
+        else dma_piece<7>(src, dst);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (kb == 0) epi();
+    // keep the A-fragment reads of later K-blocks behind this one's MFMAs (hoisted, 16 K-blocks of fragments do not fit)
+    if (kS16Kb > 8 && (kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int i = 0; i < PF; ++i) { ah[i] = bufh[8 + i]; al[i] = bufl[8 + i]; }
+  for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; al[i] = bufl[kS16Kb + i]; }
 }
 
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = 2 (affine xyz features) only.
@@ -105,7 +140,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   constexpr int KP = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
-  float* cst = smem + kLdsRingFloats;
+  float* cst = smem + kRing16Floats;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,30 +156,29 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   for (int slot = 0; slot < p.num_mlps; ++slot) {
     const int head = p.first_mlp + slot;
     const float* hc = cst;
-    // negative-voxel bounding box of this MLP's output(s) + the out-of-range count, per thread, in LDS:
-    // rec[0..2] min index, rec[3..5] max index, rec[6] count, rec[7] points whose activations left the fp16 range (or
-    // whose output is not in [-1, 1]); second output of a CombinedDecoder in orec (count only shares rec[7])
-    int* rec = reinterpret_cast<int*>(cst + CL::kFloats) + tid * 8;
-    int omin0 = 0x7fffffff, omin1 = 0x7fffffff, omin2 = 0x7fffffff, omax0 = -1, omax1 = -1, omax2 = -1, ocnt = 0;   // TWO_OUT only
-    rec[0] = rec[1] = rec[2] = 0x7fffffff;
-    rec[3] = rec[4] = rec[5] = -1;
-    rec[6] = rec[7] = 0;
+    // negative-voxel bounding box of this MLP's output(s) + the range report, one record per wave and output in LDS:
+    // [0..2] min index, [3..5] max index, [6] count, [7] lanes whose activations left the fp16 range (or whose output is
+    // not in [-1, 1]); the second output of a CombinedDecoder uses the record 8 ints further
+    int* wrec = reinterpret_cast<int*>(cst + CL::kFloats) + wave * 16;
+    if (lane < 16) wrec[lane] = (lane & 7) < 3 ? 0x7fffffff : ((lane & 7) < 6 ? -1 : 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
       const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
       for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
     }
-    const float* sbase0 = p.stream + (size_t)head * kStagesHead * kStageFloats;
+    const float* sbase0 = p.stream + (size_t)head * kS16Head * kS16Floats;
 #pragma unroll
     for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
-      const float* src = sbase0 + (size_t)s * kStageFloats + wave * 1024 + lane * 4;
-      const unsigned dst = lds_ring_base + (s * kStageFloats + wave * 1024) * 4;
+      const float* src = sbase0 + (size_t)s * kS16Floats + wave * kS16WaveFloats + lane * 4;
+      const unsigned dst = lds_ring_base + (s * kS16Floats + wave * kS16WaveFloats) * 4;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) lds_dma16(src + c * 256, dst + c * 1024);
+      for (int c = 0; c < kS16Pieces; ++c) lds_dma16(src + c * 256, dst + c * 1024);
     }
     if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my pieces of stage 0 (and my constants loads)
+    // my pieces of stage 0 (and my constants loads): those of stages 1 and 2 may stay in flight
+    if (kS16Pieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();                                      // everybody's pieces of stage 0, and the constants
     h8 ah[ASDF16_PREFETCH], al[ASDF16_PREFETCH];
 #pragma unroll
@@ -171,7 +205,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const float* sbase = sbase0;
       asm volatile("" : "+s"(sbase));
       auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3
-        return sbase + (size_t)(s < kStagesHead ? s : s - kStagesHead) * kStageFloats;
+        return sbase + (size_t)(s < kS16Head ? s : s - kS16Head) * kS16Floats;
       };
 
       // ---- layer 0 (fp32 MFMA, K = 4 point features): planes of relu(.) * S_x
@@ -200,18 +234,29 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
           split_tile(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax);
         };
+#if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, epi);
         ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue());
         ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoEpilogue());
         ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, NoEpilogue());
+#else
+        if (t & 1) {
+          ASDF_STAGE16(32, 0, 2, acc, h0h, h0l, t * 2 + 0, epi);
+          ASDF_STAGE16(32, 1, 3, acc, h0h, h0l, t * 2 + 1, NoEpilogue());
+        } else {
+          ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 2 + 0, epi);
+          ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 2 + 1, NoEpilogue());
+        }
+#endif
       }
 
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
       f32x16 acc2[2];
-#pragma unroll
-      for (int t = 0; t < kTilesHidden; ++t) {
+      // one tile of layer 2; SLOT is the ring slot of its first stage (a tag type: the slot must be a compile-time constant)
+      auto l2_tile = [&](int t, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
         acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
 #pragma unroll
@@ -220,16 +265,29 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) split_tile(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax);
           else split_tile(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                          h1l[2 * kTilesL1 - 1], amax);          // K-blocks 14, 15: consumed by the second stage of this tile
+                          h1l[2 * kTilesL1 - 1], amax);          // K-blocks 14, 15: consumed by the second half of this tile
         };
-        constexpr int S0 = kStagesL1;
-        if (t & 1) {
-          ASDF_STAGE16(16, 0, 2, acc, h1h, h1l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(16, 1, 3, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
-        } else {
-          ASDF_STAGE16(16, 0, 0, acc, h1h, h1l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(16, 1, 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
-        }
+        constexpr int S0 = 256 / kS16Kb;         // stages of layer 1
+#if ASDF16_STAGE_KB == 8
+        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t * 2 + 0, epi);
+        ASDF_STAGE16(16, 1, SLOT + 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
+#else
+        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t, epi);      // one stage per tile
+#endif
+      };
+#pragma unroll
+      for (int tt = 0; tt < kTilesHidden / 4; ++tt) {
+#if ASDF16_STAGE_KB == 8
+        l2_tile(4 * tt + 0, std::integral_constant<int, 0>());
+        l2_tile(4 * tt + 1, std::integral_constant<int, 2>());
+        l2_tile(4 * tt + 2, std::integral_constant<int, 0>());
+        l2_tile(4 * tt + 3, std::integral_constant<int, 2>());
+#else
+        l2_tile(4 * tt + 0, std::integral_constant<int, 0>());
+        l2_tile(4 * tt + 1, std::integral_constant<int, 1>());
+        l2_tile(4 * tt + 2, std::integral_constant<int, 2>());
+        l2_tile(4 * tt + 3, std::integral_constant<int, 3>());
+#endif
       }
 
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
@@ -262,11 +320,21 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           else split_tile(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
                           h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax);     // K-blocks 30, 31: fourth stage of this tile
         };
-        constexpr int S0 = kStagesL1 + kStagesL2;
+        constexpr int S0 = 512 / kS16Kb;         // stages of layers 1 and 2
+#if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, epi);
         ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoEpilogue());
         ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoEpilogue());
         ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, NoEpilogue());
+#else
+        if (t & 1) {
+          ASDF_STAGE16(32, 0, 2, acc, h2h, h2l, S0 + t * 2 + 0, epi);
+          ASDF_STAGE16(32, 1, 3, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue());
+        } else {
+          ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 2 + 0, epi);
+          ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue());
+        }
+#endif
       }
       dot_w4(acc3[(kTilesHidden - 1) & 1], kTilesHidden - 1);
 #undef ASDF_STAGE16
@@ -283,41 +351,44 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         if (out) out[pi] = sdf;
         if (TWO_OUT && p.sdf1) p.sdf1[pi] = sdfb;
       }
-      if (p.bbox && valid && half == 0 && p.mode != kPointList) {
+      if (p.bbox && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
-        if (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f))) rec[7] += 1;
-        if (sdf < 0.0f) {
-          rec[0] = min(rec[0], i0); rec[1] = min(rec[1], i1); rec[2] = min(rec[2], i2);
-          rec[3] = max(rec[3], i0); rec[4] = max(rec[4], i1); rec[5] = max(rec[5], i2); rec[6] += 1;
-        }
-        if (TWO_OUT && sdfb < 0.0f) {
-          omin0 = min(omin0, i0); omin1 = min(omin1, i1); omin2 = min(omin2, i2);
-          omax0 = max(omax0, i0); omax1 = max(omax1, i1); omax2 = max(omax2, i2); ++ocnt;
-        }
+        // every lane reports its own activations (the two halves of a wave hold different features of the same point)
+        int bad = (valid && (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
+        auto fold = [&](bool neg, int* rec, int extra) {
+          int a0 = neg ? i0 : 0x7fffffff, a1 = neg ? i1 : 0x7fffffff, a2 = neg ? i2 : 0x7fffffff;
+          int b0 = neg ? i0 : -1, b1 = neg ? i1 : -1, b2 = neg ? i2 : -1, n = neg ? 1 : 0;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) {
+            a0 = min(a0, __shfl_xor(a0, m)); a1 = min(a1, __shfl_xor(a1, m)); a2 = min(a2, __shfl_xor(a2, m));
+            b0 = max(b0, __shfl_xor(b0, m)); b1 = max(b1, __shfl_xor(b1, m)); b2 = max(b2, __shfl_xor(b2, m));
+            n += __shfl_xor(n, m);
+            extra += __shfl_xor(extra, m);
+          }
+          if (lane == 0 && (n | extra)) {
+            rec[0] = min(rec[0], a0); rec[1] = min(rec[1], a1); rec[2] = min(rec[2], a2);
+            rec[3] = max(rec[3], b0); rec[4] = max(rec[4], b1); rec[5] = max(rec[5], b2);
+            rec[6] += n; rec[7] += extra;
+          }
+        };
+        fold(valid && half == 0 && sdf < 0.0f, wrec, bad);
+        if (TWO_OUT) fold(valid && half == 0 && sdfb < 0.0f, wrec + 8, 0);
       }
     }   // tiles
 
-    if (p.bbox) {
-      auto flush = [&](int* rec, int a0_, int a1_, int a2_, int b0_, int b1_, int b2_, int n) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-          a0_ = min(a0_, __shfl_xor(a0_, m)); a1_ = min(a1_, __shfl_xor(a1_, m)); a2_ = min(a2_, __shfl_xor(a2_, m));
-          b0_ = max(b0_, __shfl_xor(b0_, m)); b1_ = max(b1_, __shfl_xor(b1_, m)); b2_ = max(b2_, __shfl_xor(b2_, m));
-          n += __shfl_xor(n, m);
-        }
-        if (lane == 0 && n) {
-          atomicMin(rec + 0, a0_); atomicMin(rec + 1, a1_); atomicMin(rec + 2, a2_);
-          atomicMax(rec + 3, b0_); atomicMax(rec + 4, b1_); atomicMax(rec + 5, b2_);
-          atomicAdd(rec + 6, n);
+    if (p.bbox && lane == 0) {
+      // one set of atomics per wave: record 0 = hand (MLP 0 / first row), record 1 = object (MLP 1 / second row);
+      // word 7: lanes out of range (0 unless the fp16 planes overflowed; the host then falls back to fp32)
+      auto flush = [&](int* out, const int* rec) {
+        if (rec[6]) {
+          atomicMin(out + 0, rec[0]); atomicMin(out + 1, rec[1]); atomicMin(out + 2, rec[2]);
+          atomicMax(out + 3, rec[3]); atomicMax(out + 4, rec[4]); atomicMax(out + 5, rec[5]);
+          atomicAdd(out + 6, rec[6]);
         }
       };
-      flush(p.bbox + (head == 0 ? 0 : 8), rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6]);
-      if (TWO_OUT) flush(p.bbox + 8, omin0, omin1, omin2, omax0, omax1, omax2, ocnt);
-      // record word 7: points out of range (0 unless the fp16 planes overflowed; the host then falls back to fp32)
-      int bad = rec[7];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) bad += __shfl_xor(bad, m);
-      if (lane == 0 && bad) atomicAdd(p.bbox + (head == 0 ? 7 : 15), bad);
+      flush(p.bbox + (head == 0 ? 0 : 8), wrec);
+      if (TWO_OUT) flush(p.bbox + 8, wrec + 8);
+      if (wrec[7]) atomicAdd(p.bbox + (head == 0 ? 7 : 15), wrec[7]);
     }
   }   // MLPs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
