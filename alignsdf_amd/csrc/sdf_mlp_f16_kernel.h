@@ -33,6 +33,9 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #ifndef ASDF16_STAGE_KB
 #define ASDF16_STAGE_KB 16       // K-blocks per stage: 16 = 32 KiB stages (one barrier per 48 MFMAs), 8 = 16 KiB stages
 #endif
+#ifndef ASDF16_SCHED_KB
+#define ASDF16_SCHED_KB 1        // a scheduling fence every this many K-blocks bounds how far A-fragment reads are hoisted
+#endif
 #ifndef ASDF16_PREFETCH
 #define ASDF16_PREFETCH 1        // A fragments are read from LDS this many K-blocks ahead of their MFMAs
 #endif
@@ -53,26 +56,34 @@ constexpr int kLdsBytesF16 = (kRing16Floats + kCstFloats) * 4 + kWaves * 16 * 4;
 static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 static_assert(kLdsBytesF16 <= 160 * 1024, "LDS budget");
 
-// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer; amax tracks the largest value
-// handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it, sdf_layout / alignsdf_hip.h)
-__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
-    const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
+// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
+// amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
+__device__ __forceinline__ void split_part(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax, int e) {
+  const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
+  const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
 #ifndef ASDF16_NO_RANGE_CHECK
-    amax = fmaxf(amax, fmaxf(t0, t1));
+  amax = fmaxf(amax, fmaxf(t0, t1));
 #endif
-    const _Float16 a = (_Float16)t0, b = (_Float16)t1;
-    hi0[e] = a;
-    hi1[e] = b;
-    lo0[e] = (_Float16)(t0 - (float)a);
-    lo1[e] = (_Float16)(t1 - (float)b);
-  }
+  const _Float16 a = (_Float16)t0, b = (_Float16)t1;
+  hi0[e] = a;
+  hi1[e] = b;
+  lo0[e] = (_Float16)(t0 - (float)a);
+  lo1[e] = (_Float16)(t1 - (float)b);
 #ifndef ASDF16_NO_RANGE_CHECK
   asm volatile("" : "+v"(amax));      // keep the running maximum where it is computed (see dot_w4's pin in sdf_mlp_kernel.h)
 #endif
 }
+
+__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_part(acc, mul, hi0, lo0, hi1, lo1, amax, e);
+}
+
+// a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
+constexpr int kEpiChunks = 8;
+struct NoEpilogue16 {
+  __device__ __forceinline__ void operator()(int) const {}
+};
 
 // One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
 template <int P>
@@ -124,10 +135,13 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
         else dma_piece<7>(src, dst);
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef ASDF16_FENCE_EVERY_MFMA
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
-    if (kb == 0) epi();
+    if (kb < kEpiChunks) epi(kb);
     // keep the A-fragment reads of later K-blocks behind this one's MFMAs (hoisted, 16 K-blocks of fragments do not fit)
-    if (kS16Kb > 8 && (kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    if (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; al[i] = bufl[kS16Kb + i]; }
@@ -229,23 +243,23 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
         acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
-        auto epi = [&]() {
+        auto epi = [&](int c) {
           if (t == 0) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          split_tile(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax);
+          split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax, c);
         };
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, epi);
-        ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue());
-        ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoEpilogue());
-        ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, NoEpilogue());
+        ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue16());
+        ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoEpilogue16());
+        ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, NoEpilogue16());
 #else
         if (t & 1) {
           ASDF_STAGE16(32, 0, 2, acc, h0h, h0l, t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 3, acc, h0h, h0l, t * 2 + 1, NoEpilogue());
+          ASDF_STAGE16(32, 1, 3, acc, h0h, h0l, t * 2 + 1, NoEpilogue16());
         } else {
           ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 2 + 1, NoEpilogue());
+          ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 2 + 1, NoEpilogue16());
         }
 #endif
       }
@@ -261,16 +275,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
-        auto epi = [&]() {
+        auto epi = [&](int c) {
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
-          if (t > 0) split_tile(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax);
-          else split_tile(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                          h1l[2 * kTilesL1 - 1], amax);          // K-blocks 14, 15: consumed by the second half of this tile
+          if (t > 0) split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax, c);
+          else split_part(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
+                          h1l[2 * kTilesL1 - 1], amax, c);       // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
         };
         constexpr int S0 = 256 / kS16Kb;         // stages of layer 1
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t * 2 + 0, epi);
-        ASDF_STAGE16(16, 1, SLOT + 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue());
+        ASDF_STAGE16(16, 1, SLOT + 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue16());
 #else
         ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t, epi);      // one stage per tile
 #endif
@@ -293,46 +307,45 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
       float part = 0.0f, partb = 0.0f;
       f32x16 acc3[2];
-      auto dot_w4 = [&](const f32x16 a, int t) {
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(hc + CL::kW4 + (t * 2 + half) * 16);
-        const f32x4* w4b = reinterpret_cast<const f32x4*>(hc + CL::kW4b + (t * 2 + half) * 16);
+      // accumulator registers 2 c, 2 c + 1 of tile t into the last-layer dot product(s)
+      auto dot_w4_part = [&](const f32x16 a, int t, int c) {
+        const float* w4 = hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
+        const float* w4b = hc + CL::kW4b + (t * 2 + half) * 16 + 2 * c;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 w = w4[c];
-          f32x4 wb = w;
-          if (TWO_OUT) wb = w4b[c];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = __int_as_float(max(__float_as_int(a[c * 4 + r]), 0));
-            part = fmaf(v, w[r], part);
-            if (TWO_OUT) partb = fmaf(v, wb[r], partb);
-          }
+        for (int r = 0; r < 2; ++r) {
+          const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
+          part = fmaf(v, w4[r], part);
+          if (TWO_OUT) partb = fmaf(v, w4b[r], partb);
         }
         if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
+      };
+      auto dot_w4 = [&](const f32x16 a, int t) {
+#pragma unroll
+        for (int c = 0; c < kEpiChunks; ++c) dot_w4_part(a, t, c);
       };
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
         acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
-        auto epi = [&]() {
+        auto epi = [&](int c) {
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
-          if (t > 0) dot_w4(acc3[(t - 1) & 1], t - 1);
-          else split_tile(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
-                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax);     // K-blocks 30, 31: fourth stage of this tile
+          if (t > 0) dot_w4_part(acc3[(t - 1) & 1], t - 1, c);
+          else split_part(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
+                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax, c);  // K-blocks 30, 31: end of this tile
         };
         constexpr int S0 = 512 / kS16Kb;         // stages of layers 1 and 2
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, epi);
-        ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoEpilogue());
-        ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoEpilogue());
-        ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, NoEpilogue());
+        ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoEpilogue16());
+        ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoEpilogue16());
+        ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, NoEpilogue16());
 #else
         if (t & 1) {
           ASDF_STAGE16(32, 0, 2, acc, h2h, h2l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 3, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue());
+          ASDF_STAGE16(32, 1, 3, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue16());
         } else {
           ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue());
+          ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue16());
         }
 #endif
       }
