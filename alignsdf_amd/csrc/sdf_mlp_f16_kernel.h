@@ -123,7 +123,7 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
     for (int j = 0; j < 3; ++j) {
       // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
       acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
-      const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier
+      const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
       if (!(ABL & 1) && m >= 0 && m < kS16Pieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
