@@ -19,6 +19,9 @@
 //     placed mid-stage in the shadow of an MFMA;
 //   * bias / ReLU / final dot-product + tanh are fused epilogues on the accumulator registers,
 //     deferred into the MFMA stream of the next output tile.
+// Two kernels share this structure: sdf_mlp_kernel.h (v_mfma_f32_32x32x2_f32, the description above) and
+// sdf_mlp_f16_kernel.h (split-half: two fp16 planes per operand, three v_mfma_f32_32x32x16_f16 per product sum, 32 KiB
+// stages) - the default for the grid sweeps.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
