@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libalignsdf_hip.so")
-SOURCES = ["decoder.hip", "mc33.hip", "icp.hip", "mesh_cc.hip"]
+SOURCES = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "mc33.hip", "icp.hip", "mesh_cc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library. Returns its path."""
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "alignsdf_hip.h"))
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -34,8 +34,11 @@ def build(force=False, verbose=False):
             cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True, cwd=CSRC)
+            jobs.append((src, subprocess.Popen(cmd, cwd=CSRC)))      # the translation units compile side by side
         objs.append(o)
+    failed = [src for src, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc (%s)" % ", ".join(failed))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:

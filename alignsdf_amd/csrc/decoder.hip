@@ -10,8 +10,7 @@
 #include "../../include/alignsdf_hip.h"
 #include "common.h"
 #include "pack.h"
-#include "sdf_mlp_f16_kernel.h"
-#include "sdf_mlp_kernel.h"
+#include "k1_launch.h"
 
 namespace asdf {
 
@@ -226,20 +225,10 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     for (int h = 0; h < kHeads; ++h) d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
-    for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel})
-      if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16);
+    if (e == hipSuccess) e = k1h_prepare();
   }
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sdf_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sdf_mlp_combined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  for (const void* k : {(const void*)sdf_mlp_nerf9_kernel, (const void*)sdf_mlp_nerf15_kernel,
-                        (const void*)sdf_mlp_combined_nerf9_kernel, (const void*)sdf_mlp_combined_nerf15_kernel})
-    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kMaxKP));
-  for (const void* k : {(const void*)sdf_mlp_cls_kernel, (const void*)sdf_mlp_combined_cls_kernel,
-                        (const void*)sdf_mlp_nerf9_cls_kernel, (const void*)sdf_mlp_nerf15_cls_kernel,
-                        (const void*)sdf_mlp_combined_nerf9_cls_kernel, (const void*)sdf_mlp_combined_nerf15_cls_kernel})
-    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_cls(kMaxKP));
+  if (e == hipSuccess) e = k1_prepare();
+  if (e == hipSuccess) e = k1_cls_prepare();
 
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -336,17 +325,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
     p.cls = d->cls;
     p.num_class = d->num_class;
     if (!two_out && p.first_mlp != 0) { p.first_mlp = 0; p.num_mlps = 2; }
-    const int lds = lds_bytes_cls(d->kp);
-    if (d->kp == 2) {
-      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-      else hipLaunchKernelGGL(sdf_mlp_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-    } else if (d->kp == 5) {
-      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf9_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-      else hipLaunchKernelGGL(sdf_mlp_nerf9_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-    } else {
-      if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-      else hipLaunchKernelGGL(sdf_mlp_nerf15_cls_kernel, dim3(grid), dim3(256), lds, st, p);
-    }
+    k1_cls_launch(d->kp, two_out, p, grid, st);
     ASDF_HIP(hipGetLastError());
     return ASDF_OK;
   }
@@ -355,17 +334,9 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (d->math == ASDF_MATH_F16X3 && d->stream16 && p.mode != kPointList) {
     p.stream = d->stream16;
     p.cst = d->cst16;
-    if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
-    else hipLaunchKernelGGL(sdf_mlp_f16_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
-  } else if (d->kp == 2) {
-    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
-    else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
-  } else if (d->kp == 5) {
-    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
-    else hipLaunchKernelGGL(sdf_mlp_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+    k1h_launch(two_out, p, grid, st);
   } else {
-    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
-    else hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+    k1_launch(d->kp, two_out, p, grid, st);
   }
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;

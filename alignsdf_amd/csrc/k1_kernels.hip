@@ -1,0 +1,37 @@
+// K1 on the fp32 MFMA: SeparateDecoder / CombinedDecoder, affine xyz features or the in-kernel NeRF encoding (PointFeatSize 9 / 15, utils/mesh.py:53-55).
+#include "k1_launch.h"
+#include "sdf_mlp_kernel.h"
+
+namespace asdf {
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
+
+hipError_t k1_prepare() {
+  hipError_t e = hipSuccess;
+  for (const void* k : {(const void*)sdf_mlp_kernel, (const void*)sdf_mlp_combined_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  for (const void* k : {(const void*)sdf_mlp_nerf9_kernel, (const void*)sdf_mlp_nerf15_kernel,
+                        (const void*)sdf_mlp_combined_nerf9_kernel, (const void*)sdf_mlp_combined_nerf15_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kMaxKP));
+  return e;
+}
+
+void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  if (kp == 2) {
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_kernel, dim3(grid), dim3(256), kLdsBytes, st, p);
+  } else if (kp == 5) {
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_nerf9_kernel, dim3(grid), dim3(256), lds_bytes(5), st, p);
+  } else {
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+    else hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
+  }
+}
+
+}  // namespace asdf

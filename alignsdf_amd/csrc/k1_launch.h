@@ -1,0 +1,20 @@
+// Launch interface of the fused decoder kernels: each family is its own translation unit (k1_kernels.hip: fp32 MFMA,
+// k1_cls_kernels.hip: fp32 MFMA + part classifier, k1h_kernels.hip: split-half fp16 MFMA) and compiles on its own.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sdf_mlp_common.h"
+
+namespace asdf {
+
+// raise the dynamic-LDS limit of the family's kernels (once per process; cheap)
+hipError_t k1_prepare();
+hipError_t k1_cls_prepare();
+hipError_t k1h_prepare();
+
+// kp = point-feature K-steps (2 affine xyz, 5 / 8 NeRF encoding of 9 / 15 features); two_out = CombinedDecoder
+void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
+void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
+void k1h_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // kp == 2 only
+
+}  // namespace asdf

@@ -1,0 +1,22 @@
+// K1h: the fused decoder on split-half fp16 MFMAs (sdf_mlp_f16_kernel.h), the default arithmetic of the grid sweeps.
+#include "k1_launch.h"
+#include "sdf_mlp_f16_kernel.h"
+
+namespace asdf {
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams p) { sdf_mlp_f16_body<false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
+
+hipError_t k1h_prepare() {
+  hipError_t e = hipSuccess;
+  for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16);
+  return e;
+}
+
+void k1h_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
+  else hipLaunchKernelGGL(sdf_mlp_f16_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
+}
+
+}  // namespace asdf

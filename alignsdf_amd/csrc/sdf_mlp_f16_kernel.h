@@ -407,7 +407,6 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams p) { sdf_mlp_f16_body<false>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
+// The __global__ instantiations live in k1h_kernels.hip; tools/k1h_ablate.hip instantiates its own.
 
 }  // namespace asdf

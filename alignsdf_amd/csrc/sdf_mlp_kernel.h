@@ -349,19 +349,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, true>(p); }
-// NeRF positional encoding of the query point (PointFeatSize 9 / 15 without pose alignment, utils/mesh.py:53-55)
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, false>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
-// label pass (utils/mesh.py:137-157): the same sweeps with the part classifier riding in the last-layer epilogue
-__global__ __launch_bounds__(256, 1) void sdf_mlp_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, false, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 2, true, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf9_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, false, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, false, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true, true>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_cls_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true, true>(p); }
+// The __global__ instantiations live in k1_kernels.hip / k1_cls_kernels.hip (one translation unit per family, so that
+// they compile side by side); tools/k1_ablate.hip instantiates its own.
 
 }  // namespace asdf

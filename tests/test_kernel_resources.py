@@ -12,13 +12,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.fixture(scope="module")
 def compiled(tmp_path_factory):
-    """One device-only compile of decoder.hip: (resource-usage remarks, ISA text)."""
-    asm = tmp_path_factory.mktemp("isa") / "decoder.s"
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                          "--cuda-device-only", "decoder.hip", "-o", str(asm), "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC,
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    return out.stderr, asm.read_text()
+    """One device-only compile of every decoder translation unit (side by side): (resource-usage remarks, ISA text)."""
+    out_dir = tmp_path_factory.mktemp("isa")
+    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip"]
+    procs = [(u, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                                   "--cuda-device-only", u, "-o", str(out_dir / (u + ".s")), "-Rpass-analysis=kernel-resource-usage"],
+                                  cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for u in units]
+    remarks, isa = "", ""
+    for u, proc in procs:
+        _, err = proc.communicate(timeout=900)
+        assert proc.returncode == 0, (u, err[-2000:])
+        remarks += err
+        isa += (out_dir / (u + ".s")).read_text()
+    return remarks, isa
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
