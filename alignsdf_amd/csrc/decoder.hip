@@ -147,7 +147,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 108; }
+int asdf_version(void) { return 109; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -219,7 +219,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   };
   up(&d->stream, stream); up(&d->wlat, wlat); up(&d->wpt, wpt); up(&d->bias02, b02); up(&d->cst, cst); up(&d->embed, emb);
   d->math = ASDF_MATH_F32;
-  if (hp.kp == 2 && e == hipSuccess) {
+  if (e == hipSuccess) {
     if (!pack_decoder_f16(*spec, heads, hp)) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
     up(&d->cst16, hp.cst16);
     if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
@@ -265,7 +265,6 @@ int asdf_debug_pack_host_f16(const asdf_decoder_spec_t* spec, const asdf_head_pa
   if (!spec || !heads || !spec_supported(spec)) return ASDF_EINVAL;
   HostPack hp;
   if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
-  if (hp.kp != 2) return ASDF_EINVAL;
   if (!pack_decoder_f16(*spec, heads, hp)) return ASDF_ENOMEM;
   if (stream16) std::memcpy(stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t));
   if (cst16) std::memcpy(cst16, hp.cst16.data(), hp.cst16.size() * sizeof(float));
@@ -334,7 +333,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (d->math == ASDF_MATH_F16X3 && d->stream16 && p.mode != kPointList) {
     p.stream = d->stream16;
     p.cst = d->cst16;
-    k1h_launch(two_out, p, grid, st);
+    k1h_launch(d->kp, two_out, p, grid, st);
   } else {
     k1_launch(d->kp, two_out, p, grid, st);
   }
@@ -365,7 +364,7 @@ int asdf_decode_points(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float
 
 int asdf_decoder_set_math(asdf_decoder_t* d, int32_t math) {
   if (!d || (math != ASDF_MATH_F32 && math != ASDF_MATH_F16X3)) return ASDF_EINVAL;
-  if (math == ASDF_MATH_F16X3 && !d->stream16) return ASDF_EINVAL;      // NeRF-encoded decoders: fp32 MFMA only
+  if (math == ASDF_MATH_F16X3 && !d->stream16) return ASDF_EINVAL;
   d->math = math;
   return ASDF_OK;
 }

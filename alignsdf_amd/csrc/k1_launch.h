@@ -10,11 +10,13 @@ namespace asdf {
 // raise the dynamic-LDS limit of the family's kernels (once per process; cheap)
 hipError_t k1_prepare();
 hipError_t k1_cls_prepare();
-hipError_t k1h_prepare();
+hipError_t k1h_prepare();            // includes the NeRF-encoded family
+hipError_t k1h_nerf_prepare();
 
 // kp = point-feature K-steps (2 affine xyz, 5 / 8 NeRF encoding of 9 / 15 features); two_out = CombinedDecoder
 void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
-void k1h_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // kp == 2 only
+void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
+void k1h_nerf_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // kp 5 / 8 (k1h_nerf_kernels.hip)
 
 }  // namespace asdf

@@ -8,13 +8,14 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams 
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
 
 hipError_t k1h_prepare() {
-  hipError_t e = hipSuccess;
+  hipError_t e = k1h_nerf_prepare();
   for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16);
   return e;
 }
 
-void k1h_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  if (kp != 2) { k1h_nerf_launch(kp, two_out, p, grid, st); return; }
   if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
   else hipLaunchKernelGGL(sdf_mlp_f16_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
 }

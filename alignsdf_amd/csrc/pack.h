@@ -48,8 +48,7 @@ inline float weight_scale(const float* w, int rows, int cols, int ld) {
 // fp32 point-feature products enter the same accumulator pre-multiplied by S_w S_x, and the (exact, power-of-two)
 // rescale happens when the accumulator is turned into the next layer's planes.
 inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_params_t* heads, HostPack& hp) {
-  if (hp.kp != 2) return false;
-  const CstOffsets co = cst_offsets(2);
+  const CstOffsets co = cst_offsets(hp.kp);
   try {
     hp.stream16.assign((size_t)kStagesAll * kStageFloats * 2, 0);
     hp.cst16 = hp.cst;
@@ -98,6 +97,9 @@ inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_pa
         }
     c[co.b4 + 2] = 1.0f / sw1;      // accumulator -> next planes: relu(acc) / S_w (the S_x factor stays in)
     c[co.b4 + 3] = 1.0f / sw2;
+    // NeRF encoding: the layer-2 point-feature fragments are static (not folded per sample) - scale them here
+    if (spec.feature_mode == ASDF_FEATURES_NERF)
+      for (int i = 0; i < kTilesHidden * hp.kp * 64; ++i) c[co.a2 + i] *= hp.s2[h];
   }
   return true;
 }

@@ -52,9 +52,9 @@ constexpr int kS16Pieces = kS16Kb / 2;               // 1 KiB LDS-DMA pieces per
 constexpr int kS16WaveFloats = kS16Floats / kWaves;  // a wave's share of a stage
 constexpr int kRing16Floats = kRing * kS16Floats;
 // LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
-constexpr int kLdsBytesF16 = (kRing16Floats + kCstFloats) * 4 + kWaves * 16 * 4;
+constexpr int lds_bytes_f16(int kp) { return (kRing16Floats + cst_offsets(kp).floats) * 4 + kWaves * 16 * 4; }
+constexpr int kLdsBytesF16 = lds_bytes_f16(2);
 static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
-static_assert(kLdsBytesF16 <= 160 * 1024, "LDS budget");
 
 // relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
 // amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
@@ -147,11 +147,13 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
   for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; al[i] = bufl[kS16Kb + i]; }
 }
 
-// p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = 2 (affine xyz features) only.
-template <bool TWO_OUT, int ABL = 0>
+// p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
+// MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
+// constants block is 40 / 75 KiB).
+template <bool TWO_OUT, int ABL = 0, int KP = 2>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
-  using CL = CstLayout<2>;
-  constexpr int KP = 2;
+  using CL = CstLayout<KP>;
+  static_assert(lds_bytes_f16(KP) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
   float* cst = smem + kRing16Floats;
@@ -214,8 +216,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
       float amax = 0.0f;                        // largest activation plane value of this tile
       float bp[KP];
-      bp[0] = half ? x1 : x0;
-      bp[1] = half ? 0.0f : x2;
+      if (KP == 2) {
+        bp[0] = half ? x1 : x0;
+        bp[1] = half ? 0.0f : x2;
+      } else {
+#pragma unroll
+        for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
+      }
       const float* sbase = sbase0;
       asm volatile("" : "+s"(sbase));
       auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3

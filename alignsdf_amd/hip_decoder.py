@@ -159,7 +159,7 @@ class HipSdfDecoder:
         # ASDF_MATH overrides the default
         self.math = "f32"
         want = os.environ.get("ASDF_MATH", DEFAULT_MATH)
-        if want == "f16x3" and not self.nerf_features:
+        if want == "f16x3":
             self.set_math("f16x3")
         elif want not in ("f32", "f16x3"):
             raise ValueError("ASDF_MATH must be 'f32' or 'f16x3', not %r" % want)

@@ -119,8 +119,7 @@ int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, flo
  *   ASDF_MATH_F16X3  split-half: every operand carried as two fp16 planes (22 significand bits) of a power-of-two
  *                    scaled value, a product sum = three v_mfma_f32_32x32x16_f16 into one fp32 accumulator.  fp32-class
  *                    results (same error against fp64 as the fp32 chain on the test decoders, well inside the 1e-5 bar)
- *                    at 3/16 of the matrix-pipe time.  Available for xyz / pose-aligned (affine) point features;
- *                    ASDF_EINVAL for NeRF-encoded decoders.  Operands must stay inside the fp16 range (hidden
+ *                    at 3/16 of the matrix-pipe time.  Operands must stay inside the fp16 range (hidden
  *                    activations |x| < 8188): violations are counted in word 7 of the bbox record of asdf_decode_grid,
  *                    and a caller that sees a non-zero count switches to ASDF_MATH_F32 and repeats the sweep (pass a
  *                    bbox buffer to every sweep whose range is not known to be safe).
@@ -204,7 +203,7 @@ int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t n
  * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed);
-/* The split-half image of the same decoder (ASDF_MATH_F16X3; affine point features only): stream16 2*128*8192 fp16 bit
+/* The split-half image of the same decoder (ASDF_MATH_F16X3): stream16 2*128*8192 fp16 bit
  * patterns (stage = [kblock 8][plane hi/lo][lane 64][8]), cst16 = the constants block with the scaled entries,
  * s2[2] = the layer-2 accumulator scale per head that K0 applies to the per-sample constants. */
 int asdf_debug_pack_host_f16(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16,

@@ -66,7 +66,7 @@ def pack_host(sd, point_feat_size, encode_style):
     out["combined"] = combined
     out["kp"] = kp
     out["nerf"] = nerf
-    if not nerf:      # split-half image (sdf_mlp_f16_kernel.h)
+    if True:          # split-half image (sdf_mlp_f16_kernel.h)
         out["stream16"] = np.zeros(256 * STAGE * 2, np.uint16)
         out["cst16"] = np.zeros(2 * offsets(kp)["FLOATS"], np.float32)
         out["s2"] = np.zeros(2, np.float32)

@@ -31,7 +31,7 @@ def test_default_is_split_half():
     assert _decoder("nerf3").math == "f16x3"
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
 def test_both_modes_match_reference_points_and_grids(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     hip = _decoder(tag)
@@ -147,11 +147,10 @@ def test_fp16_overflow_in_the_sample_pipeline(golden_dir):
     hip.close()
 
 
-def test_nerf_encoded_decoder_stays_on_fp32(native_lib):
+def test_set_math_argument_checks(native_lib):
     hip = _decoder("nerf9")
-    assert hip.math == "f32"                      # the default falls back: split-half covers affine point features only
-    assert native_lib.asdf_decoder_set_math(hip._h, 1) == -1
+    assert hip.math == "f16x3"                    # NeRF-encoded decoders run the split-half kernel too (16 KiB stages)
     assert native_lib.asdf_decoder_set_math(hip._h, 7) == -1
-    assert native_lib.asdf_decoder_get_math(hip._h) == 0
-    with pytest.raises(Exception):
-        hip.set_math("f16x3")
+    assert native_lib.asdf_decoder_set_math(None, 0) == -1
+    assert native_lib.asdf_decoder_set_math(hip._h, 0) == 0 and native_lib.asdf_decoder_get_math(hip._h) == 0
+    assert native_lib.asdf_decoder_set_math(hip._h, 1) == 0 and native_lib.asdf_decoder_get_math(hip._h) == 1
