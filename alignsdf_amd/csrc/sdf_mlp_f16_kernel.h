@@ -86,6 +86,8 @@ struct NoEpilogue16 {
 };
 
 // One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
+// (Writing M0 once per four pieces instead of save / set / restore around each: -0.5 %, not worth relying on M0 surviving
+// between asm statements.)
 template <int P>
 __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
   lds_dma16_off<(P & 3) * 1024>(src + (P >> 2) * 1024, dst + (P >> 2) * 4096);
@@ -93,7 +95,8 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 
 // One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
-// stage in stream order.  ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier.
+// stage in stream order.  ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
+// 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
 template <int KB, int Q, int SLOT, int ABL, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
@@ -124,7 +127,7 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
       // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
       acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
       const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
-      if (!(ABL & 1) && m >= 0 && m < kS16Pieces) {
+      if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < kS16Pieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
         else if (m == 2) dma_piece<2>(src, dst);
@@ -185,13 +188,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     }
     const float* sbase0 = p.stream + (size_t)head * kS16Head * kS16Floats;
 #pragma unroll
-    for (int s = 0; s < ((ABL & 1) ? kRing : kRing - 1); ++s) {
+    for (int s = 0; s < ((ABL & 33) ? kRing : kRing - 1); ++s) {
       const float* src = sbase0 + (size_t)s * kS16Floats + wave * kS16WaveFloats + lane * 4;
       const unsigned dst = lds_ring_base + (s * kS16Floats + wave * kS16WaveFloats) * 4;
 #pragma unroll
       for (int c = 0; c < kS16Pieces; ++c) lds_dma16(src + c * 256, dst + c * 1024);
     }
-    if (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ABL & 33) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // my pieces of stage 0 (and my constants loads): those of stages 1 and 2 may stay in flight
     if (kS16Pieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
