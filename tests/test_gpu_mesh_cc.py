@@ -83,3 +83,44 @@ def test_full_size_decoder_surface(golden_dir):
     r = decode_two_pass(True, True, dec, torch.from_numpy(syn.latent_code(3)).cuda(), None, None, specs, 256)
     for part in ("hand", "obj"):
         _check(r["vol_" + part].cpu().numpy(), float(r["voxel_size"]), r["origin"])
+
+
+def _compare_raw(verts, faces, vs=1.0, origin=(0.0, 0.0, 0.0)):
+    """Hand-built meshes (not marching-cubes output): device filter vs the host restatement, in lattice units."""
+    v = torch.tensor(verts, dtype=torch.float32).cuda()
+    f = torch.tensor(faces, dtype=torch.int32).cuda()
+    ov, of, counts = mesh_post.keep_largest_component_device(v, f, vs, list(origin))
+    c = counts.cpu().numpy()
+    hv, hf = mesh_oracle.keep_largest_component(np.asarray(verts, np.float32), np.asarray(faces, np.int32))
+    assert np.array_equal(of[:c[1]].cpu().numpy(), hf) and np.array_equal(ov[:c[0]].cpu().numpy(), hv)
+    return c
+
+
+def _tetra(base, p0, size):
+    p = np.array(p0, np.float32)
+    verts = [p, p + [size, 0, 0], p + [0, size, 0], p + [0, 0, size]]
+    faces = [[base + 0, base + 2, base + 1], [base + 0, base + 1, base + 3], [base + 1, base + 2, base + 3], [base + 0, base + 3, base + 2]]
+    return [list(map(float, x)) for x in verts], faces
+
+
+def test_hand_built_meshes_with_non_manifold_and_duplicate_elements():
+    # two separate tetrahedra of different size (the smaller one first) + an unreferenced vertex
+    v1, f1 = _tetra(0, (0, 0, 0), 1.0)
+    v2, f2 = _tetra(4, (5, 5, 5), 3.0)
+    c = _compare_raw(v1 + v2 + [[9.0, 9.0, 9.0]], f1 + f2)
+    assert c[2] == 2 and c[0] == 4 and c[1] == 4 and c[3] == 4
+    # the same two sharing one vertex only: still two components (adjacency is by edges, not vertices)
+    f2s = [[(i if i != 4 else 3) for i in tri] for tri in f2]
+    assert _compare_raw(v1 + v2, f1 + f2s)[2] == 2
+    # a third triangle on an edge of a closed tetrahedron makes that edge non-manifold: its component is not watertight
+    extra_v = v1 + v2 + [[0.5, 0.5, -1.0]]
+    assert _compare_raw(extra_v, f1 + f2 + [[0, 1, 8]])[2] == 1
+    # a duplicated face (both copies claim the same three edges -> every edge has 3 owners)
+    assert _compare_raw(v1 + v2, f1 + [f1[0]] + f2)[2] == 1
+    # a lone triangle and a 2-triangle strip next to a closed surface: fewer than 4 faces / open -> dropped from the count
+    strip_v = v2 + [[20.0, 0, 0], [21.0, 0, 0], [20.0, 1, 0], [21.0, 1, 0]]
+    assert _compare_raw(strip_v, [[t[0] - 4, t[1] - 4, t[2] - 4] for t in f2] + [[4, 5, 6], [5, 7, 6]])[2] == 1
+    # equal areas: the first component wins
+    v3, f3 = _tetra(4, (7, 7, 7), 1.0)
+    c = _compare_raw(v1 + v3, f1 + f3)
+    assert c[2] == 2 and c[3] == 0
