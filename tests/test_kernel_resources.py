@@ -58,7 +58,8 @@ def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
     """In the ISA of the shipped decoder kernels every scratch load / store must come before the first MFMA of the kernel
     body (kernel / head-loop prologue) - a spill between MFMAs costs whole percents and no parity test sees it."""
     text = compiled[1]
-    for mangled in ("_ZN4asdf14sdf_mlp_kernelENS_12DecodeParamsE", "_ZN4asdf18sdf_mlp_f16_kernelENS_12DecodeParamsE"):
+    for mangled in ("_ZN4asdf14sdf_mlp_kernelENS_12DecodeParamsE", "_ZN4asdf18sdf_mlp_f16_kernelENS_12DecodeParamsE",
+                    "_ZN4asdf27sdf_mlp_f16_combined_kernelENS_12DecodeParamsE"):
         body = text[text.index(mangled + ":"):]
         body = body[:body.index("s_endpgm")].splitlines()
         mfma = [i for i, l in enumerate(body) if "v_mfma_" in l]
