@@ -234,13 +234,18 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 
       // ---- layer 0 (fp32 MFMA, K = 4 point features): planes of relu(.) * S_x
       h8 h0h[2 * kTilesHidden], h0l[2 * kTilesHidden];
-#pragma unroll
-      for (int t = 0; t < kTilesHidden; ++t) {
+      auto l0_tile = [&](int t) {
         f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
         split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
-      }
+      };
+      // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
+      // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
+      // the others ride in the epilogue slots of that stage, under its fp16 MFMAs.
+      constexpr int kL0Front = kS16Kb / 2 < kEpiChunks ? kTilesHidden : kS16Kb / 2;
+#pragma unroll
+      for (int t = 0; t < kL0Front; ++t) l0_tile(t);
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, EPI) \
   stage16<KB, Q, SLOT, ABL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, EPI)
@@ -254,7 +259,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         f32x16& acc = acc1[t & 1];
         acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
         auto epi = [&](int c) {
-          if (t == 0) return;
+          if (t == 0) {
+            if (kL0Front < kTilesHidden) l0_tile(kL0Front + c);      // layer-0 tiles 8 .. 15: consumed by the next stage
+            return;
+          }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
           split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax, c);
         };
