@@ -119,6 +119,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL then prints a five-line banner on STDOUT of every rank, next to the
+        # one JSON line the caller parses
+        os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from alignsdf_amd.hip_decoder import HipSdfDecoder
@@ -266,7 +269,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.tag, N, vh.cpu().numpy(), vo.cpu().numpy())
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
