@@ -119,9 +119,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL then prints a five-line banner on STDOUT of every rank, next to the
-        # one JSON line the caller parses
-        os.environ["NCCL_DEBUG"] = "WARN"
+        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL then prints a five-line banner on STDOUT of every rank (at WARN as
+        # well), next to the one JSON line the caller parses
+        os.environ.pop("NCCL_DEBUG", None)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from alignsdf_amd.hip_decoder import HipSdfDecoder

@@ -2,7 +2,7 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, ".")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
 torch.cuda.set_device(0)
-os.environ["NCCL_DEBUG"] = "WARN"
+os.environ.pop("NCCL_DEBUG", None)
 dist.init_process_group("nccl", rank=0, world_size=1)
 from alignsdf_amd.dist_reconstruct import gather_records, RECORD_FIELDS
 recs = [dict(index=3, V_hand=10, F_hand=20, V_obj=5, F_obj=6, milliseconds=1.5), dict(index=1, V_hand=1, F_hand=2, V_obj=3, F_obj=4, milliseconds=0.5)]
