@@ -106,6 +106,41 @@ __global__ __launch_bounds__(256) void neg_bbox_kernel(const float* __restrict__
   }
 }
 
+// Voxels whose value lies within tau of the iso level, of one or two volumes swept on the same lattice: their linear
+// indices are appended to idx (order arbitrary), *count counts all of them (also those beyond cap: status[1] then counts
+// the voxels that could not be listed).  float4 path when n is a multiple of 4.
+__global__ __launch_bounds__(256) void collect_near_level_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                                 float tau, int* idx, int* count, int cap, int* status) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto hit = [&](long long i) {
+    const int k = atomicAdd(count, 1);
+    if (k < cap) idx[k] = (int)i;
+    else if (status) atomicAdd(status + 1, 1);
+  };
+  if ((n & 3) == 0) {
+    for (long long q = t0; q < n / 4; q += stride) {
+      float4 va = a ? reinterpret_cast<const float4*>(a)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+      float4 vb = b ? reinterpret_cast<const float4*>(b)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (fabsf(va.x) < tau || fabsf(vb.x) < tau) hit(4 * q + 0);
+      if (fabsf(va.y) < tau || fabsf(vb.y) < tau) hit(4 * q + 1);
+      if (fabsf(va.z) < tau || fabsf(vb.z) < tau) hit(4 * q + 2);
+      if (fabsf(va.w) < tau || fabsf(vb.w) < tau) hit(4 * q + 3);
+    }
+  } else {
+    for (long long i = t0; i < n; i += stride)
+      if ((a && fabsf(a[i]) < tau) || (b && fabsf(b[i]) < tau)) hit(i);
+  }
+}
+
+__global__ void bbox_reinit_keep_flags_kernel(int* bbox) {   // words 7 / 15 (the fp16 range report) survive
+  const int i = threadIdx.x;
+  if (i < 16 && (i & 7) != 7) {
+    const int j = i & 7;
+    bbox[i] = j < 3 ? 0x7fffffff : (j < 6 ? -1 : 0);
+  }
+}
+
 }  // namespace asdf
 
 using namespace asdf;
@@ -129,7 +164,16 @@ struct asdf_decoder {
   float s2[ASDF_MAX_HEADS];
   int math;
   bool sample_bound;
+  int* status;      // [4] device words: [0] = lanes whose activations left the fp16 range in split-half launches since the last
+                    // clear, [1] = near-level voxels that did not fit the refinement list
+  // near-level refinement of split-half sweeps (asdf_decoder_set_refine)
+  void* ev_start;   // one-shot hipEvent_t pair recorded around the dominant kernel of the next sweep (asdf_decoder_time_next_sweep)
+  void* ev_stop;
+  float refine_tau;
+  int* near_idx;    // [kNearCap] lattice indices
+  int* near_count;  // device word
 };
+static constexpr int kNearCap = 1 << 16;
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
 static bool spec_supported(const asdf_decoder_spec_t* s) {
@@ -147,7 +191,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 109; }
+int asdf_version(void) { return 112; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -180,6 +224,9 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
   float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16};
   for (float* b : bufs) (void)hipFree(b);
+  (void)hipFree(d->status);
+  (void)hipFree(d->near_idx);
+  (void)hipFree(d->near_count);
   delete d;
 }
 
@@ -229,6 +276,11 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   }
   if (e == hipSuccess) e = k1_prepare();
   if (e == hipSuccess) e = k1_cls_prepare();
+  if (e == hipSuccess) e = hipMalloc((void**)&d->status, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(d->status, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kNearCap * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->near_count, sizeof(int));
+  d->refine_tau = 4e-6f;
 
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -299,6 +351,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (!d->sample_bound) return ASDF_EINVAL;
   p.stream = d->stream;
   p.cst = d->cst;
+  p.status = d->status;
   // a SeparateDecoder head whose output pointer is NULL is not evaluated at all (the reference always runs both,
   // networks/model.py:304-344, and discards one when HandBranch / ObjectBranch is off)
   p.first_mlp = 0;
@@ -328,14 +381,44 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
     ASDF_HIP(hipGetLastError());
     return ASDF_OK;
   }
-  // split-half arithmetic: grid sweeps only - they carry the fp16 range report in the bbox record (word 7 / 15) that the
-  // caller reads back anyway; explicit point lists (no record to report through) stay on the fp32 chain
+  // split-half arithmetic: grid sweeps only; the fp16 range report goes to the decoder's status word (asdf_decoder_status)
+  // and, when the caller passed one, to word 7 / 15 of the bbox record it reads back anyway.  Explicit point lists (the
+  // label pass, a few 10^4 points) stay on the fp32 chain
   if (d->math == ASDF_MATH_F16X3 && d->stream16 && p.mode != kPointList) {
     p.stream = d->stream16;
     p.cst = d->cst16;
+    if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
     k1h_launch(d->kp, two_out, p, grid, st);
+    if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
+    d->ev_start = d->ev_stop = nullptr;
+    if (d->refine_tau > 0.0f && p.P <= 0x7fffffffLL) {
+      // Near-level refinement: the split-half result and the exact fp32 FMA chain differ by a few 1e-7, so the SIGN of a
+      // voxel within that distance of the iso level - all that marching cubes and the negative-voxel box look at - could
+      // depend on the arithmetic.  Every voxel with |sdf| < tau (a few hundred of 16.7 M at N = 256) is re-evaluated on
+      // the fp32 MFMA chain (the same kernel as ASDF_MATH_F32, coordinates from the same device function) and written
+      // back in place: surfaces and boxes are those of the fp32 chain.
+      ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
+      const long long n4 = (p.P + 3) / 4;
+      const int cgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+      hipLaunchKernelGGL(collect_near_level_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, p.P, d->refine_tau, d->near_idx,
+                         d->near_count, kNearCap, d->status);
+      DecodeParams q = p;
+      q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr;
+      q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
+      const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
+      k1_launch(d->kp, two_out, q, rgrid, st);
+      if (p.bbox) {      // the fused box saw the unrefined values: recount on the volumes (the range report words stay)
+        hipLaunchKernelGGL(bbox_reinit_keep_flags_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+        const int bgrid = (int)((p.P + 255) / 256 < 2048 ? (p.P + 255) / 256 : 2048);
+        if (p.sdf0) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf0, p.P, p.N, p.N, p.bbox);
+        if (p.sdf1) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf1, p.P, p.N, p.N, p.bbox + 8);
+      }
+    }
   } else {
+    if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
     k1_launch(d->kp, two_out, p, grid, st);
+    if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
+    d->ev_start = d->ev_stop = nullptr;
   }
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
@@ -370,6 +453,52 @@ int asdf_decoder_set_math(asdf_decoder_t* d, int32_t math) {
 }
 
 int asdf_decoder_get_math(const asdf_decoder_t* d) { return d ? d->math : ASDF_EINVAL; }
+
+int asdf_decoder_time_next_sweep(asdf_decoder_t* d, void* event_start, void* event_stop) {
+  if (!d || (!event_start) != (!event_stop)) return ASDF_EINVAL;
+  d->ev_start = event_start;
+  d->ev_stop = event_stop;
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_refine(asdf_decoder_t* d, float tau) {
+  if (!d || !(tau >= 0.0f) || tau > 1.0f) return ASDF_EINVAL;
+  d->refine_tau = tau;
+  return ASDF_OK;
+}
+
+int asdf_decoder_status(asdf_decoder_t* d, int32_t out_host[4], int32_t clear, void* stream) {
+  if (!d || !out_host) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  ASDF_HIP(hipMemcpyAsync(out_host, d->status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (clear) ASDF_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), st));
+  ASDF_HIP(hipStreamSynchronize(st));
+  return ASDF_OK;
+}
+
+// Debug hook: the coordinates grid_point() produces, so that the in-kernel lattice can be compared bit for bit with the
+// reference's (utils/mesh.py:27-40) - the decoder kernels call the very same device function.
+namespace asdf {
+__global__ void grid_coords_kernel(float* out, long long first, long long count, int N, int mode, float vs, float o0, float o1, float o2) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  float c0, c1, c2;
+  grid_point(first + k, N, mode, vs, o0, o1, o2, c0, c1, c2);
+  out[k * 3 + 0] = c0; out[k * 3 + 1] = c1; out[k * 3 + 2] = c2;
+}
+}  // namespace asdf
+
+int asdf_debug_grid_coords(int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, int64_t first, int64_t count,
+                           float* coords_dev, void* stream) {
+  if (!origin || !coords_dev || N < 2 || N > 1024 || first < 0 || count < 0 || first + count > (int64_t)N * N * N) return ASDF_EINVAL;
+  if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
+  if (count == 0) return ASDF_OK;
+  hipLaunchKernelGGL(grid_coords_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coords_dev,
+                     (long long)first, (long long)count, N, grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger,
+                     voxel_size, origin[0], origin[1], origin[2]);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
+}
 
 int asdf_decoder_set_classifier(asdf_decoder_t* d, const float* w_host, const float* b_host, int32_t num_class) {
   if (!d || !w_host || !b_host || num_class < 1 || num_class > kMaxClasses) return ASDF_EINVAL;

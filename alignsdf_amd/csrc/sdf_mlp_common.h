@@ -46,6 +46,7 @@ enum GridMode : int {
   kGridReference = 0,   // true-division ("sheared") indices of utils/mesh.py:33-34
   kGridInteger = 1,     // integer floor-division indices (what the code presumably intended)
   kPointList = 2,       // explicit xyz list
+  kGridSubset = 3,      // listed lattice points of a grid (idx / count_dev / grid_mode): coordinates as the sweep, outputs in place
 };
 
 struct DecodeParams {
@@ -55,6 +56,10 @@ struct DecodeParams {
   float* sdf1;              // [P] object SDF (may be null)
   const float* xyz;         // [P][3] when mode == kPointList
   int* bbox;                // [kHeads][8]: min0,min1,min2,max0,max1,max2,count,pad (or null)
+  const int* idx;           // kGridSubset: [<= P] linear lattice indices
+  const int* count_dev;     // kGridSubset: number of listed points (device word; P is the capacity)
+  int grid_mode;            // kGridSubset: kGridReference / kGridInteger of the lattice
+  int* status;              // decoder-owned status record: [0] += lanes whose activations left the fp16 range (K1h only)
   long long P;              // number of query points
   int N;                    // grid resolution (P == N^3 for grid modes)
   int mode;

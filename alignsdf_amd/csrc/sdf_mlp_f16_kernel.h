@@ -42,6 +42,21 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #ifndef ASDF16_BARRIER_KB
 #define ASDF16_BARRIER_KB (ASDF16_STAGE_KB / 2)      // K-block in front of which the stage's wait + barrier sit
 #endif
+#ifndef ASDF16_MFMA_ORDER
+#define ASDF16_MFMA_ORDER 0      // order of the three MFMAs of a K-block (an energy experiment: see the tuning log)
+#endif
+#ifndef ASDF16_LOADS_FIRST
+#define ASDF16_LOADS_FIRST 1     // a scheduling fence BEHIND the LDS reads of a K-block: they issue ahead of its MFMAs (the
+#endif                           // compiler otherwise sinks them to one MFMA in front of their first use)
+#ifndef ASDF16_PRELOAD
+#define ASDF16_PRELOAD 1         // biases / point fragments / w4 of the NEXT tile are read half a tile ahead
+#endif
+#ifndef ASDF16_PIN_ACC
+#define ASDF16_PIN_ACC 1         // deferred epilogues read the finished accumulator part by part (no up-front copy)
+#endif
+#ifndef ASDF16_PRE_KB
+#define ASDF16_PRE_KB (ASDF16_STAGE_KB / 2 + 2)      // K-block of a tile's last stage whose region carries the next tile's preloads
+#endif
 
 // The split-half stream of a head is a flat sequence of (tile, K-block) records of 2 KiB ([plane hi / lo][lane][8 halves]),
 // 1024 of them; a stage is ASDF16_STAGE_KB consecutive records of one tile, so the stage size is the kernel's choice.
@@ -81,9 +96,26 @@ __device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0
 
 // a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
 constexpr int kEpiChunks = 8;
-struct NoEpilogue16 {
+// ... starting at this K-block: the accumulator the epilogue reads was finished by the MFMA right in front of the stage,
+// and an AGPR read within ~3 MFMAs of it waits for the matrix pipe (s_nop + dependency stall)
+#ifndef ASDF16_EPI_SHIFT
+#define ASDF16_EPI_SHIFT (ASDF16_STAGE_KB > 8 ? 1 : 0)
+#endif
+constexpr int kEpiShift = ASDF16_EPI_SHIFT;
+static_assert(kEpiShift + kEpiChunks <= ASDF16_STAGE_KB, "epilogue slots");
+struct NoOp16 {
   __device__ __forceinline__ void operator()(int) const {}
 };
+typedef NoOp16 NoEpilogue16;
+
+// make the compiler treat an accumulator as freshly defined here: element reads behind this statement cannot be hoisted
+// in front of it (instruction selection otherwise copies a whole finished accumulator out of the AGPRs right behind its
+// last MFMA - an s_nop 11 plus the wait for that MFMA at every tile boundary)
+__device__ __forceinline__ void pin_acc(f32x16& acc) {
+#if ASDF16_PIN_ACC
+  asm volatile("" : "+a"(acc));
+#endif
+}
 
 // One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
 // (Writing M0 once per four pieces instead of save / set / restore around each: -0.5 %, not worth relying on M0 surviving
@@ -95,12 +127,18 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 
 // One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
-// stage in stream order.  ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
+// stage in stream order.  Every K-block is one scheduling region
+//     [A-fragment reads of K-block kb + PREFETCH, pre(kb)]  fence  [3 MFMAs (+ DMA pieces), epi(kb)]  fence
+// pre(kb) carries LDS reads whose results are wanted a K-block (or half a tile) later, epi(kb) the VALU work of the
+// deferred epilogue.  The fence behind the reads is what keeps them AHEAD of the K-block's MFMAs: left to itself the
+// scheduler sinks every LDS read to one MFMA (32 cycles) in front of its first use and the wave then sits in
+// s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
+// ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, class Epi>
+template <int KB, int Q, int SLOT, int ABL, class Pre, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
-                                        h8 (&ah)[ASDF16_PREFETCH], h8 (&al)[ASDF16_PREFETCH], Epi&& epi) {
+                                        h8 (&ah)[ASDF16_PREFETCH], h8 (&al)[ASDF16_PREFETCH], Pre&& pre, Epi&& epi) {
   constexpr int PF = ASDF16_PREFETCH;
   constexpr int BKB = ASDF16_BARRIER_KB;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
@@ -121,11 +159,23 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
     }
     bufh[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 0) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 0) * 64];
     bufl[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 1) * 64];
+    pre(kb);
+#if ASDF16_LOADS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     constexpr int base = Q * kS16Kb;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+#if ASDF16_MFMA_ORDER == 0
       // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
       acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
+#elif ASDF16_MFMA_ORDER == 1
+      // W_hi . x_lo, W_hi . x_hi, W_lo . x_hi - consecutive MFMAs share an operand
+      acc = ASDF_MFMA16(j == 2 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
+#else
+      // W_lo . x_hi, W_hi . x_hi, W_hi . x_lo
+      acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
+#endif
       const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
       if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < kS16Pieces) {
         if (m == 0) dma_piece<0>(src, dst);
@@ -142,9 +192,9 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
-    if (kb < kEpiChunks) epi(kb);
-    // keep the A-fragment reads of later K-blocks behind this one's MFMAs (hoisted, 16 K-blocks of fragments do not fit)
-    if (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1) __builtin_amdgcn_sched_barrier(0);
+    epi(kb);
+    // K-block = scheduling region (hoisted, 16 K-blocks of A fragments do not fit the register file either)
+    if (ASDF16_LOADS_FIRST || (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1)) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; al[i] = bufl[kS16Kb + i]; }
@@ -232,52 +282,101 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         return sbase + (size_t)(s < kS16Head ? s : s - kS16Head) * kS16Floats;
       };
 
+      // LDS reads that feed a tile are issued half a tile (or one K-block) ahead of their first use - `pre` slots of
+      // stage16 - into registers that are dead at that point: the OTHER accumulator of the double buffer takes the next
+      // tile's bias row, `pf2` its point-feature fragments, `w4n` the last-layer weights of the next epilogue part.
+      f32x16 acc1[2], acc2[2], acc3[2];
+      float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
+      float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
+      auto load_pf2 = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < KP; ++s) pf2[s] = hc[CL::kA2 + (t * KP + s) * 64 + lane];
+      };
+      auto load_w4 = [&](int t, int c) {        // accumulator registers 2 c, 2 c + 1 of tile t
+        const float* w4 = hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
+        const float* w4b = hc + CL::kW4b + (t * 2 + half) * 16 + 2 * c;
+        w4n[0] = w4[0]; w4n[1] = w4[1];
+        if (TWO_OUT) { w4bn[0] = w4b[0]; w4bn[1] = w4b[1]; }
+      };
+      auto next_w4 = [&]() {
+        w4c[0] = w4n[0]; w4c[1] = w4n[1];
+        if (TWO_OUT) { w4bc[0] = w4bn[0]; w4bc[1] = w4bn[1]; }
+      };
+
       // ---- layer 0 (fp32 MFMA, K = 4 point features): planes of relu(.) * S_x
       h8 h0h[2 * kTilesHidden], h0l[2 * kTilesHidden];
-      auto l0_tile = [&](int t) {
-        f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+      f32x16 acc0[2];
+      float pf0[2][KP];
+      auto l0_load = [&](int t) {
+        acc0[t & 1] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
+        for (int s = 0; s < KP; ++s) pf0[t & 1][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
+      };
+      auto l0_compute = [&](int t) {
+        f32x16 acc = acc0[t & 1];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(pf0[t & 1][s], bp[s], acc);
         split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
       };
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
       // the others ride in the epilogue slots of that stage, under its fp16 MFMAs.
       constexpr int kL0Front = kS16Kb / 2 < kEpiChunks ? kTilesHidden : kS16Kb / 2;
+      l0_load(0);
+      acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
 #pragma unroll
-      for (int t = 0; t < kL0Front; ++t) l0_tile(t);
+      for (int t = 0; t < kL0Front; ++t) {
+        if (ASDF16_PRELOAD && t + 1 < kTilesHidden) { l0_load(t + 1); __builtin_amdgcn_sched_barrier(0); }
+        l0_compute(t);
+        if (!ASDF16_PRELOAD && t + 1 < kTilesHidden) l0_load(t + 1);
+        if (ASDF16_PRELOAD) __builtin_amdgcn_sched_barrier(0);
+      }
 
-#define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, EPI) \
-  stage16<KB, Q, SLOT, ABL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, EPI)
+#define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
+  stage16<KB, Q, SLOT, ABL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
       h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesL1; ++t) { h1h[t] = h0h[t]; h1l[t] = h0l[t]; }
-      f32x16 acc1[2];
 #pragma unroll
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
-        acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
-        auto epi = [&](int c) {
+        if (!ASDF16_PRELOAD && t > 0) acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
+        auto pre = [&](int kb) {       // first stage: the layer-0 tile of the NEXT K-block's epilogue slot
+          const int c = kb - kEpiShift;
+          if (t == 0 && ASDF16_PRELOAD && kL0Front < kTilesHidden && c >= 0 && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
+        };
+        auto epi = [&](int kb) {
+          const int c = kb - kEpiShift;
+          if (c < 0 || c >= kEpiChunks) return;
           if (t == 0) {
-            if (kL0Front < kTilesHidden) l0_tile(kL0Front + c);      // layer-0 tiles 8 .. 15: consumed by the next stage
+            if (kL0Front < kTilesHidden) {       // layer-0 tiles 8 .. 15: consumed by the next stage
+              l0_compute(kL0Front + c);
+              if (!ASDF16_PRELOAD && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
+            }
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
+          pin_acc(acc1[(t - 1) & 1]);
           split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax, c);
         };
+        auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
+          if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
+          if (t + 1 < kTilesL1) acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16);
+          else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); load_pf2(0); }
+        };
 #if ASDF16_STAGE_KB == 8
-        ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, epi);
-        ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoEpilogue16());
-        ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoEpilogue16());
-        ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, NoEpilogue16());
+        ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, pre, epi);
+        ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 4 + 1, NoOp16(), NoOp16());
+        ASDF_STAGE16(32, 2, 2, acc, h0h, h0l, t * 4 + 2, NoOp16(), NoOp16());
+        ASDF_STAGE16(32, 3, 3, acc, h0h, h0l, t * 4 + 3, pre_last, NoOp16());
 #else
         if (t & 1) {
-          ASDF_STAGE16(32, 0, 2, acc, h0h, h0l, t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 3, acc, h0h, h0l, t * 2 + 1, NoEpilogue16());
+          ASDF_STAGE16(32, 0, 2, acc, h0h, h0l, t * 2 + 0, pre, epi);
+          ASDF_STAGE16(32, 1, 3, acc, h0h, h0l, t * 2 + 1, pre_last, NoOp16());
         } else {
-          ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 2 + 1, NoEpilogue16());
+          ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 2 + 0, pre, epi);
+          ASDF_STAGE16(32, 1, 1, acc, h0h, h0l, t * 2 + 1, pre_last, NoOp16());
         }
 #endif
       }
@@ -285,26 +384,37 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
-      f32x16 acc2[2];
       // one tile of layer 2; SLOT is the ring slot of its first stage (a tag type: the slot must be a compile-time constant)
       auto l2_tile = [&](int t, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
-        acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
+        if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
-        auto epi = [&](int c) {
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(pf2[s], bp[s], acc);
+        auto epi = [&](int kb) {
+          const int c = kb - kEpiShift;
+          if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
-          if (t > 0) split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax, c);
-          else split_part(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                          h1l[2 * kTilesL1 - 1], amax, c);       // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
+          if (t > 0) {
+            pin_acc(acc2[(t - 1) & 1]);
+            split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax, c);
+          } else {
+            pin_acc(acc1[(kTilesL1 - 1) & 1]);
+            split_part(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
+                       h1l[2 * kTilesL1 - 1], amax, c);       // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
+          }
+        };
+        auto pre_last = [&](int c) {
+          if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
+          if (t + 1 < kTilesHidden) { acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16); load_pf2(t + 1); }
+          else acc3[0] = load_bias16(hc + CL::kB3 + half * 16);
         };
         constexpr int S0 = 256 / kS16Kb;         // stages of layer 1
 #if ASDF16_STAGE_KB == 8
-        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t * 2 + 0, epi);
-        ASDF_STAGE16(16, 1, SLOT + 1, acc, h1h, h1l, S0 + t * 2 + 1, NoEpilogue16());
+        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t * 2 + 0, NoOp16(), epi);
+        ASDF_STAGE16(16, 1, SLOT + 1, acc, h1h, h1l, S0 + t * 2 + 1, pre_last, NoOp16());
 #else
-        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t, epi);      // one stage per tile
+        ASDF_STAGE16(16, 0, SLOT, acc, h1h, h1l, S0 + t, pre_last, epi);      // one stage per tile
 #endif
       };
 #pragma unroll
@@ -324,50 +434,67 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
       float part = 0.0f, partb = 0.0f;
-      f32x16 acc3[2];
-      // accumulator registers 2 c, 2 c + 1 of tile t into the last-layer dot product(s)
-      auto dot_w4_part = [&](const f32x16 a, int t, int c) {
-        const float* w4 = hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
-        const float* w4b = hc + CL::kW4b + (t * 2 + half) * 16 + 2 * c;
+      // accumulator registers 2 c, 2 c + 1 of a finished tile into the last-layer dot product(s), weights from (w4c, w4bc)
+      auto dot_w4_part = [&](const f32x16& a, int c) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
-          part = fmaf(v, w4[r], part);
-          if (TWO_OUT) partb = fmaf(v, w4b[r], partb);
+          part = fmaf(v, w4c[r], part);
+          if (TWO_OUT) partb = fmaf(v, w4bc[r], partb);
         }
         if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
-      };
-      auto dot_w4 = [&](const f32x16 a, int t) {
-#pragma unroll
-        for (int c = 0; c < kEpiChunks; ++c) dot_w4_part(a, t, c);
       };
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
-        acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
-        auto epi = [&](int c) {
+        if (!ASDF16_PRELOAD) acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
+        auto pre = [&](int kb) {       // first stage: w4 of the next epilogue part
+          const int c = kb - kEpiShift;
+          if (t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
+        };
+        auto epi = [&](int kb) {
+          const int c = kb - kEpiShift;
+          if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
-          if (t > 0) dot_w4_part(acc3[(t - 1) & 1], t - 1, c);
-          else split_part(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
-                          h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax, c);  // K-blocks 30, 31: end of this tile
+          if (t > 0) {
+            pin_acc(acc3[(t - 1) & 1]);
+            dot_w4_part(acc3[(t - 1) & 1], c);
+            next_w4();
+          } else {
+            pin_acc(acc2[(kTilesHidden - 1) & 1]);
+            split_part(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
+                       h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax, c);  // K-blocks 30, 31: end of this tile
+          }
+        };
+        auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
+          if (c != ASDF16_PRE_KB) return;
+          if (ASDF16_PRELOAD && t + 1 < kTilesHidden) acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
+          load_w4(t, 0);
+          next_w4();
         };
         constexpr int S0 = 512 / kS16Kb;         // stages of layers 1 and 2
 #if ASDF16_STAGE_KB == 8
-        ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, epi);
-        ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoEpilogue16());
-        ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoEpilogue16());
-        ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, NoEpilogue16());
+        ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 4 + 0, pre, epi);
+        ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 4 + 1, NoOp16(), NoOp16());
+        ASDF_STAGE16(32, 2, 2, acc, h2h, h2l, S0 + t * 4 + 2, NoOp16(), NoOp16());
+        ASDF_STAGE16(32, 3, 3, acc, h2h, h2l, S0 + t * 4 + 3, pre_last, NoOp16());
 #else
         if (t & 1) {
-          ASDF_STAGE16(32, 0, 2, acc, h2h, h2l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 3, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue16());
+          ASDF_STAGE16(32, 0, 2, acc, h2h, h2l, S0 + t * 2 + 0, pre, epi);
+          ASDF_STAGE16(32, 1, 3, acc, h2h, h2l, S0 + t * 2 + 1, pre_last, NoOp16());
         } else {
-          ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 2 + 0, epi);
-          ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 2 + 1, NoEpilogue16());
+          ASDF_STAGE16(32, 0, 0, acc, h2h, h2l, S0 + t * 2 + 0, pre, epi);
+          ASDF_STAGE16(32, 1, 1, acc, h2h, h2l, S0 + t * 2 + 1, pre_last, NoOp16());
         }
 #endif
       }
-      dot_w4(acc3[(kTilesHidden - 1) & 1], kTilesHidden - 1);
+      // the last tile's epilogue has no MFMA stream to hide under
+#pragma unroll
+      for (int c = 0; c < kEpiChunks; ++c) {
+        if (c + 1 < kEpiChunks) load_w4(kTilesHidden - 1, c + 1);
+        dot_w4_part(acc3[(kTilesHidden - 1) & 1], c);
+        next_w4();
+      }
 #undef ASDF_STAGE16
       part += __shfl_xor(part, 32);
       const float sdf = tanhf(part + hc[CL::kB4]);
@@ -382,10 +509,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         if (out) out[pi] = sdf;
         if (TWO_OUT && p.sdf1) p.sdf1[pi] = sdfb;
       }
+      // every lane reports its own activations (the two halves of a wave hold different features of the same point):
+      // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
+      // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
+      // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
+      const int bad = (valid && (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
       if (p.bbox && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
-        // every lane reports its own activations (the two halves of a wave hold different features of the same point)
-        int bad = (valid && (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
         auto fold = [&](bool neg, int* rec, int extra) {
           int a0 = neg ? i0 : 0x7fffffff, a1 = neg ? i1 : 0x7fffffff, a2 = neg ? i2 : 0x7fffffff;
           int b0 = neg ? i0 : -1, b1 = neg ? i1 : -1, b2 = neg ? i2 : -1, n = neg ? 1 : 0;
@@ -404,10 +534,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         };
         fold(valid && half == 0 && sdf < 0.0f, wrec, bad);
         if (TWO_OUT) fold(valid && half == 0 && sdfb < 0.0f, wrec + 8, 0);
+      } else {
+        const unsigned long long m = __ballot(bad);
+        if (m && lane == 0) wrec[7] += __popcll(m);
       }
     }   // tiles
 
-    if (p.bbox && lane == 0) {
+    if (lane == 0) {
       // one set of atomics per wave: record 0 = hand (MLP 0 / first row), record 1 = object (MLP 1 / second row);
       // word 7: lanes out of range (0 unless the fp16 planes overflowed; the host then falls back to fp32)
       auto flush = [&](int* out, const int* rec) {
@@ -417,9 +550,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           atomicAdd(out + 6, rec[6]);
         }
       };
-      flush(p.bbox + (head == 0 ? 0 : 8), wrec);
-      if (TWO_OUT) flush(p.bbox + 8, wrec + 8);
-      if (wrec[7]) atomicAdd(p.bbox + (head == 0 ? 7 : 15), wrec[7]);
+      if (p.bbox && p.mode != kPointList) {
+        flush(p.bbox + (head == 0 ? 0 : 8), wrec);
+        if (TWO_OUT) flush(p.bbox + 8, wrec + 8);
+        if (wrec[7]) atomicAdd(p.bbox + (head == 0 ? 7 : 15), wrec[7]);
+      }
+      if (wrec[7] && p.status) atomicAdd(p.status, wrec[7]);
     }
   }   // MLPs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -96,7 +96,10 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
 
-  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  // kGridSubset: the point count lives on the device (the list was compacted by a kernel just in front of this launch)
+  long long npts = p.P;
+  if (p.mode == kGridSubset) { const long long c = *p.count_dev; npts = c < npts ? c : npts; }
+  const long long ntiles = (npts + kWgPts - 1) / kWgPts;
   if ((long long)blockIdx.x >= ntiles) return;
 
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
@@ -139,10 +142,15 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
-      const bool valid = pi < p.P;
+      const bool valid = pi < npts;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+      long long po = pi;                        // where this point's outputs go
       if (p.mode == kPointList) {
         if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
+      } else if (p.mode == kGridSubset) {
+        // listed lattice points: the same coordinate function as the sweep, outputs scattered back into the volumes
+        po = valid ? (long long)p.idx[pi] : 0;
+        grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       } else {
         grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       }
@@ -292,8 +300,8 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       const bool is_hand = head == 0;
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
-        if (out) out[pi] = sdf;
-        if (combined && p.sdf1) p.sdf1[pi] = sdfb;
+        if (out) out[po] = sdf;
+        if (combined && p.sdf1) p.sdf1[po] = sdfb;
       }
       if (CLS) {
         int best = 0;
@@ -315,7 +323,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         }
       }
       if (p.bbox && valid && half == 0 && p.mode != kPointList) {
-        const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
+        const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
         if (sdf < 0.0f) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
           bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;

@@ -20,6 +20,8 @@ def create_mesh(decoder, latent_vec, filename, N=256, max_batch=32 ** 3, grid_mo
     mode = {"reference": _native.GRID_REFERENCE, "integer": _native.GRID_INTEGER}[grid_mode]
     voxel_origin = [-1, -1, -1]
     voxel_size = 2.0 / (N - 1)
+    # no bbox buffer on this path: decode_grid reads the decoder's fp16 range status behind the sweep and repeats it on the
+    # fp32 kernel if the split-half planes overflowed
     sdf_values, _, _ = hip.decode_grid(N, voxel_origin, voxel_size, mode, want_bbox=False)
     torch.cuda.synchronize(sdf_values.device)
     print("sampling takes: %f" % (time.time() - start))

@@ -164,6 +164,7 @@ class HipSdfDecoder:
         elif want not in ("f32", "f16x3"):
             raise ValueError("ASDF_MATH must be 'f32' or 'f16x3', not %r" % want)
         self._latent = None
+        self.refine_tau = 4e-6
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
 
     def set_math(self, math):
@@ -172,17 +173,36 @@ class HipSdfDecoder:
         _native.check(self._L.asdf_decoder_set_math(self._h, code), "asdf_decoder_set_math")
         self.math = math
 
+    def set_refine(self, tau):
+        """Near-level refinement of split-half grid sweeps (asdf_decoder_set_refine): voxels with |sdf| < tau are re-evaluated
+        on the fp32 chain so that boxes and surfaces are sign-for-sign those of the fp32 kernel.  Default 4e-6; 0 = off."""
+        _native.check(self._L.asdf_decoder_set_refine(self._h, ctypes.c_float(float(tau))), "asdf_decoder_set_refine")
+        self.refine_tau = float(tau)
+
     def fall_back_if_overflowed(self, bbox_host):
-        """bbox words 7 / 15 count outputs outside [-1, 1]: non-zero only if an activation overflowed the fp16 planes of
-        the split-half arithmetic.  Switches this decoder to the fp32 MFMA chain (for good) and returns True; the caller
-        repeats the pass."""
-        if self.math == "f16x3" and (int(bbox_host[7]) or int(bbox_host[15])):
+        """bbox words 7 / 15 count points whose activations left the fp16 range of the split-half planes; they are non-zero
+        only for a sweep that ran under f16x3 (the fp32 kernel leaves them 0), so the decision rests on the record alone -
+        whatever arithmetic the decoder has been switched to since that sweep was queued.  Switches the decoder to the fp32
+        MFMA chain (for good) and returns True; the caller repeats the sweep the record belongs to."""
+        bad = int(bbox_host[7]) + int(bbox_host[15])
+        if not bad:
+            return False
+        self._to_f32(bad)
+        return True
+
+    def _to_f32(self, bad):
+        if self.math != "f32":
             import logging
-            logging.warning("split-half decoder: %d outputs out of range (an activation left the fp16 range); "
-                            "falling back to the fp32 MFMA kernel", int(bbox_host[7]) + int(bbox_host[15]))
+            logging.warning("split-half decoder: %d activations left the fp16 range; falling back to the fp32 MFMA kernel", bad)
             self.set_math("f32")
-            return True
-        return False
+
+    def range_violations(self, clear=True):
+        """Number of (point, lane-half) pairs whose activations left the fp16 range in split-half sweeps of this decoder
+        since the last clear - the decoder-owned status word, independent of any bbox buffer.  Synchronises the stream."""
+        out = (ctypes.c_int32 * 4)()
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decoder_status(self._h, out, 1 if clear else 0, self._stream()), "asdf_decoder_status")
+        return int(out[0])
 
     def close(self):
         if getattr(self, "_h", None):
@@ -229,27 +249,49 @@ class HipSdfDecoder:
             _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
                           "asdf_decoder_set_sample")
 
-    def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True):
+    def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True,
+                    check_range=None):
         """Heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None), all device
-        tensors; a head switched off (`hand` / `obj` False, SeparateDecoder only) is not evaluated and returns None."""
+        tensors; a head switched off (`hand` / `obj` False, SeparateDecoder only) is not evaluated and returns None.
+
+        Under the split-half arithmetic a sweep WITH a bbox reports fp16 range violations in words 7 / 15 of the record
+        (the caller reads it anyway: fall_back_if_overflowed).  A sweep WITHOUT one is guarded here: the decoder's status
+        word is read behind the launch (one stream synchronisation) and, if it is non-zero, the decoder switches to the
+        fp32 kernel and the sweep is repeated.  check_range=False skips that for callers that know the range is safe."""
         if self.combined:
             hand = obj = True
         hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
         obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
         bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
-        with torch.cuda.device(self.device):
-            if self.event_log is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
-                                                   int(grid_mode), hand.data_ptr() if hand is not None else None,
-                                                   obj.data_ptr() if obj is not None else None,
-                                                   bbox.data_ptr() if want_bbox else None, self._stream()),
-                          "asdf_decode_grid")
-            if self.event_log is not None:
-                ev[1].record()
-                self.event_log.append(ev)
+        guard = self.math == "f16x3" and not want_bbox and (check_range is None or check_range)
+
+        def launch():
+            with torch.cuda.device(self.device):
+                if self.event_log is not None:
+                    # the events bracket the decoder kernel itself (asdf_decoder_time_next_sweep), not the bbox / refinement
+                    # kernels around it; a first record() makes torch create the handles
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                    ev[1].record()
+                    _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
+                                                                       ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
+                _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
+                                                       int(grid_mode), hand.data_ptr() if hand is not None else None,
+                                                       obj.data_ptr() if obj is not None else None,
+                                                       bbox.data_ptr() if want_bbox else None, self._stream()),
+                              "asdf_decode_grid")
+                if self.event_log is not None:
+                    self.event_log.append(ev)
+
+        if guard:
+            self.range_violations(clear=True)       # earlier sweeps answer for themselves
+        launch()
+        if guard:
+            bad = self.range_violations(clear=True)
+            if bad:
+                self._to_f32(bad)
+                launch()
         return hand, obj, bbox
 
     def decode_points(self, xyz):

@@ -66,3 +66,26 @@ def marching_cubes_lewiner(volume, level=0.0, spacing=(1.0, 1.0, 1.0)):
     if not np.array_equal(spacing, (1, 1, 1)):
         verts = verts * np.r_[spacing]
     return verts, faces
+
+
+def time_chain(vol_hand, vol_obj, peak_gbs, repeats=5):
+    """HBM roofline record of the marching-cubes kernel chain (classify / scan / emit) on the two volumes of one sample:
+    achieved = algorithmic bytes (4 N^3 read + 12 V + 12 F written per volume) / duration of the chain between
+    two events on the launch stream (best of `repeats`; the V / F read-back between count and emit is inside, as in the
+    product)."""
+    best, nbytes = None, 0
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nbytes = 0
+        for vol in (vol_hand, vol_obj):
+            v, f = marching_cubes_device(vol, 0.0)
+            nbytes += 4 * vol.numel() + 12 * v.shape[0] + 12 * f.shape[0]
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    gbs = nbytes / (best * 1e-3) / 1e9
+    return {"bound": "hbm", "kernels": "mc_classify + mc_scan + mc_emit_verts + mc_emit_faces (both volumes of one sample)",
+            "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, "traffic": None,
+            "chain_ms_both_volumes": best, "algorithmic_bytes": nbytes}

@@ -96,6 +96,7 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
  *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels,
  *   [h*8 + 7] = #points whose hidden activations left the fp16 range of the split-half planes (|x| >= 8188) - always
  *   0 under ASDF_MATH_F32; if non-zero under ASDF_MATH_F16X3 the caller should switch to ASDF_MATH_F32 and repeat.
+ *   With bbox_dev == NULL the same count is available from asdf_decoder_status.
  * Replaces one pass of utils/mesh.py:27-63 (or :82-115) plus the nonzero/min/max of
  * get_higher_res_cube (utils/mesh.py:208-237); deep_sdf/mesh.py:24-54 for the legacy entry point. */
 int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
@@ -128,6 +129,31 @@ int asdf_decode_points(asdf_decoder_t* dec, const float* xyz_dev, int64_t M, flo
 #define ASDF_MATH_F16X3 1
 int asdf_decoder_set_math(asdf_decoder_t* dec, int32_t math);
 int asdf_decoder_get_math(const asdf_decoder_t* dec);
+
+/* Near-level refinement of ASDF_MATH_F16X3 grid sweeps (on by default, tau = 4e-6; 0 switches it off): after the sweep every
+ * voxel with |sdf| < tau in either output is re-evaluated on the fp32 MFMA chain - the arithmetic of ASDF_MATH_F32 - and
+ * written back, and the negative-voxel box is recounted on the refined volumes.  The two arithmetics agree to a few 1e-7
+ * (well inside the 1e-5 bar), but the SIGN of a voxel that close to the level is all that the zoom cube
+ * (utils/mesh.py:208-237) and marching cubes (utils/mesh.py:354) look at: with the refinement, boxes and surfaces are
+ * those of the fp32 chain, voxel for voxel.  Costs one compaction pass over the volumes and one fp32 launch over a few
+ * hundred points (about 0.5 ms per N = 256 sweep).  At most 65536 voxels are refined per sweep; asdf_decoder_status
+ * word [1] counts any beyond that. */
+int asdf_decoder_set_refine(asdf_decoder_t* dec, float tau);
+
+/* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed
+ * as void*, created by the caller with timing enabled) immediately before and after the launch of its dominant kernel
+ * (sdf_mlp_f16_kernel or sdf_mlp_kernel) on the call's stream - not around the small kernels next to it (bbox
+ * initialisation, near-level refinement).  One shot: the pair is forgotten after that call.  bench.py times the kernel the
+ * roofline record is about this way, inside the timed region. */
+int asdf_decoder_time_next_sweep(asdf_decoder_t* dec, void* event_start, void* event_stop);
+
+/* Range report of the split-half arithmetic that does NOT depend on a bbox buffer: every ASDF_MATH_F16X3 launch of this
+ * decoder adds the number of (point, lane-half) pairs whose hidden activations left the fp16 range (or whose output is not
+ * in [-1, 1]) to a device word the decoder owns.  Copies the record to out_host[4] ([0] = that count, [1] = near-level
+ * voxels beyond the refinement list's capacity, [2..3] reserved),
+ * optionally clears it, and synchronises `stream`.  A caller that sweeps without a bbox buffer (deep_sdf/mesh.py:14-61
+ * has no zoom pass) checks this once per volume and repeats the sweep under ASDF_MATH_F32 when the count is non-zero. */
+int asdf_decoder_status(asdf_decoder_t* dec, int32_t out_host[4], int32_t clear, void* stream);
 
 /* ---- Part classifier (specs["ClassifierBranch"]): classifier_head = nn.Linear(512, num_class) applied to the last
  * hidden activation of the hand MLP (SeparateDecoder, networks/model.py:257-259,306-307) or of the single MLP
@@ -197,6 +223,12 @@ int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream);
  * the metric is their sum.  Workspace: asdf_icp_workspace_bytes(na, nb).  Synchronises the stream. */
 int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t nb, void* workspace_dev,
                  size_t workspace_bytes, double* result, void* stream);
+
+/* ---- Test hook (device): coordinates of lattice points first .. first + count - 1 exactly as the decoder kernels
+ * generate them in registers (the same device function), coords_dev [count][3] fp32 in (axis 0, axis 1, axis 2) order.
+ * Lets the tests compare the in-kernel lattice with utils/mesh.py:27-40,82-96 bit for bit. */
+int asdf_debug_grid_coords(int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, int64_t first, int64_t count,
+                           float* coords_dev, void* stream);
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,

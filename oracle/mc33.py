@@ -19,8 +19,7 @@ _lib = None
 
 
 def build(force=False):
-    deps = [_SRC, os.path.join(_HERE, "..", "alignsdf_amd", "csrc", "mc33_common.h"),
-            os.path.join(_HERE, "..", "alignsdf_amd", "csrc", "mc33_tables.h")]
+    deps = [_SRC, os.path.join(_HERE, "mc33_oracle_tables.h")]      # nothing of the product's is compiled into the oracle
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-std=c99", _SRC, "-o", _LIB, "-lm"], check=True)

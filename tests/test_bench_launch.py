@@ -1,0 +1,49 @@
+"""bench.py --gpus N without an external launcher: the script spawns N ranks itself and reports as `n_gpus` the value of an
+all_reduce of ones over the process group (`--gpus` used to be parsed and ignored)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_rank_environments():
+    sys.path.insert(0, ROOT)
+    import bench
+    envs = bench.rank_environments(3, base_env={"FOO": "1"}, port=12345)
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "12345" and e["FOO"] == "1" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_gpus_flag_spawns_that_many_ranks_cpu(n):
+    """Dry run (gloo, no GPU work): `--gpus n` alone must produce n ranks that see each other."""
+    line = _run(["--gpus", str(n)], {"ASDF_BENCH_DRYRUN": "1"})
+    assert line["n_gpus"] == n and line["ranks_requested"] == n and line["world_size_env"] == n
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_one_device():
+    """The real bench with two ranks sharing the box's single GPU (gloo for the record gather): n_gpus == 2, twice the
+    samples of one rank."""
+    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "64", "--no-cpu-baseline"],
+                {"ASDF_BENCH_BACKEND": "gloo", "ASDF_BENCH_SHARE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["config"]["world_size_env"] == 2
+    assert line["config"]["samples_per_gpu"] == 2 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"]

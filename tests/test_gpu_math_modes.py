@@ -19,7 +19,7 @@ def _decoder(tag):
     hip = hip_decoder_for(dec)
     lat = torch.from_numpy(syn.latent_code(0)).cuda()
     mano = obj = None
-    if specs["PointFeatSize"] == 9 and specs["EncodeStyle"] != "nerf":
+    if specs["EncodeStyle"] != "nerf":
         m, o = syn.pose_inputs(0)
         mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()}
         obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
@@ -31,7 +31,7 @@ def test_default_is_split_half():
     assert _decoder("nerf3").math == "f16x3"
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9", "nerf15", "hand6", "hand51", "obj6"])
 def test_both_modes_match_reference_points_and_grids(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     hip = _decoder(tag)
@@ -186,3 +186,86 @@ def test_modes_agree_over_the_sample_set(tag):
         assert abs(int(a[6]) - int(b[6])) + abs(int(a[14]) - int(b[14])) <= near
         box_mismatch += int(not np.array_equal(a[[0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13]], b[[0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13]]))
     assert worst <= 4e-6 and box_mismatch == 0, (worst, box_mismatch)      # two independent fp32-class roundings
+
+
+def _overflowing_decoder(factor=4096.0):
+    """The nerf3 network with layer 0 blown up by `factor` and layer 1 shrunk by it: the same function (ReLU is positively
+    homogeneous), hidden activations of order 1e4 - beyond what the split-half planes carry at the default scale."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from oracle import sdf_oracle as orc
+    base = syn.full_state_dict("nerf3")
+    sd = {}
+    for head in "ho":
+        for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
+            sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
+        sd["lin%s0.weight" % head] *= np.float32(factor)
+        sd["lin%s0.bias" % head] *= np.float32(factor)
+        sd["lin%s1.weight" % head] /= np.float32(factor)
+    return HipSdfDecoder(sd, 256, 3, "nerf")
+
+
+def test_range_report_does_not_need_a_bbox(native_lib, golden_dir):
+    """A C-ABI caller that passes bbox_dev = NULL still learns about an fp16 range violation: the decoder-owned status word
+    (asdf_decoder_status) counts it.  The host wrapper's bbox-less sweep reads it and repeats on the fp32 kernel."""
+    import ctypes
+    hip = _overflowing_decoder()
+    hip.set_sample(torch.from_numpy(syn.latent_code(0)).cuda())
+    assert hip.math == "f16x3" and hip.range_violations(clear=True) == 0
+    N = 32
+    vh = torch.empty((N, N, N), device="cuda")
+    vo = torch.empty((N, N, N), device="cuda")
+    org = (ctypes.c_float * 3)(-1.0, -1.0, -1.0)
+    rc = native_lib.asdf_decode_grid(hip._h, N, org, ctypes.c_float(2.0 / (N - 1)), 0, vh.data_ptr(), vo.data_ptr(), None,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    bad = hip.range_violations(clear=False)
+    assert bad > 0 and hip.range_violations(clear=True) == bad and hip.range_violations() == 0     # read, read + clear, cleared
+    assert hip.math == "f16x3"                       # the raw call decides nothing; the caller does
+    # the guarded wrapper: same sweep, no bbox -> falls back and returns the reference's volumes
+    g = np.load(golden_dir + "/ref_decoder_nerf3.npz")
+    h2, o2, none = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1), want_bbox=False)
+    assert none is None and hip.math == "f32"
+    assert np.abs(h2.cpu().numpy() - g["vol1_hand_32"]).max() <= TOL and np.abs(o2.cpu().numpy() - g["vol1_obj_32"]).max() <= TOL
+    hip.close()
+
+
+def test_range_report_is_zero_on_the_shipped_decoders():
+    for tag in ("nerf3", "both9"):
+        hip = _decoder(tag)
+        hip.range_violations(clear=True)
+        hip.decode_grid(48, [-1.0, -1.0, -1.0], 2.0 / 47, want_bbox=False)
+        assert hip.math == "f16x3" and hip.range_violations() == 0
+
+
+def test_legacy_create_mesh_is_guarded(tmp_path, golden_dir, monkeypatch):
+    """deep_sdf.mesh.create_mesh (deep_sdf/mesh.py:14-61) sweeps without a bbox buffer: with a decoder whose activations
+    overflow the fp16 planes it must still return the reference's volume (it used to return garbage silently)."""
+    from alignsdf_amd.deep_sdf import mesh as legacy
+    g = np.load(golden_dir + "/ref_legacy.npz")
+    hip = _overflowing_decoder()
+    seen = {}
+    real = legacy.convert_sdf_samples_to_ply
+
+    def spy(vol, origin, vs, path):
+        seen["vol"] = vol.cpu().numpy().copy()
+        return real(vol, origin, vs, path)
+
+    monkeypatch.setattr(legacy, "convert_sdf_samples_to_ply", spy)
+    pts, faces = legacy.create_mesh(hip, torch.from_numpy(syn.latent_code(0)).cuda(), str(tmp_path / "legacy"), N=32)
+    assert hip.math == "f32"
+    assert np.abs(seen["vol"] - g["vol_32"]).max() <= TOL
+    assert len(pts) > 0 and len(faces) > 0 and (tmp_path / "legacy.ply").exists()
+    hip.close()
+
+
+def test_fallback_decision_rests_on_the_record_alone():
+    """once the decoder has switched to fp32, a bbox record of an EARLIER split-half sweep must still trigger the
+    repeat of that sweep (the pipeline queues pass 1 of sample k+1 before it reads pass 2 of sample k)."""
+    hip = _overflowing_decoder()
+    hip.set_sample(torch.from_numpy(syn.latent_code(0)).cuda())
+    _, _, bbox = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)            # queued under f16x3
+    hip.set_math("f32")                                                        # ... another sweep's report arrives first
+    assert hip.fall_back_if_overflowed(bbox.cpu().numpy()) is True             # the stale record still says: repeat me
+    _, _, clean = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
+    assert hip.fall_back_if_overflowed(clean.cpu().numpy()) is False
+    hip.close()

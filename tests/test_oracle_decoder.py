@@ -12,11 +12,16 @@ def _inputs(tag):
     specs, sd = syn.specs_for(tag), syn.full_state_dict(tag)
     lat = torch.from_numpy(syn.latent_code(0))
     mano = obj = None
-    if tag == "both9":
+    if specs["EncodeStyle"] != "nerf":
         m, o = syn.pose_inputs(0)
         mano = {k: torch.from_numpy(v) for k, v in m.items()}
         obj = {k: torch.from_numpy(v) for k, v in o.items()}
     return specs, sd, lat, mano, obj
+
+
+# round-1 fixtures + the round-2 ones (tests/golden/make_r2_goldens.py): two NeRF octaves, EncodeStyle "hand" with the wrist
+# joint only / all 16 joints (utils/utils.py:399-400), EncodeStyle "obj"
+TAGS = ["nerf3", "both9", "comb3", "nerf9", "nerf15", "hand6", "hand51", "obj6"]
 
 
 def test_grid_columns_bit_exact(golden_dir):
@@ -46,7 +51,7 @@ def test_effective_weights_match_module_hook(tag, golden_dir):
             assert np.array_equal(params[layer][0].numpy()[:4], g["effw_%s%d_rows" % (head, layer)])
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_decoder_and_embedding_vs_reference(tag, golden_dir):
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     specs, sd, lat, mano, obj = _inputs(tag)
@@ -59,7 +64,7 @@ def test_decoder_and_embedding_vs_reference(tag, golden_dir):
     assert np.abs(o.numpy() - g["rand_obj"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "comb3", "nerf9"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_two_pass_flow_vs_reference(tag, golden_dir):
     """Full create_mesh_combined_decoder restatement at N=32: volumes, bbox, zoom cube."""
     g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))

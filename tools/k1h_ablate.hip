@@ -1,38 +1,58 @@
 // Timing-only ablation / schedule sweep for the split-half decoder kernel (results are NOT checked here - parity lives
 // in tests/).  Build (per knob setting):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ialignsdf_amd/csrc [-DASDF16_PREFETCH=2 -DASDF16_BARRIER_KB=5] tools/k1h_ablate.hip -o /tmp/k1h
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -Ialignsdf_amd/csrc [-DASDF16_PREFETCH=2 ...] tools/k1h_ablate.hip -o tools/bin/k1h_x
+// Run:  k1h_x [N] [data]     data = path of a tools/dump_k1h_inputs.py image (the product's real weights + folded
+//                            constants), "zero" (all-zero operands: the DVFS upper bound) or "small" (default: small
+//                            pseudo-random weights that keep every ablation finite)
+// Besides the launch time the tool reports the shader clock the kernel ran at (s_memtime ticks of workgroup 0 / wall).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "sdf_mlp_f16_kernel.h"
 using namespace asdf;
 #ifndef ABL_LIST
 #define ABL_LIST X(0) X(32) X(1) X(16) X(4)
 #endif
-#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { sdf_mlp_f16_body<false, n>(p); }
+__device__ unsigned long long g_ticks[2];
+#define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { \
+    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n>(p); \
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 128;
+  const char* data = argc > 2 ? argv[2] : "small";
   const long long P = (long long)N * N * N;
   float *stream, *cst, *o0, *o1;
   std::vector<uint16_t> h((size_t)kStagesAll * kStageFloats * 2);
-  for (size_t i = 0; i < h.size(); ++i) { _Float16 v = (_Float16)((float)((int)((i * 2654435761u) >> 20) % 2001 - 1000) * 2e-5f); h[i] = *(uint16_t*)&v; }   // small weights: activations stay finite in every ablation
-  hipMalloc(&stream, h.size() * 2); hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   std::vector<float> c(kHeads * kCstFloats);
-  for (size_t i = 0; i < c.size(); ++i) c[i] = (float)((int)((i * 40503u) >> 4) % 201 - 100) * 1e-3f;
-  hipMalloc(&cst, c.size() * 4); hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
-  hipMalloc(&o0, P * 4); hipMalloc(&o1, P * 4);
+  if (!strcmp(data, "small")) {
+    for (size_t i = 0; i < h.size(); ++i) { _Float16 v = (_Float16)((float)((int)((i * 2654435761u) >> 20) % 2001 - 1000) * 2e-5f); h[i] = *(uint16_t*)&v; }
+    for (size_t i = 0; i < c.size(); ++i) c[i] = (float)((int)((i * 40503u) >> 4) % 201 - 100) * 1e-3f;
+  } else if (!strcmp(data, "zero")) {
+    std::fill(h.begin(), h.end(), 0); std::fill(c.begin(), c.end(), 0.0f);
+  } else {
+    FILE* f = fopen(data, "rb");
+    if (!f || fread(h.data(), 2, h.size(), f) != h.size() || fread(c.data(), 4, c.size(), f) != c.size()) { printf("cannot read %s\n", data); return 1; }
+    fclose(f);
+  }
+  (void)hipMalloc(&stream, h.size() * 2); (void)hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMalloc(&cst, c.size() * 4); (void)hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&o0, P * 4); (void)hipMalloc(&o1, P * 4);
+  int* bbox; (void)hipMalloc(&bbox, 64); (void)hipMemset(bbox, 0, 64);
   DecodeParams p{}; p.stream = stream; p.cst = cst; p.sdf0 = o0; p.sdf1 = o1; p.P = P; p.N = N; p.mode = kGridReference;
-  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0;
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0; p.bbox = bbox;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const double flop = (double)P * 2 * 3145728.0;
-  printf("PREFETCH %d  BARRIER_KB %d\n", ASDF16_PREFETCH, ASDF16_BARRIER_KB);
-#define X(n) { hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16); \
-    float best = 1e9; for (int it = 0; it < 4; ++it) { hipEventRecord(e0); hipLaunchKernelGGL(k_abl_##n, dim3(256), dim3(256), kLdsBytesF16, 0, p); \
-      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; } \
-    printf("ABL %2d  N=%d  %.3f ms  %.0f TF/s f16 MFMA (%.1f%% of 2516)  err=%d\n", n, N, best, flop / best / 1e9, flop / best / 1e9 / 25.166, (int)hipGetLastError()); }
+  printf("PREFETCH %d  BARRIER_KB %d  data %s\n", ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
+#define X(n) { (void)hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16); \
+    float best = 1e9; double ghz = 0; for (int it = 0; it < 4; ++it) { (void)hipEventRecord(e0); hipLaunchKernelGGL(k_abl_##n, dim3(256), dim3(256), kLdsBytesF16, 0, p); \
+      (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); \
+      unsigned long long t[2]; (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), 16); \
+      if (ms < best) { best = ms; ghz = (double)(t[1] - t[0]) / (ms * 1e6); } } \
+    printf("ABL %2d  N=%d  %.3f ms  %.0f TF/s f16 MFMA (%.1f%% of 2516)  wg0 ticks/wall = %.3f GHz  err=%d\n", n, N, best, flop / best / 1e9, flop / best / 1e9 / 25.166, ghz, (int)hipGetLastError()); }
   ABL_LIST
 #undef X
   return 0;
