@@ -15,7 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
-RECORD_FIELDS = ("index", "V_hand", "F_hand", "V_obj", "F_obj", "milliseconds")
+RECORD_FIELDS = ("index", "V_hand", "F_hand", "V_obj", "F_obj", "milliseconds", "icp_skipped")
 
 
 def shard_range(num_items, world_size, rank):
@@ -88,7 +88,10 @@ def main(argv=None):
     p.add_argument("--experiment", "-e", dest="experiment_directory", required=True)
     p.add_argument("--task", "-t", dest="task", default="obman", choices=["obman", "dexycb"])
     p.add_argument("--optim", dest="optim", action="store_true")
-    p.add_argument("--codes", dest="code_dir", default=None)
+    p.add_argument("--codes", dest="code_dir", default=None, help="directory of precomputed <sample>.npz codes")
+    p.add_argument("--synthetic", action="store_true", help="deterministic synthetic codes (tests / benchmarks only)")
+    p.add_argument("--allow_missing_gt", action="store_true", help="write unaligned meshes when a ground-truth mesh is missing")
+    p.add_argument("--data_root", default="data")
     p.add_argument("--cube_dim", type=int, default=128)
     p.add_argument("--split", dest="split_filename", default=None, help="default: input/<task>.json like the reference")
     args = p.parse_args(argv)
@@ -96,12 +99,13 @@ def main(argv=None):
     names = json.load(open(split))["filenames"]
     specs, decoder = rc.load_experiment(args.experiment_directory)
     output_dir = os.path.join(args.experiment_directory, "Eval_" + args.task)
-    source = rc.npz_code_source(args.code_dir) if args.code_dir else None
+    source = rc.code_source_from_args(args, specs, p)
 
     def process(start, end, rank):
         print("rank %d: samples %d to %d" % (rank, start, end - 1), flush=True)
         recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
-                              eval_mode=True, label_out=args.optim, code_source=source)
+                              eval_mode=True, label_out=args.optim, code_source=source, data_root=args.data_root,
+                              allow_missing_gt=args.allow_missing_gt)
         for r in recs:
             r["milliseconds"] = 1e3 * r["seconds"]
         return recs
@@ -111,6 +115,9 @@ def main(argv=None):
         with open(os.path.join(output_dir, "reconstruct_summary.json"), "w") as f:
             json.dump(merged, f)
         print("reconstructed %d samples" % len(merged))
+        skipped = sum(1 for r in merged if r.get("icp_skipped"))
+        if skipped:
+            print("WARNING: %d of them were written WITHOUT the eval-mode alignment (no ground-truth mesh)" % skipped)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,8 @@ Covers the default and `--obj` modes: every `<name>_hand.ply` (`_obj.ply`) under
 compared with <data_dir>/mesh_hand/<name>.obj (mesh_obj), and `chamfer_hand.txt` (`chamfer_obj.txt`) is written in the
 reference's layout - one `name, chamfer, joints error, verts error` line per mesh sorted by decreasing Chamfer
 distance, then mean / median / failure count.  The joint / vertex / object-pose errors of the reference come from the
-MANO and pose predictions of the image encoder, which is outside this build: they are written as 0.0.  The `--mano`,
+MANO and pose predictions of the image encoder, which is outside this build: they are written as `nan` ("not computed";
+round 1 wrote 0.0, which a reader could not tell from a perfect score).  The `--mano`,
 `--fit` and `--rot` modes and the best / worst example folders are not reproduced.
 """
 import argparse
@@ -18,7 +19,7 @@ from .deep_sdf.metrics.chamfer import compute_trimesh_chamfer
 
 
 def evaluate(experiment_directory, data_dir, task="obman", obj=False, optim=False, start_point=0, end_point=None, seed=0):
-    """[(name, chamfer_dist, 0.0, 0.0)] for the predicted meshes [start_point, end_point) (evaluate.py:19-112).
+    """[(name, chamfer_dist, nan, nan)] for the predicted meshes [start_point, end_point) (evaluate.py:19-112).
     Meshes that cannot be evaluated are skipped like the reference's bare `except: continue`."""
     suffix = "_obj.ply" if obj else "_hand.ply"
     pred_mesh_path = os.path.join(experiment_directory, "Eval_" + task, "meshes")
@@ -30,7 +31,7 @@ def evaluate(experiment_directory, data_dir, task="obman", obj=False, optim=Fals
         if not (os.path.exists(gt) and os.path.exists(pred)):
             continue
         try:
-            out.append((name, compute_trimesh_chamfer(gt, pred, optim, False, seed=seed), 0.0, 0.0))
+            out.append((name, compute_trimesh_chamfer(gt, pred, optim, False, seed=seed), float("nan"), float("nan")))
         except Exception as e:      # noqa: BLE001
             logging.warning("skipping %s: %s", name, e)
     return out, len(names)
@@ -48,11 +49,11 @@ def write_summary(experiment_directory, task, summary, n_pred, obj=False):
         f.write("mean chamfer distance:{}\n".format(np.mean(chamfer)))
         f.write("median chamfer distance:{}\n".format(np.median(chamfer)))
         if obj:
-            f.write("mean obj center error:{}\n".format(0.0))
-            f.write("mean obj corners error:{}\n".format(0.0))
+            f.write("mean obj center error:{}\n".format(float("nan")))       # not computed (encoder outputs)
+            f.write("mean obj corners error:{}\n".format(float("nan")))
         else:
-            f.write("mean joints error:{}\n".format(0.0))
-            f.write("mean verts error:{}\n".format(0.0))
+            f.write("mean joints error:{}\n".format(float("nan")))
+            f.write("mean verts error:{}\n".format(float("nan")))
         f.write("failure count:{}\n".format(n_pred - len(summary)))
     return path
 

@@ -3,8 +3,10 @@
 `SeparateDecoder` has the constructor signature, attribute names and state-dict keys of the reference
 class (networks/model.py:191-282: `lin{h,o}{0..4}.weight_g|weight_v|bias`, plain `weight` on the last
 layer), so `module.decoder.*` tensors of a reference `latest.pth` load unchanged.  It exists to carry
-parameters to the HIP path (alignsdf_amd.hip_decoder.HipSdfDecoder); its `forward` is a plain PyTorch
-evaluation of the same network for host-side checks and is never used by the mesh-extraction path.
+parameters to the HIP path (alignsdf_amd.hip_decoder.HipSdfDecoder).  Its `forward` is a plain PyTorch
+evaluation of the same network: the mesh-extraction path calls it (on PyTorch-ROCm device tensors, through
+alignsdf_amd.torch_decoder) only for the variants the HIP kernels do not cover - `use_tanh`, the LayerNorm
+form (`weight_norm` false), `xyz_in_all` - like the reference calls its module.
 """
 import warnings
 
@@ -28,10 +30,8 @@ class SeparateDecoder(nn.Module):
                  norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
                  use_classifier=False):
         super().__init__()
-        if not weight_norm and norm_layers:
-            raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
         self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
-        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
+        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers or ()), tuple(latent_in), weight_norm
         self.dropout, self.dropout_prob = dropout, dropout_prob
         self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = use_classifier, use_tanh, xyz_in_all, latent_dropout
         self.num_class = num_class
@@ -44,6 +44,8 @@ class SeparateDecoder(nn.Module):
             for layer in range(len(sizes) - 1):
                 n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
                 setattr(self, prefix + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+                if not weight_norm and layer in self.norm_layers:          # LayerNorm form: bnh* / bno* (networks/model.py:252-253)
+                    setattr(self, "bn" + prefix[3] + str(layer), nn.LayerNorm(n_out))
         if use_classifier:      # on the hand head's last hidden activation (networks/model.py:257-259)
             self.classifier_head = nn.Linear(list(dims)[-1], num_class)
 
@@ -68,7 +70,11 @@ class SeparateDecoder(nn.Module):
             if layer in self.latent_in:
                 x = torch.cat([x, x0], 1)
             x = getattr(self, prefix + str(layer))(x)
+            if layer == last and self.use_tanh:               # networks/model.py:314-315: tanh twice with use_tanh
+                x = torch.tanh(x)
             if layer < last:
+                if not self.weight_norm and layer in self.norm_layers:
+                    x = getattr(self, "bn" + prefix[3] + str(layer))(x)
                 x = torch.relu(x)
                 if self.training and self.dropout is not None and layer in self.dropout:
                     x = torch.nn.functional.dropout(x, p=self.dropout_prob, training=True)
@@ -89,33 +95,43 @@ class CombinedDecoder(nn.Module):
                  norm_layers=(), latent_in=(), weight_norm=False, xyz_in_all=None, use_tanh=False, latent_dropout=False,
                  use_classifier=False):
         super().__init__()
-        if xyz_in_all or use_tanh:
-            raise NotImplementedError("xyz_in_all / use_tanh variants are outside the accelerated hot path")
-        if not weight_norm and norm_layers:
-            raise NotImplementedError("LayerNorm variant (weight_norm=False with norm_layers) is not supported")
         self.latent_size, self.point_feat_size, self.encode_style = latent_size, point_feat_size, encode_style
-        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers), tuple(latent_in), weight_norm
+        self.norm_layers, self.latent_in, self.weight_norm = tuple(norm_layers or ()), tuple(latent_in), weight_norm
         self.dropout, self.dropout_prob = dropout, dropout_prob
-        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = use_classifier, False, xyz_in_all, latent_dropout
+        self.use_classifier, self.use_tanh, self.xyz_in_all, self.latent_dropout = use_classifier, use_tanh, xyz_in_all, latent_dropout
         self.num_class = num_class
         sizes = [latent_size + point_feat_size] + list(dims) + [2]
         self.num_layers = len(sizes)
         for layer in range(len(sizes) - 1):
-            n_out = sizes[layer + 1] - sizes[0] if (layer + 1) in self.latent_in else sizes[layer + 1]
+            if (layer + 1) in self.latent_in:
+                n_out = sizes[layer + 1] - sizes[0]
+            else:
+                n_out = sizes[layer + 1]
+                if xyz_in_all and layer != self.num_layers - 2:      # room for the xyz re-injection (networks/model.py:118-119)
+                    n_out -= point_feat_size
             setattr(self, "lin" + str(layer), _linear(sizes[layer], n_out, weight_norm and layer in self.norm_layers))
+            if not weight_norm and layer in self.norm_layers:        # LayerNorm form (networks/model.py:131-132)
+                setattr(self, "bn" + str(layer), nn.LayerNorm(n_out))
         if use_classifier:      # networks/model.py:134-137
             self.classifier_head = nn.Linear(list(dims)[-1], num_class)
 
     def forward(self, inputs):
         x = inputs
+        xyz = inputs[:, -self.point_feat_size:]
         scores = torch.zeros(1, device=inputs.device)
         for layer in range(self.num_layers - 1):
             if self.use_classifier and layer == self.num_layers - 2:
                 scores = self.classifier_head(x)
             if layer in self.latent_in:
                 x = torch.cat([x, inputs], 1)
+            elif layer != 0 and self.xyz_in_all:                     # networks/model.py:166-167
+                x = torch.cat([x, xyz], 1)
             x = getattr(self, "lin" + str(layer))(x)
+            if layer == self.num_layers - 2 and self.use_tanh:
+                x = torch.tanh(x)
             if layer < self.num_layers - 2:
+                if not self.weight_norm and layer in self.norm_layers:
+                    x = getattr(self, "bn" + str(layer))(x)
                 x = torch.relu(x)
         x = torch.tanh(x)
         return x[:, 0:1], x[:, 1:2], scores
@@ -135,7 +151,7 @@ def build_decoder(specs, state_dict=None):
             for pre in ("module.decoder.", "decoder."):
                 if k.startswith(pre):
                     k = k[len(pre):]
-            if k.startswith(("lin", "classifier_head")):
+            if k.startswith(("lin", "bn", "classifier_head")):
                 sd[k] = torch.as_tensor(v)
         dec.load_state_dict(sd)
     return dec.eval()

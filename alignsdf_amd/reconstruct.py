@@ -75,8 +75,12 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     behind both, and its host part is covered by the pass that is already running."""
     from .marching_cubes import marching_cubes_device
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
-    from .utils.utils import hip_decoder_for, sample_embedding
-    hip = hip_decoder_for(decoder)
+    from .utils.utils import bind_sample, decoder_for
+    it = iter(samples)
+    cur = next(it, None)
+    if cur is None:
+        return
+    hip = decoder_for(decoder, specs, cur[2])      # the HIP kernels, or the module on PyTorch-ROCm for variants they do not cover
     hb, ob = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
     mode = GRID_MODES[grid_mode]
     voxel = 2.0 / (N - 1)
@@ -84,7 +88,7 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     def bind(sample):
         _, latent, mano, obj = sample
-        hip.set_sample(latent, sample_embedding(specs, mano, obj, hip.combined))
+        bind_sample(hip, specs, latent, mano, obj)
 
     def to_host(r, key, t):
         ready = torch.cuda.Event()
@@ -155,10 +159,6 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     r["copy_done_" + part] = done           # the side stream is in order: the last event covers all
         return rebound
 
-    it = iter(samples)
-    cur = next(it, None)
-    if cur is None:
-        return
     r = second_pass(first_pass(cur))
     nxt = next(it, None)
     bbox_next = first_pass(nxt) if nxt is not None else None
@@ -221,7 +221,7 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
 
 def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, end_point, task="obman", device="cuda", scale=None,
                 cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference",
-                data_root="data"):
+                data_root="data", allow_missing_gt=False):
     """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
     decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
     Returns the list of per-sample records."""
@@ -233,7 +233,10 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     for attr in ("module", "decoder"):
         decoder = getattr(decoder, attr, decoder)
     if code_source is None:
-        code_source = synthetic_code_source("nerf3" if specs["PointFeatSize"] == 3 else "both9", device)
+        # the encoder front end is outside this build: without codes there is nothing to reconstruct.  (Round 1 substituted
+        # synthetic latents here, which wrote meaningless <real sample>_hand.ply files that the evaluation then scored.)
+        raise ValueError("reconstruct() needs a code_source: npz_code_source(<dir of per-sample .npz codes>), "
+                         "model_output_code_source(<encoder callable>), or synthetic_code_source(...) for tests and benchmarks")
     def samples():
         for k, path in enumerate(names):
             name = path.split("/")[-1].split(".")[0]                       # reconstruct.py:78
@@ -259,7 +262,8 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                 r["copy_done_hand"].synchronize()
                 kv, kf = kept(r, "hand")
                 r["pending_hand"] = mesh_utils.begin_export_surface(
-                    kv, kf, r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None, True, task, False, data_root)
+                    kv, kf, r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None, True, task, False, data_root,
+                    allow_missing_gt=allow_missing_gt)
 
         for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
                                                     label_out=label_out and hand_on, midpoint=begin_hand if eval_mode else None):
@@ -273,7 +277,10 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                     r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
                     base = os.path.join(mesh_dir, "%s_%s" % (name, part))
                     if part == "hand" and "pending_hand" in r:
-                        _, _, trans, icp_scale = mesh_utils.end_export_surface(r.pop("pending_hand"))
+                        pending = r.pop("pending_hand")
+                        if eval_mode and pending[2][2] is None:
+                            rec["icp_skipped"] = True          # allow_missing_gt: no ground-truth mesh, written unaligned
+                        _, _, trans, icp_scale = mesh_utils.end_export_surface(pending)
                     else:
                         kv, kf = kept(r, part)
                         _, _, trans, icp_scale = mesh_utils.export_surface(
@@ -298,6 +305,15 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     return records
 
 
+def code_source_from_args(args, specs, parser):
+    """--codes DIR | --synthetic; neither is an error (there is no silent default)."""
+    if args.code_dir:
+        return npz_code_source(args.code_dir)
+    if getattr(args, "synthetic", False):
+        return synthetic_code_source("nerf3" if specs["PointFeatSize"] == 3 else "both9")
+    parser.error("no latent codes: pass --codes <dir of <sample>.npz written by the encoder run> (or --synthetic for a benchmark run)")
+
+
 def load_experiment(model_directory, device="cuda"):
     """specs.json + ModelParameters/latest.pth -> (specs, decoder module) (reconstruct.py:166-170,
     networks/model_utils.py:40-47; only the `module.decoder.*` tensors are read)."""
@@ -317,6 +333,8 @@ def main(argv=None):
     p.add_argument("--label", dest="label_out", action="store_true")
     p.add_argument("--viz", dest="viz", action="store_true")
     p.add_argument("--codes", dest="code_dir", default=None, help="directory of precomputed <sample>.npz codes")
+    p.add_argument("--synthetic", action="store_true", help="deterministic synthetic codes (tests / benchmarks only: the meshes mean nothing)")
+    p.add_argument("--allow_missing_gt", action="store_true", help="eval mode: write unaligned meshes when a ground-truth mesh is missing instead of aborting")
     p.add_argument("--cube_dim", type=int, default=128, help="grid resolution (reference CLI hard-codes 128, reconstruct.py:178)")
     args = p.parse_args(argv)
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
@@ -326,9 +344,10 @@ def main(argv=None):
     if args.start_point is None or args.end_point is None:
         with open(split) as f:
             args.start_point, args.end_point = 0, len(json.load(f)["filenames"])
-    source = npz_code_source(args.code_dir) if args.code_dir else None
+    source = code_source_from_args(args, specs, p)
     return reconstruct(decoder, specs, split, output_dir, args.start_point, args.end_point, task=args.task, cube_dim=args.cube_dim,
-                       label_out=args.label_out, viz=args.viz, eval_mode=args.eval_mode, code_source=source)
+                       label_out=args.label_out, viz=args.viz, eval_mode=args.eval_mode, code_source=source,
+                       allow_missing_gt=args.allow_missing_gt)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ from .. import _native
 from ..marching_cubes import marching_cubes_device
 from ..mesh_post import keep_largest_component_device
 from ..ply import write_ply
-from .utils import hip_decoder_for, sample_embedding
+from .utils import bind_sample, decoder_for
 
 GRID_MODES = {"reference": _native.GRID_REFERENCE, "integer": _native.GRID_INTEGER}
 
@@ -97,11 +97,12 @@ def ground_truth_mesh_path(ply_filename_out, task, data_root="data"):
     return os.path.join(data_root, task, "test", mesh_dir, gt_mesh_name)
 
 
-def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data"):
+def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data", allow_missing_gt=False):
     """First half of utils/mesh.py:383-397 for the placed vertices of the (already filtered) surface: in eval mode sample
     both meshes and ENQUEUE the translate+scale ICP (K7) against the ground-truth mesh without waiting for it.
-    Returns a ticket for end_mesh.  A missing ground-truth file is logged and the unaligned mesh is written (the
-    reference would abort the run there)."""
+    Returns a ticket for end_mesh.  A missing ground-truth file aborts like the reference (its trimesh.load raises at
+    utils/mesh.py:389) - a wrong data_root must not produce a full run of silently unaligned meshes; with
+    allow_missing_gt the mesh is written unaligned and the caller records `icp_skipped`."""
     out_v, out_f = mesh_points, faces
     job = None
     if eval_mode:
@@ -110,8 +111,11 @@ def begin_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obma
             from ..icp import load_obj, start_alignment
             gt_v, gt_f = load_obj(gt_path)
             job = start_alignment(out_v, out_f, gt_v, gt_f)                         # 30 000 samples, <= 100 iterations
+        elif allow_missing_gt:
+            logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh (allow_missing_gt)" % gt_path)
         else:
-            logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh" % gt_path)
+            raise FileNotFoundError("eval_mode: ground-truth mesh %s not found (data_root=%r); pass allow_missing_gt to write "
+                                    "unaligned meshes instead" % (gt_path, data_root))
     return out_v, out_f, job, ply_filename_out
 
 
@@ -131,10 +135,10 @@ def end_mesh(ticket):
     return trans, scale
 
 
-def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data"):
+def finish_mesh(mesh_points, faces, ply_filename_out, eval_mode=False, task="obman", data_root="data", allow_missing_gt=False):
     """utils/mesh.py:383-397 for the placed vertices of the (already filtered) surface: in eval mode align it to the
     ground-truth mesh with the translate+scale ICP (K7); export.  Returns (trans [3], scale [1])."""
-    return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root))
+    return end_mesh(begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root, allow_missing_gt))
 
 
 def filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size):
@@ -145,7 +149,7 @@ def filter_surface_device(verts_d, faces_d, voxel_grid_origin, voxel_size):
 
 
 def begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None,
-                         eval_mode=False, task="obman", largest_component=True, data_root="data", kept=None):
+                         eval_mode=False, task="obman", largest_component=True, data_root="data", kept=None, allow_missing_gt=False):
     """place_vertices + the largest-component filter + begin_mesh: everything of the host tail up to (and including)
     enqueuing the eval-mode ICP.  `kept` = (verts, faces) of the largest component in lattice units when the caller has
     already run the device filter (the sample pipeline does, right behind marching cubes); otherwise the surface is
@@ -157,8 +161,8 @@ def begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_fi
     verts, faces, mesh_points = place_vertices(verts_d, faces_d, voxel_grid_origin, voxel_size, offset, scale)
     if kept is not None:
         _, kept_faces, kept_points = place_vertices(kept[0], kept[1], voxel_grid_origin, voxel_size, offset, scale)
-        return verts, faces, begin_mesh(kept_points, kept_faces, ply_filename_out, eval_mode, task, data_root)
-    return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root)
+        return verts, faces, begin_mesh(kept_points, kept_faces, ply_filename_out, eval_mode, task, data_root, allow_missing_gt)
+    return verts, faces, begin_mesh(mesh_points, faces, ply_filename_out, eval_mode, task, data_root, allow_missing_gt)
 
 
 def end_export_surface(pending):
@@ -169,15 +173,16 @@ def end_export_surface(pending):
 
 
 def export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, eval_mode=False,
-                   task="obman", largest_component=True, data_root="data", kept=None):
+                   task="obman", largest_component=True, data_root="data", kept=None, allow_missing_gt=False):
     """The host tail of convert_sdf_samples_to_ply for an already extracted surface (utils/mesh.py:360-397).
     Returns (verts, faces, trans, scale)."""
     return end_export_surface(begin_export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset,
-                                                   scale, eval_mode, task, largest_component, data_root, kept))
+                                                   scale, eval_mode, task, largest_component, data_root, kept, allow_missing_gt))
 
 
 def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None,
-                               scale=None, eval_mode=False, task="obman", largest_component=True, data_root="data"):
+                               scale=None, eval_mode=False, task="obman", largest_component=True, data_root="data",
+                               allow_missing_gt=False):
     """Iso-surface of one SDF volume -> .ply (utils/mesh.py:331-399).  Returns (verts, faces, trans, scale) with
     verts / faces the raw marching-cubes output like the reference.  MC failures are logged and skipped exactly
     like the reference (utils/mesh.py:353-358).  The written file holds the largest watertight component when the
@@ -194,7 +199,7 @@ def convert_sdf_samples_to_ply(pytorch_3d_sdf_tensor, voxel_grid_origin, voxel_s
         print(e)
         return None, None, np.array([0, 0, 0]), np.array([1])
     return export_surface(verts_d, faces_d, voxel_grid_origin, voxel_size, ply_filename_out, offset, scale, eval_mode, task,
-                          largest_component, data_root)
+                          largest_component, data_root, allow_missing_gt=allow_missing_gt)
 
 
 # colour per part label of the `--viz` output (the table of utils/mesh.py:305-310)
@@ -237,8 +242,8 @@ def write_color_labeled_ply(xyz, faces, labels, ply_filename_out, offset=None, s
 def label_points(decoder, latent_vec, mano_results, obj_results, specs, points):
     """Part label of every point [V,3] (normalised coordinates, any device): the label pass of utils/mesh.py:137-157
     in one launch (the reference chunks by max_batch).  Returns a float32 CPU tensor like `out_labels`."""
-    hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, hip.combined))
+    hip = decoder_for(decoder, specs, mano_results)
+    bind_sample(hip, specs, latent_vec, mano_results, obj_results)
     return hip.classify_points(points, want_sdf=False)[3].float().cpu()
 
 
@@ -250,12 +255,13 @@ def write_label_outputs(vertices, faces, labels, ply_filename_hand, offset, scal
     write_verts_label_to_npz(vertices, labels, ply_filename_hand + "_label.npz", offset, scale)
 
 
-def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference"):
+def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference",
+                    cam_intr=None):
     """Pass 1 on [-1,1]^3, zoom cube, pass 2 (utils/mesh.py:21-121) entirely on the device.
     Returns dict(vol_hand, vol_obj device tensors of pass 2, voxel_size 0-dim fp32 tensor, origin list,
     bbox int32[16] of pass 1)."""
-    hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, hip.combined))
+    hip = decoder_for(decoder, specs, mano_results)
+    bind_sample(hip, specs, latent_vec, mano_results, obj_results, cam_intr)
     mode = GRID_MODES[grid_mode]
     voxel_size = 2.0 / (N - 1)
     # a branch that is switched off is neither meshed nor used for the zoom cube (utils/mesh.py:239-247), so its
@@ -295,7 +301,7 @@ def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, l
     (utils/mesh.py:137-184) and needs a decoder with a classifier head.  As in the reference, the object mesh is
     written with the hand mesh's ICP translation / scale as its offset / scale (utils/mesh.py:123-133,186-195)."""
     decoder.eval() if hasattr(decoder, "eval") else None
-    r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode)
+    r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode, cam_intr)
     stats = {}
     if hand_branch:
         v, f, offset, scale = convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"], filename + "_hand.ply", None,

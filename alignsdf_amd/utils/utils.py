@@ -1,7 +1,7 @@
 """Drop-in counterparts of the hot-path helpers of the reference's utils/utils.py.
 
 `decode_sdf_multi_output` keeps the reference signature (utils/utils.py:561) but evaluates the decoder
-through the HIP path.  Because the reference feeds it already-embedded queries, it accepts either raw
+through the HIP path (or, for the variants the kernels do not cover, through the module on PyTorch-ROCm).  Because the reference feeds it already-embedded queries, it accepts either raw
 normalised xyz [M,3] (PointFeatSize 3, or with `raw_xyz=True` plus pose dicts so the affine embedding is
 folded into the kernel) - embedded [M,pf] queries of a pose-aligned model cannot be un-embedded and raise.
 """
@@ -33,6 +33,37 @@ def hip_decoder_for(decoder, device=None):
             hit[1].close()
         per_mod[str(dev)] = (fp, HipSdfDecoder(decoder, device=dev))
     return per_mod[str(dev)][1]
+
+
+def decoder_for(decoder, specs=None, mano_results=None, device=None):
+    """The evaluator of this decoder for this kind of sample: the packed HIP decoder wherever the kernels cover the variant,
+    otherwise the module itself on PyTorch-ROCm (alignsdf_amd.torch_decoder: use_tanh / LayerNorm / xyz_in_all / PixelAlign /
+    pose-aligned model without mano_results) - the stock-module path of SURVEY 8 b2."""
+    from ..torch_decoder import TorchModuleDecoder, needs_module_path
+    if isinstance(decoder, (HipSdfDecoder, TorchModuleDecoder)):
+        if isinstance(decoder, HipSdfDecoder):
+            why = needs_module_path(None, specs, mano_results)
+            if why:
+                raise NotImplementedError("%s - pass the nn.Module so that it can be called" % why)
+        return decoder
+    why = needs_module_path(decoder, specs, mano_results)
+    if why is None:
+        return hip_decoder_for(decoder, device)
+    dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    per_mod = _cache.setdefault(decoder, {})
+    key = "torch:%s:%s" % (dev, why)
+    if key not in per_mod:
+        per_mod[key] = (None, TorchModuleDecoder(decoder, specs, why, dev))
+    per_mod[key][1].specs = specs
+    return per_mod[key][1]
+
+
+def bind_sample(dec, specs, latent_vec, mano_results, obj_results, cam_intr=None):
+    """Bind one sample's codes to an evaluator returned by decoder_for."""
+    if isinstance(dec, HipSdfDecoder):
+        dec.set_sample(latent_vec, sample_embedding(specs, mano_results, obj_results, dec.combined))
+    else:
+        dec.set_sample(latent_vec, mano_results, obj_results, cam_intr)
 
 
 def sample_embedding(specs, mano_results, obj_results, combined=False):
@@ -67,12 +98,10 @@ def kinematic_embedding(xyz, mano_results, num_points_per_scene, point_feat_size
 
 def decode_sdf_multi_output(decoder, latent_vector, queries, mano_results, cam_intr, specs, obj_results=None):
     """(sdf_hand [M,1], sdf_obj [M,1], predicted_class) for normalised xyz queries [M,3]."""
-    if specs.get("PixelAlign", False):
-        raise NotImplementedError("PixelAlign is false in every shipped config and is outside the HIP path")
     if queries.shape[1] != 3:
-        raise NotImplementedError("pass raw normalised xyz [M,3]; the pose embedding is folded into the HIP decoder")
-    hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vector, sample_embedding(specs, mano_results, obj_results, hip.combined))
+        raise NotImplementedError("pass raw normalised xyz [M,3]; the pose embedding is folded into the decoder")
+    hip = decoder_for(decoder, specs, mano_results)
+    bind_sample(hip, specs, latent_vector, mano_results, obj_results, cam_intr)
     if hip.num_class:
         h, o, scores, _ = hip.classify_points(queries)
         return h.unsqueeze(1), o.unsqueeze(1), scores

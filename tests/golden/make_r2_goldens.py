@@ -156,48 +156,10 @@ def small(ref):
 
 
 def variant_state(name, syn, torch):
-    """(specs, decoder class name, state dict, mano, obj, cam, latent) of one fallback variant; the weights are the synthetic
-    recipe re-shaped for the variant's parameter layout."""
-    latent = torch.from_numpy(syn.latent_code(0))
-    mano = obj = cam = None
-    if name == "tanh":
-        specs, sd, cls = syn.specs_for("nerf3"), syn.full_state_dict("nerf3"), "SeparateDecoder"
-        specs["NetworkSpecs"]["use_tanh"] = True
-    elif name == "layernorm":
-        specs, cls = syn.specs_for("nerf3"), "SeparateDecoder"
-        specs["NetworkSpecs"]["weight_norm"] = False
-        from oracle import sdf_oracle as orc
-        base, sd = syn.full_state_dict("nerf3"), {}
-        for head in "ho":
-            for k in range(4):
-                w = orc.effective_weight(base["lin%s%d.weight_v" % (head, k)], base["lin%s%d.weight_g" % (head, k)]).numpy()
-                sd["lin%s%d.weight" % (head, k)], sd["lin%s%d.bias" % (head, k)] = w, base["lin%s%d.bias" % (head, k)]
-                n = w.shape[0]
-                sd["bn%s%d.weight" % (head, k)] = (1.0 + 0.1 * syn.normal((n,), 8100 + 10 * k + (head == "o"))).astype(np.float32)
-                sd["bn%s%d.bias" % (head, k)] = (0.05 * syn.normal((n,), 8200 + 10 * k + (head == "o"))).astype(np.float32)
-            sd["lin%s4.weight" % head], sd["lin%s4.bias" % head] = base["lin%s4.weight" % head], base["lin%s4.bias" % head]
-    elif name == "xyzall":
-        specs, cls = syn.specs_for("comb3"), "CombinedDecoder"
-        specs["NetworkSpecs"]["xyz_in_all"] = True
-        base, sd = syn.full_state_dict("comb3"), {}
-        # layer shapes with xyz_in_all (networks/model.py:114-122): out rows shrink by pf except where latent_in follows
-        rows = {0: 509, 1: 253, 2: 509, 3: 509}
-        for k in range(4):
-            sd["lin%d.weight_v" % k] = base["lin%d.weight_v" % k][:rows[k]]
-            sd["lin%d.weight_g" % k] = base["lin%d.weight_g" % k][:rows[k]]
-            sd["lin%d.bias" % k] = base["lin%d.bias" % k][:rows[k]]
-        sd["lin4.weight"], sd["lin4.bias"] = base["lin4.weight"], base["lin4.bias"]
-    elif name == "nomano":
-        specs, sd, cls = syn.specs_for("both9"), syn.full_state_dict("both9"), "SeparateDecoder"
-    elif name == "pixelalign":
-        specs, sd, cls = syn.specs_for("nerf3"), syn.full_state_dict("nerf3"), "SeparateDecoder"
-        specs["PixelAlign"] = True
-        latent = torch.from_numpy((0.1 * syn.normal((1, 256, 8, 8), 8300)).astype(np.float32))     # image feature map [B, C, H, W]
-        mano = {"joints": torch.tensor([[[0.02, -0.01, 0.45]] * 21], dtype=torch.float32)}       # root joint in camera space
-        cam = torch.tensor([[[480.0, 0.0, 128.0, 0.0], [0.0, 480.0, 128.0, 0.0], [0.0, 0.0, 1.0, 0.0]]])      # [B, 3, 4]
-    else:
-        raise ValueError(name)
-    return specs, cls, sd, mano, obj, cam, latent
+    """alignsdf_amd.synthetic.variant_config as torch tensors."""
+    specs, cls, sd, mano, obj, cam, latent = syn.variant_config(name)
+    t = lambda d: None if d is None else {k: torch.from_numpy(v) for k, v in d.items()}
+    return specs, cls, sd, t(mano), t(obj), None if cam is None else torch.from_numpy(cam), torch.from_numpy(latent)
 
 
 VARIANTS = ("tanh", "layernorm", "xyzall", "nomano", "pixelalign")

@@ -51,7 +51,10 @@ def test_reconstruct_cli_writes_reference_layout(tmp_path):
     from alignsdf_amd.ply import read_ply
     names = ["00000012", "00000047", "00000100"]
     specs, split = make_experiment(str(tmp_path), "nerf3", names)
-    recs = rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32"])
+    with pytest.raises(SystemExit):       # no silent default: without --codes / --synthetic there is nothing to reconstruct
+        rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32"])
+    recs = rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32",
+                    "--synthetic"])
     assert [r["name"] for r in recs] == names[1:] and [r["index"] for r in recs] == [1, 2]
     mesh_dir = os.path.join(str(tmp_path), "Eval_obman", "meshes")
     assert sorted(os.listdir(mesh_dir)) == sorted(["%s_%s.ply" % (n, p) for n in names[1:] for p in ("hand", "obj")])
@@ -71,7 +74,7 @@ def test_dist_reconstruct_cli_two_ranks(tmp_path):
     env = dict(os.environ, ASDF_DIST_BACKEND="gloo", ASDF_SHARE_DEVICE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", "-m", "alignsdf_amd.dist_reconstruct", "-e", str(tmp_path), "-t", "obman", "--split", split,
-           "--cube_dim", "32"]
+           "--cube_dim", "32", "--synthetic", "--allow_missing_gt", "--data_root", str(tmp_path / "no_such_data")]
     subprocess.run(cmd, check=True, timeout=600, env=env)
     summary = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "reconstruct_summary.json")))
     assert [r["index"] for r in summary] == [0, 1, 2, 3, 4]
@@ -79,3 +82,21 @@ def test_dist_reconstruct_cli_two_ranks(tmp_path):
     meshes = sorted(os.listdir(os.path.join(str(tmp_path), "Eval_obman", "meshes")))
     assert meshes == sorted(["%s_%s.ply" % (n, p) for n in names for p in ("hand", "obj")])
     assert all(r["F_hand"] > 100 and r["F_obj"] > 100 for r in summary)
+    assert all(r["icp_skipped"] == 1 for r in summary)          # eval mode without ground-truth meshes is visible in the records
+
+
+def test_reconstruct_requires_a_code_source(tmp_path):
+    """reconstruct() used to fall back to synthetic latents and write <real sample>_hand.ply files from them."""
+    from alignsdf_amd import reconstruct as rc
+    specs, split = make_experiment(str(tmp_path), "nerf3", ["a", "b"])
+    with pytest.raises(ValueError, match="code_source"):
+        rc.reconstruct(object(), specs, split, str(tmp_path / "out"), 0, 2)
+
+
+def test_evaluation_summary_marks_uncomputed_metrics(tmp_path):
+    """The joint / vertex / object-pose errors come from the encoder (outside this build): nan, not 0.0."""
+    from alignsdf_amd.evaluate import write_summary
+    os.makedirs(tmp_path / "Eval_obman")
+    path = write_summary(str(tmp_path), "obman", [("x", 1.5, float("nan"), float("nan"))], 2)
+    text = open(path).read()
+    assert "mean joints error:nan" in text and "mean verts error:nan" in text and "failure count:1" in text

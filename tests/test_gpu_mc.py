@@ -17,9 +17,10 @@ def hip_mc(vol, level=0.0, spacing=(1.0, 1.0, 1.0)):
 
 
 def test_all_sign_patterns_vs_skimage(golden_dir):
-    """Every non-trivial 2x2x2 sign pattern x 20 magnitude draws, batched into one volume per draw set."""
-    g = np.load(golden_dir + "/mc_cells.npz")
-    for n in range(0, len(g["corners"]), 29):      # a stride through the table; the full table is pinned on the oracle
+    """ALL 5 080 fixture cells (254 non-trivial sign patterns x 20 magnitude draws) through the real kernel chain, one
+    2 x 2 x 2 volume each: vertex and face arrays bit for bit those of the installed skimage binary."""
+    g = {k: v for k, v in np.load(golden_dir + "/mc_cells.npz").items()}        # decompress once, not per access
+    for n in range(len(g["corners"])):
         vol = np.zeros((2, 2, 2), np.float32)
         for ci, (z, y, x) in enumerate(CORNER_POS):
             vol[z, y, x] = g["corners"][n][ci]
@@ -30,8 +31,9 @@ def test_all_sign_patterns_vs_skimage(golden_dir):
 
 
 def test_value_dependent_patterns_vs_skimage(golden_dir):
-    g = np.load(golden_dir + "/mc_cells_ambiguous.npz")
-    for n in range(0, len(g["corners"]), 41):
+    """ALL 19 200 draws on the value-dependent patterns (MC33 sub-cases): counts and checksums of the skimage binary."""
+    g = {k: v for k, v in np.load(golden_dir + "/mc_cells_ambiguous.npz").items()}
+    for n in range(len(g["corners"])):
         vol = np.zeros((2, 2, 2), np.float32)
         for ci, (z, y, x) in enumerate(CORNER_POS):
             vol[z, y, x] = g["corners"][n][ci]

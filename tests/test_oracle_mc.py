@@ -22,7 +22,8 @@ def checksums(v, f):
 
 
 def test_all_sign_patterns_bit_exact(golden_dir):
-    g = np.load(golden_dir + "/mc_cells.npz")
+    """All 5 080 fixture cells (254 sign patterns x 20 magnitude draws), verts and faces bit for bit."""
+    g = {k: v for k, v in np.load(golden_dir + "/mc_cells.npz").items()}        # decompress once, not per access
     for n in range(len(g["corners"])):
         v, f = mc33.marching_cubes_raw(cell_volume(g["corners"][n]))
         V, F = int(g["V"][n]), int(g["F"][n])
@@ -31,11 +32,10 @@ def test_all_sign_patterns_bit_exact(golden_dir):
 
 
 def test_value_dependent_patterns(golden_dir):
-    """Every fourth fixture cell here (one C call per cell: the full set takes minutes on the CPU); the GPU suite runs all of
-    them in one launch (tests/test_gpu_mc.py::test_value_dependent_patterns_vs_skimage)."""
-    g = np.load(golden_dir + "/mc_cells_ambiguous.npz")
+    """ALL 19 200 extra draws on the 128 value-dependent sign patterns: counts and checksums of the installed binary."""
+    g = {k: v for k, v in np.load(golden_dir + "/mc_cells_ambiguous.npz").items()}
     seen = set()
-    for n in range(0, len(g["corners"]), 4):
+    for n in range(len(g["corners"])):
         v, f = mc33.marching_cubes_raw(cell_volume(g["corners"][n]))
         assert (len(v), len(f)) == (int(g["V"][n]), int(g["F"][n])), n
         fs, vs = checksums(v, f)

@@ -30,6 +30,7 @@ if EVAL:
         with open(os.path.join(gt_dir, "%08d.obj" % i), "w") as f:
             f.write("".join("v %.6f %.6f %.6f\n" % tuple(p) for p in P) + "".join("f %d %d %d\n" % (a + 1, b + 1, c + 1) for a, b, c in F))
 kw = dict(eval_mode=True, data_root=os.path.join(tmp, "data")) if EVAL else {}
+kw["code_source"] = rc.synthetic_code_source("nerf3")
 rc.reconstruct(dec, specs, split, tmp, 0, 1, cube_dim=N, **kw)          # warm-up
 torch.cuda.synchronize()
 t = time.perf_counter()
