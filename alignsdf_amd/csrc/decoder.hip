@@ -164,8 +164,14 @@ struct asdf_decoder {
   float s2[ASDF_MAX_HEADS];
   int math;
   bool sample_bound;
-  int* status;      // [4] device words: [0] = lanes whose activations left the fp16 range in split-half launches since the last
-                    // clear, [1] = near-level voxels that did not fit the refinement list
+  int* status;      // [16] device words: [0] = lanes whose activations left the fp16 range in split-half launches since the
+                    // last clear, [1] = near-level voxels that did not fit the refinement list, [4..6] / [8..10] = largest
+                    // plane value (float bits) of h0 / h1 / h2 of MLP 0 / MLP 1
+  // activation scales of the split-half image (asdf_decoder_set_act_scales) and what is needed to rebuild its constants
+  float sw[ASDF_MAX_HEADS][3];
+  float sx[ASDF_MAX_HEADS][3];
+  float* cst_host;    // the fp32 constants image (static parts), host copy
+  float* cst16_host;  // staging buffer of the rebuilt split-half constants
   // near-level refinement of split-half sweeps (asdf_decoder_set_refine)
   void* ev_start;   // one-shot hipEvent_t pair recorded around the dominant kernel of the next sweep (asdf_decoder_time_next_sweep)
   void* ev_stop;
@@ -191,7 +197,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 112; }
+int asdf_version(void) { return 113; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -227,6 +233,8 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   (void)hipFree(d->status);
   (void)hipFree(d->near_idx);
   (void)hipFree(d->near_count);
+  std::free(d->cst_host);
+  std::free(d->cst16_host);
   delete d;
 }
 
@@ -271,13 +279,20 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     up(&d->cst16, hp.cst16);
     if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-    for (int h = 0; h < kHeads; ++h) d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
+    for (int h = 0; h < kHeads; ++h) {
+      d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
+      for (int l = 0; l < 3; ++l) { d->sw[h][l] = h < spec->num_heads ? hp.sw[h][l] : 1.0f; d->sx[h][l] = kActScale; }
+    }
+    d->cst_host = (float*)std::malloc(hp.cst.size() * sizeof(float));
+    d->cst16_host = (float*)std::malloc(hp.cst.size() * sizeof(float));
+    if (!d->cst_host || !d->cst16_host) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
+    std::memcpy(d->cst_host, hp.cst.data(), hp.cst.size() * sizeof(float));
     if (e == hipSuccess) e = k1h_prepare();
   }
   if (e == hipSuccess) e = k1_prepare();
   if (e == hipSuccess) e = k1_cls_prepare();
-  if (e == hipSuccess) e = hipMalloc((void**)&d->status, 4 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(d->status, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->status, 16 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(d->status, 0, 16 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kNearCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_count, sizeof(int));
   d->refine_tau = 4e-6f;
@@ -467,12 +482,37 @@ int asdf_decoder_set_refine(asdf_decoder_t* d, float tau) {
   return ASDF_OK;
 }
 
-int asdf_decoder_status(asdf_decoder_t* d, int32_t out_host[4], int32_t clear, void* stream) {
+int asdf_decoder_status(asdf_decoder_t* d, int32_t out_host[16], int32_t clear, void* stream) {
   if (!d || !out_host) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  ASDF_HIP(hipMemcpyAsync(out_host, d->status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  if (clear) ASDF_HIP(hipMemsetAsync(d->status, 0, 4 * sizeof(int), st));
+  ASDF_HIP(hipMemcpyAsync(out_host, d->status, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (clear) ASDF_HIP(hipMemsetAsync(d->status, 0, 16 * sizeof(int), st));
   ASDF_HIP(hipStreamSynchronize(st));
+  return ASDF_OK;
+}
+
+int asdf_decoder_get_act_scales(const asdf_decoder_t* d, float sx_out[ASDF_MAX_HEADS][3]) {
+  if (!d || !sx_out) return ASDF_EINVAL;
+  std::memcpy(sx_out, d->sx, sizeof(d->sx));
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_act_scales(asdf_decoder_t* d, const float sx[ASDF_MAX_HEADS][3], void* stream) {
+  if (!d || !sx || !d->cst16) return ASDF_EINVAL;
+  for (int h = 0; h < d->spec.num_heads; ++h)
+    for (int l = 0; l < 3; ++l) {
+      int e = 0;
+      const float m = std::frexp(sx[h][l], &e);
+      if (!(sx[h][l] > 0.0f) || m != 0.5f || e < -23 || e > 25) return ASDF_EINVAL;      // powers of two in [2^-24, 2^24]
+    }
+  hipStream_t st = (hipStream_t)stream;
+  ASDF_HIP(hipStreamSynchronize(st));                      // sweeps in flight still read the old constants
+  std::memcpy(d->sx, sx, sizeof(d->sx));
+  const size_t n = (size_t)kHeads * cst_offsets(d->kp).floats;
+  std::memcpy(d->cst16_host, d->cst_host, n * sizeof(float));
+  scale_constants_f16(d->spec, d->kp, d->cst_host, d->sw, d->sx, d->cst16_host, d->s2);
+  ASDF_HIP(hipMemcpy(d->cst16, d->cst16_host, n * sizeof(float), hipMemcpyHostToDevice));
+  d->sample_bound = false;                                 // the folded per-sample constants carried the old layer-2 scale
   return ASDF_OK;
 }
 

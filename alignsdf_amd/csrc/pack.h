@@ -21,9 +21,14 @@ struct HostPack {
   std::vector<uint16_t> stream16;   // [kStagesAll][kStageFloats * 2] fp16 bits: stage = [kblock 8][plane 2][lane 64][8]
   std::vector<float> cst16;         // the constants block with the scaled entries of the split-half kernel
   float s2[kHeads];                 // scale of the layer-2 accumulator (K0 applies it to c2 / A2)
+  float sw[kHeads][3];              // S_w of layers 1..3 (max |w| S_w in [512, 1024))
 };
 
-constexpr float kActScale = 8.0f;   // S_x: activations are carried as x * S_x in the fp16 planes
+constexpr float kActScale = 8.0f;   // default S_x: activations are carried as x * S_x in the fp16 planes
+// target of the calibrated S_x (host side, hip_decoder.py): the largest plane value of a layer over the calibration sweep
+// lands in [1024, 2048) - a factor 32 to 64 below the fp16 maximum - and activations down to 2^-13 of the layer maximum keep
+// a normal low plane (two full planes = 22 significand bits)
+constexpr float kActTarget = 2048.0f;
 
 inline uint16_t f16_bits(float x) {
   const _Float16 h = (_Float16)x;   // round to nearest even
@@ -40,6 +45,36 @@ inline float weight_scale(const float* w, int rows, int cols, int ld) {
     for (int c = 0; c < cols; ++c) m = std::fmax(m, std::fabs(w[(size_t)r * ld + c]));
   if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
   return std::exp2(std::floor(std::log2(1000.0f / m)));
+}
+
+// The static constants of the split-half image for given scales.  cst = the fp32 constants image (unscaled b1, b3, w4, w4b and,
+// for the NeRF encoding, the static point fragments A2), sw = S_w of layers 1..3, sx = S_x of the three activation vectors
+// h0, h1, h2 (powers of two).  With acc_l = S_w,l S_x,l-1 (W_l x + b_l):
+//   b1 * (sw1 sx0),  b3 * (sw3 sx2),  w4 / (sw3 sx2),  s2 = sw2 sx1 (K0 scales the folded c2 / A2 by it),
+//   mul0 = sx0,  mul1 = sx1 / (sw1 sx0),  mul2 = sx2 / (sw2 sx1)      (accumulator -> next planes, exact powers of two).
+// Per-sample entries (A0, A2, c0, c2) are K0's and are left alone here (A2 of the NeRF image is static: scaled here).
+inline void scale_constants_f16(const asdf_decoder_spec_t& spec, int kp, const float* cst, const float (*sw)[3], const float (*sx)[3],
+                                float* cst16, float* s2) {
+  const CstOffsets co = cst_offsets(kp);
+  for (int h = 0; h < spec.num_heads; ++h) {
+    const float* c = cst + (size_t)h * co.floats;
+    float* d = cst16 + (size_t)h * co.floats;
+    const float s1 = sw[h][0] * sx[h][0], s3 = sw[h][2] * sx[h][2];
+    s2[h] = sw[h][1] * sx[h][1];
+    for (int i = 0; i < kTilesL1 * 32; ++i) d[co.b1 + i] = c[co.b1 + i] * s1;
+    for (int i = 0; i < kHidden; ++i) {
+      d[co.b3 + i] = c[co.b3 + i] * s3;
+      d[co.w4 + i] = c[co.w4 + i] / s3;
+      d[co.w4b + i] = c[co.w4b + i] / s3;
+    }
+    d[co.b4] = c[co.b4];
+    d[co.b4 + 1] = c[co.b4 + 1];
+    d[co.b4 + 2] = sx[h][1] / s1;
+    d[co.b4 + 3] = sx[h][2] / s2[h];
+    d[co.b4 + 4] = sx[h][0];
+    if (spec.feature_mode == ASDF_FEATURES_NERF)
+      for (int i = 0; i < kTilesHidden * kp * 64; ++i) d[co.a2 + i] = c[co.a2 + i] * s2[h];
+  }
 }
 
 // Split-half image of the hidden layers: every weight w of layers 1-3 is carried as two fp16 planes of w * S_w
@@ -83,24 +118,10 @@ inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_pa
     pack(kTilesL1, 4, sw1, [&](int row, int feat) { return row < n1 ? W1[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 2, sw2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 4, sw3, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
-    const float s1 = sw1 * kActScale, s3 = sw3 * kActScale;
-    hp.s2[h] = sw2 * kActScale;
-    float* c = &hp.cst16[(size_t)h * co.floats];
-    for (int t = 0; t < kTilesHidden; ++t)
-      for (int hh = 0; hh < 2; ++hh)
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * t + tile_row(r, hh);
-          if (t < kTilesL1) c[co.b1 + (t * 2 + hh) * 16 + r] = row < n1 ? heads[h].b[1][row] * s1 : 0.0f;
-          c[co.b3 + (t * 2 + hh) * 16 + r] = heads[h].b[3][row] * s3;
-          c[co.w4 + (t * 2 + hh) * 16 + r] = W4[row] / s3;
-          c[co.w4b + (t * 2 + hh) * 16 + r] = spec.outputs[h] > 1 ? W4[kHidden + row] / s3 : 0.0f;
-        }
-    c[co.b4 + 2] = 1.0f / sw1;      // accumulator -> next planes: relu(acc) / S_w (the S_x factor stays in)
-    c[co.b4 + 3] = 1.0f / sw2;
-    // NeRF encoding: the layer-2 point-feature fragments are static (not folded per sample) - scale them here
-    if (spec.feature_mode == ASDF_FEATURES_NERF)
-      for (int i = 0; i < kTilesHidden * hp.kp * 64; ++i) c[co.a2 + i] *= hp.s2[h];
+    hp.sw[h][0] = sw1; hp.sw[h][1] = sw2; hp.sw[h][2] = sw3;
   }
+  const float sx_default[kHeads][3] = {{kActScale, kActScale, kActScale}, {kActScale, kActScale, kActScale}};
+  scale_constants_f16(spec, hp.kp, hp.cst.data(), hp.sw, sx_default, hp.cst16.data(), hp.s2);
   return true;
 }
 

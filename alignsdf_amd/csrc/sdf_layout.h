@@ -58,10 +58,11 @@ struct CstLayout {
   static constexpr int kB3 = kC2 + kHidden;                       // 512
   static constexpr int kW4 = kB3 + kHidden;                       // 512
   static constexpr int kW4b = kW4 + kHidden;                      // 512: second output row (CombinedDecoder), zero otherwise
-  static constexpr int kB4 = kW4b + kHidden;                      // 2 (+2 pad): b4 of output 0 and output 1
-  static constexpr int kFloats = kB4 + 4;
+  static constexpr int kB4 = kW4b + kHidden;                      // 8: b4 of output 0 / 1; split-half image: [2] mul1, [3] mul2,
+                                                                  //    [4] mul0 (accumulator -> next planes multipliers), [5..7] pad
+  static constexpr int kFloats = kB4 + 8;
 };
-constexpr int kCstFloats = CstLayout<2>::kFloats;                 // 6916 floats = 27 664 B (xyz features)
+constexpr int kCstFloats = CstLayout<2>::kFloats;                 // 6920 floats = 27 680 B (xyz features)
 constexpr int kMaxKP = 8;                                          // NeRF encoding up to PointFeatSize 15
 constexpr int kCstFloatsMax = CstLayout<kMaxKP>::kFloats;
 
@@ -80,7 +81,7 @@ __host__ __device__ constexpr CstOffsets cst_offsets(int kp) {
   o.w4 = o.b3 + kHidden;
   o.w4b = o.w4 + kHidden;
   o.b4 = o.w4b + kHidden;
-  o.floats = o.b4 + 4;
+  o.floats = o.b4 + 8;
   return o;
 }
 

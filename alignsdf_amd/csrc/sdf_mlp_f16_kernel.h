@@ -67,7 +67,8 @@ constexpr int kS16Pieces = kS16Kb / 2;               // 1 KiB LDS-DMA pieces per
 constexpr int kS16WaveFloats = kS16Floats / kWaves;  // a wave's share of a stage
 constexpr int kRing16Floats = kRing * kS16Floats;
 // LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
-constexpr int lds_bytes_f16(int kp) { return (kRing16Floats + cst_offsets(kp).floats) * 4 + kWaves * 16 * 4; }
+constexpr int kWrecInts = 20;    // per wave: two 8-int negative-voxel records + the largest plane value of layers 0..2 (+ pad)
+constexpr int lds_bytes_f16(int kp) { return (kRing16Floats + cst_offsets(kp).floats) * 4 + kWaves * kWrecInts * 4; }
 constexpr int kLdsBytesF16 = lds_bytes_f16(2);
 static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 
@@ -228,8 +229,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     // negative-voxel bounding box of this MLP's output(s) + the range report, one record per wave and output in LDS:
     // [0..2] min index, [3..5] max index, [6] count, [7] lanes whose activations left the fp16 range (or whose output is
     // not in [-1, 1]); the second output of a CombinedDecoder uses the record 8 ints further
-    int* wrec = reinterpret_cast<int*>(cst + CL::kFloats) + wave * 16;
-    if (lane < 16) wrec[lane] = (lane & 7) < 3 ? 0x7fffffff : ((lane & 7) < 6 ? -1 : 0);
+    int* wrec = reinterpret_cast<int*>(cst + CL::kFloats) + wave * kWrecInts;
+    if (lane < kWrecInts) wrec[lane] = lane >= 16 ? 0 : ((lane & 7) < 3 ? 0x7fffffff : ((lane & 7) < 6 ? -1 : 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
@@ -255,7 +256,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       ah[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 0) * 64];
       al[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 1) * 64];
     }
-    const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3];      // 1 / S_w of layers 1 and 2
+    // accumulator -> next layer's planes: S_x of the produced activations / (S_w S_x) of the accumulator (powers of two)
+    const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3], mul0 = hc[CL::kB4 + 4];
 
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -267,7 +269,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       } else {
         grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       }
-      float amax = 0.0f;                        // largest activation plane value of this tile
+      // largest plane value (x S_x) this lane hands to the fp16 conversion, per activation vector h0 / h1 / h2: >= 65504
+      // is an overflow (range report); the maxima themselves go to the decoder's status record, from which the host
+      // calibrates the S_x of each layer
+      float amax = 0.0f, amax1 = 0.0f, amax2 = 0.0f;
       float bp[KP];
       if (KP == 2) {
         bp[0] = half ? x1 : x0;
@@ -288,7 +293,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       f32x16 acc1[2], acc2[2], acc3[2];
       float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
       float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
+      // (the 8 K-step form of PointFeatSize 15 has no registers to spare for these: it reads its fragments at the point of use)
+      constexpr bool kPreloadPf = KP <= 5;
       auto load_pf2 = [&](int t) {
+        if (!kPreloadPf) return;
 #pragma unroll
         for (int s = 0; s < KP; ++s) pf2[s] = hc[CL::kA2 + (t * KP + s) * 64 + lane];
       };
@@ -308,15 +316,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       f32x16 acc0[2];
       float pf0[2][KP];
       auto l0_load = [&](int t) {
+        if (!kPreloadPf) return;
         acc0[t & 1] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < KP; ++s) pf0[t & 1][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
       };
       auto l0_compute = [&](int t) {
-        f32x16 acc = acc0[t & 1];
+        f32x16 acc = kPreloadPf ? acc0[t & 1] : load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(pf0[t & 1][s], bp[s], acc);
-        split_tile(acc, kActScaleDev, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
+        split_tile(acc, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
       };
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
@@ -358,7 +367,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
           pin_acc(acc1[(t - 1) & 1]);
-          split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax, c);
+          split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax1, c);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
@@ -390,18 +399,18 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         f32x16& acc = acc2[t & 1];
         if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(pf2[s], bp[s], acc);
+        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
         auto epi = [&](int kb) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
             pin_acc(acc2[(t - 1) & 1]);
-            split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax, c);
+            split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax2, c);
           } else {
             pin_acc(acc1[(kTilesL1 - 1) & 1]);
             split_part(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                       h1l[2 * kTilesL1 - 1], amax, c);       // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
+                       h1l[2 * kTilesL1 - 1], amax1, c);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
         };
         auto pre_last = [&](int c) {
@@ -463,7 +472,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           } else {
             pin_acc(acc2[(kTilesHidden - 1) & 1]);
             split_part(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
-                       h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax, c);  // K-blocks 30, 31: end of this tile
+                       h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c);  // K-blocks 30, 31: end of this tile
           }
         };
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
@@ -513,7 +522,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
-      const int bad = (valid && (!(amax < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
+      const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
+      const int bad = (valid && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
+      if (valid && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
+        atomicMax(wrec + 16, __float_as_int(amax));
+        atomicMax(wrec + 17, __float_as_int(amax1));
+        atomicMax(wrec + 18, __float_as_int(amax2));
+      }
       if (p.bbox && p.mode != kPointList) {
         const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
         auto fold = [&](bool neg, int* rec, int extra) {
@@ -555,7 +570,11 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         if (TWO_OUT) flush(p.bbox + 8, wrec + 8);
         if (wrec[7]) atomicAdd(p.bbox + (head == 0 ? 7 : 15), wrec[7]);
       }
-      if (wrec[7] && p.status) atomicAdd(p.status, wrec[7]);
+      if (p.status) {
+        if (wrec[7]) atomicAdd(p.status, wrec[7]);
+        int* peak = p.status + 4 + 4 * head;       // [4..6] MLP 0, [8..10] MLP 1: largest plane value of h0 / h1 / h2 (float bits)
+        atomicMax(peak + 0, wrec[16]); atomicMax(peak + 1, wrec[17]); atomicMax(peak + 2, wrec[18]);
+      }
     }
   }   // MLPs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

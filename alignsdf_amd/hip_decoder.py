@@ -164,6 +164,9 @@ class HipSdfDecoder:
         elif want not in ("f32", "f16x3"):
             raise ValueError("ASDF_MATH must be 'f32' or 'f16x3', not %r" % want)
         self._latent = None
+        self._bound = None           # (latent, embed) of the sample the decoder is bound to
+        self._calibrated = False     # activation scales still at their default
+        self._recalibrations = 0
         self.refine_tau = 4e-6
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
 
@@ -182,13 +185,22 @@ class HipSdfDecoder:
     def fall_back_if_overflowed(self, bbox_host):
         """bbox words 7 / 15 count points whose activations left the fp16 range of the split-half planes; they are non-zero
         only for a sweep that ran under f16x3 (the fp32 kernel leaves them 0), so the decision rests on the record alone -
-        whatever arithmetic the decoder has been switched to since that sweep was queued.  Switches the decoder to the fp32
-        MFMA chain (for good) and returns True; the caller repeats the sweep the record belongs to."""
+        whatever arithmetic the decoder has been switched to since that sweep was queued.  Returns True when the caller has
+        to repeat the sweep the record belongs to: the activation scales were re-calibrated from the peaks that sweep left
+        in the status record (first resort), or - when the scales cannot be lowered any further - the decoder was switched
+        to the fp32 MFMA chain for good."""
         bad = int(bbox_host[7]) + int(bbox_host[15])
         if not bad:
             return False
-        self._to_f32(bad)
+        self._recover(bad)
         return True
+
+    def _recover(self, bad, status=None):
+        if self.math == "f16x3" and self._recalibrations < 3:
+            self._recalibrations += 1
+            if self.calibrate(status):
+                return
+        self._to_f32(bad)
 
     def _to_f32(self, bad):
         if self.math != "f32":
@@ -196,13 +208,57 @@ class HipSdfDecoder:
             logging.warning("split-half decoder: %d activations left the fp16 range; falling back to the fp32 MFMA kernel", bad)
             self.set_math("f32")
 
+    def _status(self, clear):
+        out = (ctypes.c_int32 * 16)()
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_decoder_status(self._h, out, 1 if clear else 0, self._stream()), "asdf_decoder_status")
+        return np.frombuffer(out, dtype=np.int32).copy()
+
     def range_violations(self, clear=True):
         """Number of (point, lane-half) pairs whose activations left the fp16 range in split-half sweeps of this decoder
         since the last clear - the decoder-owned status word, independent of any bbox buffer.  Synchronises the stream."""
-        out = (ctypes.c_int32 * 4)()
+        return int(self._status(clear)[0])
+
+    def act_scales(self):
+        out = (ctypes.c_float * 6)()
+        _native.check(self._L.asdf_decoder_get_act_scales(self._h, out), "asdf_decoder_get_act_scales")
+        return np.frombuffer(out, dtype=np.float32).reshape(2, 3).copy()
+
+    def set_act_scales(self, sx):
+        """S_x per MLP and activation vector (h0, h1, h2), powers of two; re-binds the current sample (the folded constants
+        carry the layer-2 scale)."""
+        arr = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(sx, np.float32).reshape(-1)])
         with torch.cuda.device(self.device):
-            _native.check(self._L.asdf_decoder_status(self._h, out, 1 if clear else 0, self._stream()), "asdf_decoder_status")
-        return int(out[0])
+            _native.check(self._L.asdf_decoder_set_act_scales(self._h, arr, self._stream()), "asdf_decoder_set_act_scales")
+        if self._bound is not None:
+            self.set_sample(*self._bound)
+
+    def calibrate(self, status=None):
+        """Choose every S_x from the peak plane values of the sweeps since the last status clear (asdf_decoder_status words
+        4..6 / 8..10): the power of two that puts the layer's peak in [1024, 2048) - a factor 32..64 of headroom under the fp16
+        maximum for later samples, while every activation down to 2^-13 of the peak keeps two full planes.  A peak that overflowed (inf / NaN
+        pattern) moves that scale down by 2^6 instead.  Returns True when a scale changed (the caller repeats its sweep)."""
+        st = self._status(clear=True) if status is None else status
+        cur = self.act_scales()
+        new = cur.copy()
+        for h in range(1 if self.combined else 2):
+            for l in range(3):
+                bits = int(st[4 + 4 * h + l])
+                if bits == 0:
+                    continue                                  # this MLP did not run (or produced only zeros)
+                peak = float(np.int32(bits).view(np.float32))
+                if not np.isfinite(peak) or peak >= 65504.0:
+                    new[h, l] = cur[h, l] / 64.0
+                else:
+                    want = cur[h, l] * 2.0 ** np.floor(np.log2(2048.0 / peak))      # peak / cur = the activation itself
+                    new[h, l] = float(np.clip(want, 2.0 ** -24, 2.0 ** 24))
+        self._calibrated = True
+        if np.array_equal(new, cur):
+            return False
+        import logging
+        logging.info("split-half decoder: activation scales %s -> %s", cur.tolist(), new.tolist())
+        self.set_act_scales(new)
+        return True
 
     def close(self):
         if getattr(self, "_h", None):
@@ -245,6 +301,7 @@ class HipSdfDecoder:
         elif not self.nerf_features and any(f != 3 for f in self._pf):
             raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
         self._latent = lat   # keep the device buffer alive until the next set_sample
+        self._bound = (latent_vec, embed)
         with torch.cuda.device(self.device):
             _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
                           "asdf_decoder_set_sample")
@@ -284,13 +341,23 @@ class HipSdfDecoder:
                 if self.event_log is not None:
                     self.event_log.append(ev)
 
-        if guard:
-            self.range_violations(clear=True)       # earlier sweeps answer for themselves
+        # The first split-half sweep of a decoder calibrates the activation scales from the peaks it leaves in the status
+        # record (one stream synchronisation, once per decoder); a bbox-less sweep is additionally guarded.
+        first = self.math == "f16x3" and not self._calibrated and check_range is not False
+        if guard or first:
+            self._status(clear=True)                # earlier sweeps answer for themselves
         launch()
+        if first:
+            st = self._status(clear=False)
+            if self.calibrate(st):
+                self._status(clear=True)
+                launch()                            # the calibrated image; its own report is read below / by the caller
         if guard:
-            bad = self.range_violations(clear=True)
-            if bad:
-                self._to_f32(bad)
+            for _ in range(5):
+                st = self._status(clear=True)
+                if not int(st[0]):
+                    break
+                self._recover(int(st[0]), st)
                 launch()
         return hand, obj, bbox
 

@@ -109,8 +109,8 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     def second_pass(bbox):
         b = bbox.cpu().numpy()                          # waits for pass 1: the zoom cube is data dependent
-        if hip.fall_back_if_overflowed(b):              # split-half arithmetic out of fp16 range: the decoder is still
-            # bound to this sample and now on the fp32 kernel - repeat its pass 1
+        while hip.fall_back_if_overflowed(b):           # split-half planes out of fp16 range: the decoder is still bound to
+            # this sample, re-calibrated (or at last on the fp32 kernel) - repeat its pass 1
             b = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)[2].cpu().numpy()
         boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
         nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
@@ -123,11 +123,12 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         """Marching cubes (and the label pass) of one sample; returns True when the decoder was re-bound to it."""
         rebound = False
         bbox2 = r.pop("bbox2", None)
-        if bbox2 is not None and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
-            # pass 2 left the fp16 range: the decoder is on the fp32 kernel from here on; repeat this sample's pass 2
+        while bbox2 is not None and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
+            # pass 2 left the fp16 range: the decoder has been re-calibrated (or switched to the fp32 kernel); repeat this
+            # sample's pass 2
             bind(sample)
             rebound = True
-            r["vol_hand"], r["vol_obj"], _ = hip.decode_grid(N, r["origin"], float(r["voxel_size"]), mode, want_bbox=False, hand=hb, obj=ob)
+            r["vol_hand"], r["vol_obj"], bbox2 = hip.decode_grid(N, r["origin"], float(r["voxel_size"]), mode, want_bbox=True, hand=hb, obj=ob)
         for part, on in (("hand", hb), ("obj", ob)):
             r["V_" + part] = r["F_" + part] = 0
             if on:

@@ -268,8 +268,8 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     # head is not evaluated at all (the reference computes and discards it)
     _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
     b = bbox.cpu().numpy()
-    if hip.fall_back_if_overflowed(b):          # split-half arithmetic out of fp16 range: repeat on the fp32 kernel
-        _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
+    while hip.fall_back_if_overflowed(b):       # split-half planes out of fp16 range: re-calibrated (or, at last, on the
+        _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)   # fp32 kernel)
         b = bbox.cpu().numpy()
     boxes = []
     if hand_branch:
@@ -281,9 +281,9 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     guard = hip.math == "f16x3"
     vol_hand, vol_obj, bbox2 = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=guard,
                                                hand=hand_branch, obj=obj_branch)
-    if guard and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
-        vol_hand, vol_obj, _ = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=False,
-                                               hand=hand_branch, obj=obj_branch)
+    while guard and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
+        vol_hand, vol_obj, bbox2 = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=True,
+                                                   hand=hand_branch, obj=obj_branch)
     return {"vol_hand": vol_hand, "vol_obj": vol_obj, "voxel_size": new_voxel_size, "origin": new_origin.tolist(), "bbox": b}
 
 

@@ -149,11 +149,21 @@ int asdf_decoder_time_next_sweep(asdf_decoder_t* dec, void* event_start, void* e
 
 /* Range report of the split-half arithmetic that does NOT depend on a bbox buffer: every ASDF_MATH_F16X3 launch of this
  * decoder adds the number of (point, lane-half) pairs whose hidden activations left the fp16 range (or whose output is not
- * in [-1, 1]) to a device word the decoder owns.  Copies the record to out_host[4] ([0] = that count, [1] = near-level
- * voxels beyond the refinement list's capacity, [2..3] reserved),
+ * in [-1, 1]) to a device word the decoder owns.  Copies the record to out_host[16] ([0] = that count, [1] = near-level
+ * voxels beyond the refinement list's capacity, [4..6] / [8..10] = the largest fp16-plane value x S_x handed to the
+ * conversion for the activation vectors h0 / h1 / h2 of MLP 0 / MLP 1, as float bit patterns, the rest reserved),
  * optionally clears it, and synchronises `stream`.  A caller that sweeps without a bbox buffer (deep_sdf/mesh.py:14-61
  * has no zoom pass) checks this once per volume and repeats the sweep under ASDF_MATH_F32 when the count is non-zero. */
-int asdf_decoder_status(asdf_decoder_t* dec, int32_t out_host[4], int32_t clear, void* stream);
+int asdf_decoder_status(asdf_decoder_t* dec, int32_t out_host[16], int32_t clear, void* stream);
+
+/* Activation scales S_x of the split-half image, per MLP and activation vector (h0, h1, h2): every hidden activation x is
+ * carried as the two fp16 planes of x S_x.  The default 8 suits activations of order 1e-2 .. 1e3; a caller calibrates them
+ * from the peak plane values asdf_decoder_status reports after a sweep over the whole cube (pass 1): S_x such that the peak
+ * lands in [1024, 2048) keeps a factor 32 below the fp16 maximum while every activation down to 2^-13 of the layer's peak
+ * keeps two full planes (22 significand bits).  Powers of two in [2^-24, 2^24]; the static constants of the image are
+ * rebuilt (stream is synchronised first) and the per-sample constants are invalidated: call asdf_decoder_set_sample again. */
+int asdf_decoder_set_act_scales(asdf_decoder_t* dec, const float sx[ASDF_MAX_HEADS][3], void* stream);
+int asdf_decoder_get_act_scales(const asdf_decoder_t* dec, float sx_out[ASDF_MAX_HEADS][3]);
 
 /* ---- Part classifier (specs["ClassifierBranch"]): classifier_head = nn.Linear(512, num_class) applied to the last
  * hidden activation of the hand MLP (SeparateDecoder, networks/model.py:257-259,306-307) or of the single MLP
@@ -232,7 +242,7 @@ int asdf_debug_grid_coords(int32_t N, const float origin[3], float voxel_size, i
 
 /* ---- Test hook (host only, needs no device): run the weight packer of asdf_decoder_create and copy
  * its images out (any pointer may be NULL).  Sizes in floats: stream 256*4096, wlat 2*2*512*256,
- * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6916 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */
+ * wpt 2*2*512*ASDF_MAX_POINT_FEATS, bias02 2*2*512, cst 2*(6920 + 2048*(KP-2)) with KP = 2 (affine) or ceil(pf/2), embed 2*ASDF_MAX_POINT_FEATS*4. */
 int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, float* stream,
                          float* wlat, float* wpt, float* bias02, float* cst, float* embed);
 /* The split-half image of the same decoder (ASDF_MATH_F16X3): stream16 2*128*8192 fp16 bit

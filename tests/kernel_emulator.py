@@ -23,7 +23,7 @@ def offsets(kp):
     a2 = 16 * kp * 64
     c0 = 2 * a2
     return dict(A0=0, A2=a2, C0=c0, B1=c0 + 512, C2=c0 + 768, B3=c0 + 1280, W4=c0 + 1792, W4B=c0 + 2304, B4=c0 + 2816,
-                FLOATS=c0 + 2820)
+                FLOATS=c0 + 2824)
 LANE = np.arange(64)
 HALF = LANE >> 5
 ROW = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in range(2)] for r in range(16)])   # [r][half]
@@ -239,7 +239,7 @@ def run_wave16(pk, cst, xyz32):
     for head in range(len(pk["pf"])):
         c = cst[head]
         sbase = head * 128
-        mul1, mul2 = c[OFF["B4"] + 2], c[OFF["B4"] + 3]
+        mul1, mul2, mul0 = c[OFF["B4"] + 2], c[OFF["B4"] + 3], c[OFF["B4"] + 4]
 
         def planes(accs, mul):
             """list of per-K-block (hi, lo) operand planes [64][8] from a layer's output tiles"""
@@ -272,7 +272,7 @@ def run_wave16(pk, cst, xyz32):
             for s in range(2):
                 acc = mfma(c[OFF["A0"] + (t * 2 + s) * 64: OFF["A0"] + (t * 2 + s) * 64 + 64], bp[s], acc)
             l0.append(acc)
-        h0 = planes(l0, ACT_SCALE)
+        h0 = planes(l0, mul0)
         h1 = planes(layer(8, 4, 0, h0, OFF["B1"]), mul1)
         h2 = planes(layer(16, 2, 32, h1, OFF["C2"], OFF["A2"]), mul2)
         h3 = layer(16, 4, 64, h2, OFF["B3"])

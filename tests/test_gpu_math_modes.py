@@ -91,60 +91,44 @@ def test_split_half_layer_scales_vs_oracle():
         hip.close()
 
 
-def test_fp16_overflow_is_detected_and_falls_back(tmp_path):
-    """Activations beyond the fp16 range (|x| >= 8188) cannot be carried by the split-half planes: the kernel counts the
-    resulting out-of-range outputs in bbox words 7 / 15 and the two-pass drivers repeat the pass on the fp32 kernel."""
-    from alignsdf_amd.hip_decoder import HipSdfDecoder
+def test_fp16_overflow_is_detected_and_recovered(tmp_path):
+    """Activations beyond the fp16 range of the planes at the current scale (|x| S_x >= 65504) cannot be carried: the kernel
+    counts them in bbox words 7 / 15 and in the status word; the two-pass drivers re-calibrate the activation scales from
+    the recorded peaks and repeat the pass (the fp32 kernel is the last resort, test_gpu_split_half_adversarial.py)."""
     from alignsdf_amd.utils.mesh import decode_two_pass
-    from oracle import sdf_oracle as orc
     specs = syn.specs_for("nerf3")
-    base = syn.full_state_dict("nerf3")
-    sd = {}
-    for head in "ho":
-        for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
-            sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
-        # blow layer 0's outputs up by 4096 and undo it in layer 1: same function, activations of order 1e4
-        sd["lin%s0.weight" % head] *= np.float32(4096.0)
-        sd["lin%s0.bias" % head] *= np.float32(4096.0)
-        sd["lin%s1.weight" % head] /= np.float32(4096.0)
-    hip = HipSdfDecoder(sd, 256, 3, "nerf")
+    hip = _overflowing_decoder()
+    hip._calibrated = True                     # skip the first-sweep calibration: the guard itself is under test
     lat = torch.from_numpy(syn.latent_code(0)).cuda()
     hip.set_sample(lat)
     _, _, bbox = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
     b = bbox.cpu().numpy()
     assert b[7] > 0 and b[15] > 0 and hip.math == "f16x3"
     r = decode_two_pass(True, True, hip, lat, None, None, specs, 32)
-    assert hip.math == "f32" and r["bbox"][7] == 0 and r["bbox"][15] == 0
+    assert hip.math == "f16x3" and hip.act_scales()[0, 0] < 8.0 and r["bbox"][7] == 0 and r["bbox"][15] == 0
     g = np.load(str(__import__("pathlib").Path(__file__).parent / "golden" / "ref_decoder_nerf3.npz"))
     assert np.array_equal(np.stack([r["bbox"][0:6], r["bbox"][8:14]]), g["bbox_32"])
+    assert np.abs(r["vol_hand"].cpu().numpy() - g["vol2_hand_32"]).max() <= TOL
     hip.close()
 
 
 def test_fp16_overflow_in_the_sample_pipeline(golden_dir):
-    """The same decoder through pipelined_two_pass: the first sample trips the range report in pass 1, the pipeline
-    repeats the pass on the fp32 kernel and every sample comes out as the reference's volumes."""
-    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    """The same decoder through pipelined_two_pass, once with the first-sweep calibration and once with the range report
+    tripping in pass 1 of the first sample: every sample comes out as the reference's volumes, on the split-half kernel."""
     from alignsdf_amd.reconstruct import pipelined_two_pass
-    from oracle import sdf_oracle as orc
     specs = syn.specs_for("nerf3")
-    base = syn.full_state_dict("nerf3")
-    sd = {}
-    for head in "ho":
-        for layer, (w, b) in enumerate(orc.effective_head_params(base, head)):
-            sd["lin%s%d.weight" % (head, layer)], sd["lin%s%d.bias" % (head, layer)] = w.numpy().copy(), b.numpy().copy()
-        sd["lin%s0.weight" % head] *= np.float32(4096.0)
-        sd["lin%s0.bias" % head] *= np.float32(4096.0)
-        sd["lin%s1.weight" % head] /= np.float32(4096.0)
-    hip = HipSdfDecoder(sd, 256, 3, "nerf")
-    lat = torch.from_numpy(syn.latent_code(0)).cuda()
-    out = list(pipelined_two_pass(hip, specs, [(k, lat, None, None) for k in range(3)], 32))
-    assert hip.math == "f32" and len(out) == 3
     g = np.load(golden_dir + "/ref_decoder_nerf3.npz")
-    for _, r in out:
-        assert np.abs(r["vol_hand"].cpu().numpy() - g["vol2_hand_32"]).max() <= TOL
-        assert np.abs(r["vol_obj"].cpu().numpy() - g["vol2_obj_32"]).max() <= TOL
-        assert r["V_hand"] > 0 and r["V_obj"] > 0
-    hip.close()
+    for skip_calibration in (False, True):
+        hip = _overflowing_decoder()
+        hip._calibrated = skip_calibration
+        lat = torch.from_numpy(syn.latent_code(0)).cuda()
+        out = list(pipelined_two_pass(hip, specs, [(k, lat, None, None) for k in range(3)], 32))
+        assert hip.math == "f16x3" and len(out) == 3 and hip.act_scales()[0, 0] < 8.0
+        for _, r in out:
+            assert np.abs(r["vol_hand"].cpu().numpy() - g["vol2_hand_32"]).max() <= TOL
+            assert np.abs(r["vol_obj"].cpu().numpy() - g["vol2_obj_32"]).max() <= TOL
+            assert r["V_hand"] > 0 and r["V_obj"] > 0
+        hip.close()
 
 
 def test_set_math_argument_checks(native_lib):
@@ -206,7 +190,7 @@ def _overflowing_decoder(factor=4096.0):
 
 def test_range_report_does_not_need_a_bbox(native_lib, golden_dir):
     """A C-ABI caller that passes bbox_dev = NULL still learns about an fp16 range violation: the decoder-owned status word
-    (asdf_decoder_status) counts it.  The host wrapper's bbox-less sweep reads it and repeats on the fp32 kernel."""
+    (asdf_decoder_status) counts it.  The host wrapper's bbox-less sweep reads it, re-calibrates and repeats."""
     import ctypes
     hip = _overflowing_decoder()
     hip.set_sample(torch.from_numpy(syn.latent_code(0)).cuda())
@@ -223,8 +207,9 @@ def test_range_report_does_not_need_a_bbox(native_lib, golden_dir):
     assert hip.math == "f16x3"                       # the raw call decides nothing; the caller does
     # the guarded wrapper: same sweep, no bbox -> falls back and returns the reference's volumes
     g = np.load(golden_dir + "/ref_decoder_nerf3.npz")
+    hip._calibrated = True                       # no first-sweep calibration: the guard has to catch it
     h2, o2, none = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1), want_bbox=False)
-    assert none is None and hip.math == "f32"
+    assert none is None and hip.math == "f16x3" and hip.act_scales()[0, 0] < 8.0      # recovered by re-calibration
     assert np.abs(h2.cpu().numpy() - g["vol1_hand_32"]).max() <= TOL and np.abs(o2.cpu().numpy() - g["vol1_obj_32"]).max() <= TOL
     hip.close()
 
@@ -251,8 +236,9 @@ def test_legacy_create_mesh_is_guarded(tmp_path, golden_dir, monkeypatch):
         return real(vol, origin, vs, path)
 
     monkeypatch.setattr(legacy, "convert_sdf_samples_to_ply", spy)
+    hip._calibrated = True                       # the guard of the bbox-less sweep, not the first-sweep calibration
     pts, faces = legacy.create_mesh(hip, torch.from_numpy(syn.latent_code(0)).cuda(), str(tmp_path / "legacy"), N=32)
-    assert hip.math == "f32"
+    assert hip.math == "f16x3" and hip.act_scales()[0, 0] < 8.0
     assert np.abs(seen["vol"] - g["vol_32"]).max() <= TOL
     assert len(pts) > 0 and len(faces) > 0 and (tmp_path / "legacy.ply").exists()
     hip.close()
@@ -262,6 +248,7 @@ def test_fallback_decision_rests_on_the_record_alone():
     """once the decoder has switched to fp32, a bbox record of an EARLIER split-half sweep must still trigger the
     repeat of that sweep (the pipeline queues pass 1 of sample k+1 before it reads pass 2 of sample k)."""
     hip = _overflowing_decoder()
+    hip._calibrated = True
     hip.set_sample(torch.from_numpy(syn.latent_code(0)).cuda())
     _, _, bbox = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)            # queued under f16x3
     hip.set_math("f32")                                                        # ... another sweep's report arrives first

@@ -1,6 +1,6 @@
 """Dump the split-half weight stream and the folded per-sample constants of the synthetic decoder (what K1h reads in the
 product) for tools/k1h_ablate.hip:  python tools/dump_k1h_inputs.py [tag]  ->  tools/bin/k1h_<tag>.bin
-Layout: stream16 (uint16, 2 heads x 128 x 8192) followed by cst16 (float32, 2 x 6916)."""
+Layout: stream16 (uint16, 2 heads x 128 x 8192) followed by cst16 (float32, 2 x 6920)."""
 import os
 import sys
 
