@@ -83,14 +83,35 @@ __global__ void bbox_init_kernel(int* bbox) {   // 16 ints: two records of {min[
 
 // K2 (standalone form; K1 fuses the same reduction into its epilogue): bounding box of the voxels with
 // sdf < 0 - torch.nonzero + per-axis min/max of get_higher_res_cube (utils/mesh.py:208-237).
-__global__ __launch_bounds__(256) void neg_bbox_kernel(const float* __restrict__ vol, long long n, int n1, int n2, int* bbox) {
+// One wave per (i0, i1) row: the row index is wave-uniform (no per-voxel division), lanes stride over axis 2 with float4
+// loads when the row length allows; HBM-bound streaming read (4 n bytes).  `flag`: when non-null the kernel is a no-op
+// unless *flag != 0 (the conditional recount behind the near-level refinement).
+__global__ __launch_bounds__(256) void neg_bbox_kernel(const float* __restrict__ vol, int n0, int n1, int n2, int* bbox, const int* flag) {
+  if (flag && *flag == 0) return;
+  const int lane = threadIdx.x & 63;
+  const long long rows = (long long)n0 * n1;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * (blockDim.x >> 6);
   int lo0 = 0x7fffffff, lo1 = 0x7fffffff, lo2 = 0x7fffffff, hi0 = -1, hi1 = -1, hi2 = -1, cnt = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    if (vol[i] < 0.0f) {
-      const int i2 = (int)(i % n2), i1 = (int)((i / n2) % n1), i0 = (int)((i / n2) / n1);
-      lo0 = min(lo0, i0); lo1 = min(lo1, i1); lo2 = min(lo2, i2);
-      hi0 = max(hi0, i0); hi1 = max(hi1, i1); hi2 = max(hi2, i2);
-      ++cnt;
+  const bool vec = (n2 & 3) == 0 && ((size_t)vol & 15) == 0;
+  for (long long r = wave0; r < rows; r += nwaves) {
+    const float* row = vol + r * n2;
+    int rlo = 0x7fffffff, rhi = -1, rc = 0;
+    if (vec) {
+      for (int x = lane * 4; x < n2; x += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(row + x);
+        if (q.x < 0.0f) { rlo = min(rlo, x); rhi = max(rhi, x); ++rc; }
+        if (q.y < 0.0f) { rlo = min(rlo, x + 1); rhi = max(rhi, x + 1); ++rc; }
+        if (q.z < 0.0f) { rlo = min(rlo, x + 2); rhi = max(rhi, x + 2); ++rc; }
+        if (q.w < 0.0f) { rlo = min(rlo, x + 3); rhi = max(rhi, x + 3); ++rc; }
+      }
+    } else {
+      for (int x = lane; x < n2; x += 64)
+        if (row[x] < 0.0f) { rlo = min(rlo, x); rhi = max(rhi, x); ++rc; }
+    }
+    if (rc) {
+      const int i0 = (int)(r / n1), i1 = (int)(r % n1);
+      lo0 = min(lo0, i0); hi0 = max(hi0, i0); lo1 = min(lo1, i1); hi1 = max(hi1, i1);
+      lo2 = min(lo2, rlo); hi2 = max(hi2, rhi); cnt += rc;
     }
   }
 #pragma unroll
@@ -99,10 +120,21 @@ __global__ __launch_bounds__(256) void neg_bbox_kernel(const float* __restrict__
     hi0 = max(hi0, __shfl_xor(hi0, m)); hi1 = max(hi1, __shfl_xor(hi1, m)); hi2 = max(hi2, __shfl_xor(hi2, m));
     cnt += __shfl_xor(cnt, m);
   }
-  if ((threadIdx.x & 63) == 0 && cnt) {
-    atomicMin(bbox + 0, lo0); atomicMin(bbox + 1, lo1); atomicMin(bbox + 2, lo2);
-    atomicMax(bbox + 3, hi0); atomicMax(bbox + 4, hi1); atomicMax(bbox + 5, hi2);
-    atomicAdd(bbox + 6, cnt);
+  // one set of atomics per WORKGROUP (a set per wave on seven hot words serialised 16 k waves: 0.8 ms)
+  __shared__ int s_rec[4][7];
+  const int w = threadIdx.x >> 6;
+  if (lane == 0) { s_rec[w][0] = lo0; s_rec[w][1] = lo1; s_rec[w][2] = lo2; s_rec[w][3] = hi0; s_rec[w][4] = hi1; s_rec[w][5] = hi2; s_rec[w][6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      lo0 = min(lo0, s_rec[k][0]); lo1 = min(lo1, s_rec[k][1]); lo2 = min(lo2, s_rec[k][2]);
+      hi0 = max(hi0, s_rec[k][3]); hi1 = max(hi1, s_rec[k][4]); hi2 = max(hi2, s_rec[k][5]); cnt += s_rec[k][6];
+    }
+    if (cnt) {
+      atomicMin(bbox + 0, lo0); atomicMin(bbox + 1, lo1); atomicMin(bbox + 2, lo2);
+      atomicMax(bbox + 3, hi0); atomicMax(bbox + 4, hi1); atomicMax(bbox + 5, hi2);
+      atomicAdd(bbox + 6, cnt);
+    }
   }
 }
 
@@ -133,7 +165,8 @@ __global__ __launch_bounds__(256) void collect_near_level_kernel(const float* __
   }
 }
 
-__global__ void bbox_reinit_keep_flags_kernel(int* bbox) {   // words 7 / 15 (the fp16 range report) survive
+__global__ void bbox_reinit_keep_flags_kernel(int* bbox, const int* flag) {   // words 7 / 15 (the fp16 range report) survive
+  if (flag && *flag == 0) return;
   const int i = threadIdx.x;
   if (i < 16 && (i & 7) != 7) {
     const int j = i & 7;
@@ -165,7 +198,8 @@ struct asdf_decoder {
   int math;
   bool sample_bound;
   int* status;      // [16] device words: [0] = lanes whose activations left the fp16 range in split-half launches since the
-                    // last clear, [1] = near-level voxels that did not fit the refinement list, [4..6] / [8..10] = largest
+                    // last clear, [1] = near-level voxels that did not fit the refinement list, [2] = scratch flag of the
+                    // refinement (a voxel left the negative set: recount the box), [4..6] / [8..10] = largest
                     // plane value (float bits) of h0 / h1 / h2 of MLP 0 / MLP 1
   // activation scales of the split-half image (asdf_decoder_set_act_scales) and what is needed to rebuild its constants
   float sw[ASDF_MAX_HEADS][3];
@@ -197,7 +231,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 113; }
+int asdf_version(void) { return 114; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -310,9 +344,9 @@ int asdf_neg_bbox(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, int3
   if (!vol_dev || !bbox_dev || n0 < 1 || n1 < 1 || n2 < 1) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bbox_dev);
-  const long long n = (long long)n0 * n1 * n2;
-  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(neg_bbox_kernel, dim3(grid), dim3(256), 0, st, vol_dev, n, n1, n2, bbox_dev);
+  const long long rows = (long long)n0 * n1;
+  const int grid = (int)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
+  hipLaunchKernelGGL(neg_bbox_kernel, dim3(grid), dim3(256), 0, st, vol_dev, n0, n1, n2, bbox_dev, (const int*)nullptr);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }
@@ -417,16 +451,22 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
       const int cgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
       hipLaunchKernelGGL(collect_near_level_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, p.P, d->refine_tau, d->near_idx,
                          d->near_count, kNearCap, d->status);
+      ASDF_HIP(hipMemsetAsync(d->status + 2, 0, sizeof(int), st));      // the "box may shrink" flag of this sweep
       DecodeParams q = p;
-      q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr;
+      q.stream = d->stream; q.cst = d->cst; q.bbox = p.bbox; q.fixup_flag = p.bbox ? d->status + 2 : nullptr;
       q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
       const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
       k1_launch(d->kp, two_out, q, rgrid, st);
-      if (p.bbox) {      // the fused box saw the unrefined values: recount on the volumes (the range report words stay)
-        hipLaunchKernelGGL(bbox_reinit_keep_flags_kernel, dim3(1), dim3(64), 0, st, p.bbox);
-        const int bgrid = (int)((p.P + 255) / 256 < 2048 ? (p.P + 255) / 256 : 2048);
-        if (p.sdf0) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf0, p.P, p.N, p.N, p.bbox);
-        if (p.sdf1) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf1, p.P, p.N, p.N, p.bbox + 8);
+      if (p.bbox) {
+        // the fused box saw the unrefined values.  The refinement pass patches it in place - a voxel that became negative
+        // extends the box and the count exactly - and raises a flag when one became non-negative (the box may have to
+        // shrink): only then do the three kernels below recount on the refined volumes (the range report words stay).
+        const int* flag = d->status + 2;
+        hipLaunchKernelGGL(bbox_reinit_keep_flags_kernel, dim3(1), dim3(64), 0, st, p.bbox, flag);
+        const long long rows = (long long)p.N * p.N;
+        const int bgrid = (int)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
+        if (p.sdf0) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf0, p.N, p.N, p.N, p.bbox, flag);
+        if (p.sdf1) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf1, p.N, p.N, p.N, p.bbox + 8, flag);
       }
     }
   } else {

@@ -5,18 +5,26 @@
 // edge and shares it through per-layer lookup arrays.  Every cell adjacent to an intersected edge
 // references it, so "first reference" is decidable locally: the owner of an edge is the adjacent
 // in-bounds cell that comes first in scan order (axis 0 slowest).  That makes the output - vertex
-// order, face order, vertex ids - reproducible in parallel, element for element:
-//   K3 mc_classify    one thread per 4 x-consecutive cells (float4 corner-row loads): MC33 case selection
-//                     (mc33_common.h) -> 32-bit cell codes (tiling offset, #triangles, #owned vertices) in
-//                     row-padded scan order; per-block totals; volume min/max
-//   K4 mc_scan_blocks exclusive scan of the per-block totals (one workgroup)
-//   K5 mc_emit_verts  in-block scan + block base -> vertex ids; interpolate owned vertices (fp64, as
-//                     the routine does), publish their ids in a per-grid-edge table
-//   K6 mc_emit_faces  same scan for triangles; look the three vertex ids up and write the face
-//                     (K5 / K6 blocks whose 1024 cell slots hold nothing return immediately)
-// All four are HBM-bound streaming kernels: 4 B read per voxel in K3, 4 B per cell code in K5/K6.
+// order, face order, vertex ids - reproducible in parallel, element for element.
+//
+// Round-2 chain (three streaming kernels + one single-block reduction; round 1 wrote a 4-byte code for EVERY cell and
+// scanned 16 k block totals in one workgroup - 262 us per 256^3 volume, 3x the algorithmic traffic):
+//   K3 mc_classify     one thread per 4 x-consecutive cells (float4 corner-row loads): MC33 case selection
+//                      (mc33_common.h).  Only ACTIVE cells leave the kernel: each workgroup compacts its active cells
+//                      (in scan order) into a segment of a global list it reserves with one atomicAdd, and adds its
+//                      triangle / vertex totals and the volume's min / max to one of ~sqrt(#blocks) super-block slots.
+//                      HBM traffic = the 4 N^3 volume read.
+//   K4 mc_finalize     ONE workgroup over the super-block slots (128 at N = 256): grand totals, min / max, exclusive
+//                      bases per super-block; publishes (V, F, min, max) to the header and - without any host
+//                      synchronisation - to mapped pinned host memory when the caller passed some.
+//   K5 mc_emit_verts   one wave per non-empty block: base = super-block base + the totals of the blocks in front of it
+//                      inside the super-block (a 128-term wave sum), wave scan over the block's active cells -> vertex
+//                      ids; fp64 interpolation of the owned vertices (as the routine does); ids published per grid edge
+//   K6 mc_emit_faces   the same walk for triangles; three id look-ups per face
+// K5 / K6 touch only active cells (about 1 % of the cells of an SDF volume): 12 V + 12 F bytes written + the id table.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "../../include/alignsdf_hip.h"
@@ -31,7 +39,9 @@ constexpr int kMcThreads = 256;
 constexpr int kMcCellsPerThread = 4;
 constexpr int kMcChunk = kMcThreads * kMcCellsPerThread;   // cells per workgroup
 
-// cell code: [13:0] tiling offset in kMcTiles, [17:14] #triangles, [21:18] #owned (new) vertices
+// cell code: [13:0] tiling offset in kMcTiles, [17:14] #triangles, [21:18] #owned (new) vertices; in the compacted list
+// bits [31:22] carry the cell's slot inside its workgroup (0 .. 1023)
+static_assert(kMcTilesSize < (1 << 14), "tiling offsets must fit 14 bits");
 __device__ __forceinline__ unsigned code_pack(int off, int nt, int nv) { return (unsigned)off | (nt << 14) | (nv << 18); }
 __device__ __forceinline__ int code_off(unsigned c) { return c & 0x3fff; }
 __device__ __forceinline__ int code_nt(unsigned c) { return (c >> 14) & 15; }
@@ -42,15 +52,23 @@ struct McHeader {          // first 64 bytes of the workspace
   unsigned total_verts;
   unsigned min_key;        // order-preserving keys of the volume's min / max
   unsigned max_key;
-  unsigned pad[12];
+  unsigned active_total;   // reservation counter of the compacted active-cell list
+  unsigned pad[11];
+};
+
+struct McSuper {           // one slot per super-block (zero-initialised): sums by atomicAdd, min as max of the complement;
+  unsigned tris, verts, inv_min_key, max_key;      // `active` reserves segments of the super-block's own region of the
+  unsigned active, pad[3];                         // compacted list (one hot counter for all blocks serialised them: 70 us)
 };
 
 struct McDims {
   int nx, ny, nz;          // nx = fastest axis (axis 2)
   int cx, cy, cz;          // cells per axis
   int cxp;                 // cells per row padded to a multiple of 4 (one thread classifies 4 x-consecutive cells)
-  long long nslots;        // cxp * cy * cz cell slots, row-major = scan order; padding slots carry code 0
+  long long nslots;        // cxp * cy * cz cell slots, row-major = scan order; padding slots are never active
   int nblocks;
+  int sb_shift;            // a super-block = 2^sb_shift consecutive blocks (about sqrt(nblocks))
+  int nsuper;
 };
 
 __device__ __forceinline__ unsigned float_key(float f) {
@@ -105,79 +123,132 @@ __device__ __forceinline__ void load_row5(const float* __restrict__ row, int x0,
   }
 }
 
-__global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restrict__ vol, McDims d, double level,
-                                                          uint4* __restrict__ code4, uint2* __restrict__ block_tot,
-                                                          uint2* __restrict__ block_minmax) {
-  __shared__ unsigned s_tri[kMcThreads / 64], s_vert[kMcThreads / 64], s_min[kMcThreads / 64], s_max[kMcThreads / 64];
-  unsigned ntri = 0, nvert = 0;
+__global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restrict__ vol, McDims d, double level, float level_f, McHeader* hdr,
+                                                          McSuper* __restrict__ super, uint2* __restrict__ block_tot,
+                                                          uint2* __restrict__ block_seg, unsigned* __restrict__ compact) {
+  __shared__ unsigned s_tri[kMcThreads / 64], s_vert[kMcThreads / 64], s_min[kMcThreads / 64], s_max[kMcThreads / 64], s_act[kMcThreads / 64];
+  __shared__ unsigned s_seg;
+  unsigned ntri = 0, nvert = 0, nact = 0;
   float lo = INFINITY, hi = -INFINITY;
+  unsigned cc[4] = {0, 0, 0, 0};
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long group = (long long)blockIdx.x * kMcThreads + threadIdx.x;     // 4 x-consecutive cell slots
-  if (group * 4 < d.nslots) {
-    int x0, y, z;
-    cell_coords(d, group * 4, x0, y, z);
+  const bool live = group * 4 < d.nslots;
+  int x0 = 0, y = 0, z = 0;
+  if (live) cell_coords(d, group * 4, x0, y, z);
+  {
+    // four corner rows (z,y) (z,y+1) (z+1,y) (z+1,y+1), 5 values each: a float4 per row, and the fifth value is the NEXT
+    // lane's first (same row, next 4 cells) - a cross-lane move instead of a second, 4-byte-per-lane load instruction; only
+    // the last lane of the wave and the last group of a row load it themselves
     const bool vec = (d.nx & 3) == 0 && ((size_t)vol & 15) == 0;
     const float* r00 = vol + ((size_t)z * d.ny + y) * d.nx;
-    float a[4][5];      // rows (z,y) (z,y+1) (z+1,y) (z+1,y+1)
-    load_row5(r00, x0, d.nx, vec, a[0]);
-    load_row5(r00 + d.nx, x0, d.nx, vec, a[1]);
-    load_row5(r00 + (size_t)d.ny * d.nx, x0, d.nx, vec, a[2]);
-    load_row5(r00 + (size_t)d.ny * d.nx + d.nx, x0, d.nx, vec, a[3]);
-    unsigned cc[4] = {0, 0, 0, 0};
+    const float* rows[4] = {r00, r00 + d.nx, r00 + (size_t)d.ny * d.nx, r00 + (size_t)d.ny * d.nx + d.nx};
+    float a[4][5];
+    const bool neighbour = vec && lane < 63 && x0 + 4 < d.cxp;     // lane + 1 holds (x0 + 4 .. x0 + 7) of the same rows
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = x0 + i;
-      if (x >= d.cx) break;
-      // corners v0..v7: (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) and the same at z+1
-      const float c[8] = {a[0][i], a[0][i + 1], a[1][i + 1], a[1][i], a[2][i], a[2][i + 1], a[3][i + 1], a[3][i]};
-      bool any_hi = false, any_lo = false;
+    for (int r = 0; r < 4; ++r) {
+      if (vec) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) q = *reinterpret_cast<const float4*>(rows[r] + x0);
+        a[r][0] = q.x; a[r][1] = q.y; a[r][2] = q.z; a[r][3] = q.w;
+        const float nxt = __shfl_down(q.x, 1);
+        a[r][4] = neighbour ? nxt : ((live && x0 + 4 < d.nx) ? rows[r][x0 + 4] : 0.0f);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        lo = fminf(lo, c[k]); hi = fmaxf(hi, c[k]);
-        const bool above = (double)c[k] - level > 0.0;
-        any_hi |= above; any_lo |= !above;
-      }
-      if (any_hi && any_lo) {
-        // the deciders index the corner array dynamically (it lives in scratch): only active cells pay for it
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (double)c[k] - level;
-        int off;
-        const int nt = mc33_select_tiling(v, &off);
-        int nv = 0;
-        unsigned seen = 0;
-        for (int k = 0; k < 3 * nt; ++k) {
-          const int e = kMcTiles[off + k];
-          if (seen & (1u << e)) continue;
-          seen |= 1u << e;
-          if (e == 12 || owns_edge(e, x, y, z)) ++nv;
-        }
-        cc[i] = code_pack(off, nt, nv);
-        ntri += nt; nvert += nv;
+        for (int i = 0; i < 5; ++i) a[r][i] = (live && x0 + i < d.nx) ? rows[r][x0 + i] : 0.0f;
       }
     }
-    code4[group] = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+    if (live) {
+      // Sign bits of the 20 loaded values in fp32: c > level (in double, as the routine compares) <=> c > level_f, with
+      // level_f the largest float <= level (computed on the host).  A cell is active iff its 8 corner bits are mixed.
+      // The volume's min / max is taken over the loaded values once, not per cell corner (this kernel is VALU-bound: the
+      // fp64 compare + min + max per corner per cell of round 1 were 3/4 of its instructions).
+      unsigned bits[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bits[r] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          if (x0 + i < d.nx) { lo = fminf(lo, a[r][i]); hi = fmaxf(hi, a[r][i]); }      // (entries beyond the row are padding)
+          bits[r] |= (a[r][i] > level_f ? 1u : 0u) << i;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + i;
+        if (x >= d.cx) break;
+        const unsigned m0 = (bits[0] >> i) & 3, m1 = (bits[1] >> i) & 3, m2 = (bits[2] >> i) & 3, m3 = (bits[3] >> i) & 3;
+        if ((m0 | m1 | m2 | m3) != 0 && (m0 & m1 & m2 & m3) != 3) {
+          // corners v0..v7: (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) and the same at z+1
+          const float c[8] = {a[0][i], a[0][i + 1], a[1][i + 1], a[1][i], a[2][i], a[2][i + 1], a[3][i + 1], a[3][i]};
+          // the deciders index the corner array dynamically (it lives in scratch): only active cells pay for it
+          double v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (double)c[k] - level;
+          int off;
+          const int nt = mc33_select_tiling(v, &off);
+          int nv = 0;
+          unsigned seen = 0;
+          for (int k = 0; k < 3 * nt; ++k) {
+            const int e = kMcTiles[off + k];
+            if (seen & (1u << e)) continue;
+            seen |= 1u << e;
+            if (e == 12 || owns_edge(e, x, y, z)) ++nv;
+          }
+          if (nt > 0) {                       // ("impossible case 13" cells emit nothing and are not listed)
+            cc[i] = code_pack(off, nt, nv) | ((unsigned)(4 * threadIdx.x + i) << 22);
+            ntri += nt; nvert += nv; ++nact;
+          }
+        }
+      }
+    }
   }
-  // workgroup totals
+  // workgroup totals + exclusive scan of the active counts (thread order = scan order)
   unsigned klo = float_key(lo), khi = float_key(hi);
+  unsigned inc = nact;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const unsigned t = __shfl_up(inc, m);
+    if (lane >= m) inc += t;
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     ntri += __shfl_xor(ntri, m); nvert += __shfl_xor(nvert, m);
     klo = min(klo, (unsigned)__shfl_xor((int)klo, m)); khi = max(khi, (unsigned)__shfl_xor((int)khi, m));
   }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_tri[w] = ntri; s_vert[w] = nvert; s_min[w] = klo; s_max[w] = khi; }
+  if (lane == 63) s_act[w] = inc;
+  if (lane == 0) { s_tri[w] = ntri; s_vert[w] = nvert; s_min[w] = klo; s_max[w] = khi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned t = 0, vv = 0, a2 = 0xffffffffu, b2 = 0;
-    for (int i = 0; i < kMcThreads / 64; ++i) { t += s_tri[i]; vv += s_vert[i]; a2 = min(a2, s_min[i]); b2 = max(b2, s_max[i]); }
+    unsigned t = 0, vv = 0, a2 = 0xffffffffu, b2 = 0, act = 0;
+    for (int i = 0; i < kMcThreads / 64; ++i) { t += s_tri[i]; vv += s_vert[i]; a2 = min(a2, s_min[i]); b2 = max(b2, s_max[i]); act += s_act[i]; }
+    McSuper* sp = super + (blockIdx.x >> d.sb_shift);
+    atomicMax(&sp->inv_min_key, ~a2);
+    atomicMax(&sp->max_key, b2);
+    unsigned seg = 0;
+    if (act) {
+      // the super-block's region of the list starts at (first block of the super-block) * kMcChunk: room for every cell
+      seg = (unsigned)(((blockIdx.x >> d.sb_shift) << d.sb_shift) * kMcChunk) + atomicAdd(&sp->active, act);
+      atomicAdd(&sp->tris, t);
+      atomicAdd(&sp->verts, vv);
+    }
     block_tot[blockIdx.x] = make_uint2(t, vv);
-    block_minmax[blockIdx.x] = make_uint2(a2, b2);     // reduced by mc_scan_blocks (one hot atomic word would serialise)
+    block_seg[blockIdx.x] = make_uint2(seg, act);
+    s_seg = seg;
+  }
+  __syncthreads();
+  if (nact) {
+    unsigned pos = s_seg + inc - nact;
+    for (int k = 0; k < w; ++k) pos += s_act[k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (cc[i]) compact[pos++] = cc[i];
   }
 }
 
-// exclusive scan of the per-block totals into block_base by one workgroup; grand totals into the header
-__global__ __launch_bounds__(1024) void mc_scan_blocks(const uint2* __restrict__ block_sums, uint2* __restrict__ block_base,
-                                                       const uint2* __restrict__ block_minmax, int nblocks, McHeader* hdr) {
+// One workgroup over the super-block slots: grand totals, volume min / max, exclusive bases per super-block.
+__global__ __launch_bounds__(1024) void mc_finalize(const McSuper* __restrict__ super, uint2* __restrict__ super_base, int nsuper,
+                                                    McHeader* hdr, unsigned* result_mapped) {
   __shared__ uint2 s_wave[16];
   __shared__ uint2 s_carry;
   __shared__ unsigned s_lo[16], s_hi[16];
@@ -185,10 +256,10 @@ __global__ __launch_bounds__(1024) void mc_scan_blocks(const uint2* __restrict__
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned klo = 0xffffffffu, khi = 0;
-  for (int start = 0; start < nblocks; start += 1024) {
+  for (int start = 0; start < nsuper; start += 1024) {
     const int i = start + threadIdx.x;
-    uint2 v = i < nblocks ? block_sums[i] : make_uint2(0, 0);
-    if (i < nblocks) { const uint2 mm = block_minmax[i]; klo = min(klo, mm.x); khi = max(khi, mm.y); }
+    uint2 v = make_uint2(0, 0);
+    if (i < nsuper) { const McSuper s = super[i]; v = make_uint2(s.tris, s.verts); klo = min(klo, ~s.inv_min_key); khi = max(khi, s.max_key); }
     uint2 inc = v;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -199,7 +270,7 @@ __global__ __launch_bounds__(1024) void mc_scan_blocks(const uint2* __restrict__
     __syncthreads();
     uint2 pre = s_carry;
     for (int k = 0; k < w; ++k) { pre.x += s_wave[k].x; pre.y += s_wave[k].y; }
-    if (i < nblocks) block_base[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
+    if (i < nsuper) super_base[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = make_uint2(pre.x + inc.x, pre.y + inc.y);
     __syncthreads();
@@ -213,26 +284,40 @@ __global__ __launch_bounds__(1024) void mc_scan_blocks(const uint2* __restrict__
   if (threadIdx.x == 0) {
     for (int k = 1; k < 16; ++k) { klo = min(klo, s_lo[k]); khi = max(khi, s_hi[k]); }
     hdr->total_tris = s_carry.x; hdr->total_verts = s_carry.y; hdr->min_key = klo; hdr->max_key = khi;
+    if (result_mapped) {
+      result_mapped[0] = s_carry.y; result_mapped[1] = s_carry.x; result_mapped[2] = klo; result_mapped[3] = khi;
+      __threadfence_system();
+    }
   }
 }
 
-// exclusive scan of `val` over the workgroup's 256 threads, plus running carry
-__device__ __forceinline__ unsigned block_excl_scan(unsigned val, unsigned* s_wave, unsigned& carry) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+constexpr int kEmitThreads = 64;      // one wave per block of 1024 cell slots: a non-empty block holds ~30 active cells
+
+// first output id of `block`: the super-block's base + the totals of the blocks in front of it inside the super-block
+__device__ __forceinline__ uint2 block_first_ids(const McDims& d, int block, const uint2* __restrict__ super_base,
+                                                 const uint2* __restrict__ block_tot) {
+  const int lane = threadIdx.x & 63;
+  const int first = (block >> d.sb_shift) << d.sb_shift;
+  uint2 acc = make_uint2(0, 0);
+  for (int b = first + lane; b < block; b += 64) { const uint2 t = block_tot[b]; acc.x += t.x; acc.y += t.y; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); }
+  const uint2 sb = super_base[block >> d.sb_shift];
+  return make_uint2(sb.x + acc.x, sb.y + acc.y);
+}
+
+// exclusive scan of `val` over one wave plus running carry
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned val, unsigned& carry) {
+  const int lane = threadIdx.x & 63;
   unsigned inc = val;
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) {
     const unsigned a = __shfl_up(inc, m);
     if (lane >= m) inc += a;
   }
-  if (lane == 63) s_wave[w] = inc;
-  __syncthreads();
-  unsigned pre = carry;
-  for (int k = 0; k < w; ++k) pre += s_wave[k];
-  const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-  __syncthreads();
-  carry += total;
-  return pre + inc - val;
+  const unsigned out = carry + inc - val;
+  carry += __shfl(inc, 63);
+  return out;
 }
 
 __device__ __forceinline__ size_t vid_slot(const McDims& d, int e, int x, int y, int z) {
@@ -241,22 +326,21 @@ __device__ __forceinline__ size_t vid_slot(const McDims& d, int e, int x, int y,
   return 4 * (((size_t)ez * d.ny + ey) * d.nx + ex) + MC33_EDGE_AXIS(e);
 }
 
-__global__ __launch_bounds__(kMcThreads) void mc_emit_verts(const float* __restrict__ vol, McDims d, double level,
-                                                            const unsigned* __restrict__ code,
-                                                            const uint2* __restrict__ block_tot,
-                                                            const uint2* __restrict__ block_base, unsigned* __restrict__ vid,
-                                                            float* __restrict__ verts) {
-  __shared__ unsigned s_wave[kMcThreads / 64];
+__global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __restrict__ vol, McDims d, double level,
+                                                              const unsigned* __restrict__ compact, const uint2* __restrict__ block_tot,
+                                                              const uint2* __restrict__ block_seg, const uint2* __restrict__ super_base,
+                                                              unsigned* __restrict__ vid, float* __restrict__ verts) {
   if (block_tot[blockIdx.x].y == 0) return;             // no vertex is owned by this block's 1024 cell slots
-  unsigned carry = block_base[blockIdx.x].y;
+  const uint2 seg = block_seg[blockIdx.x];
+  unsigned carry = block_first_ids(d, blockIdx.x, super_base, block_tot).y;
   const long long base = (long long)blockIdx.x * kMcChunk;
-  for (int i = 0; i < kMcCellsPerThread; ++i) {
-    const long long cell = base + i * kMcThreads + threadIdx.x;
-    const unsigned cc = cell < d.nslots ? code[cell] : 0;
-    unsigned id = block_excl_scan(code_nv(cc), s_wave, carry);
+  for (unsigned i0 = 0; i0 < seg.y; i0 += kEmitThreads) {
+    const unsigned i = i0 + threadIdx.x;
+    const unsigned cc = i < seg.y ? compact[seg.x + i] : 0;
+    unsigned id = wave_excl_scan(code_nv(cc), carry);
     if (code_nv(cc) == 0) continue;
     int x, y, z;
-    cell_coords(d, cell, x, y, z);
+    cell_coords(d, base + (cc >> 22), x, y, z);
     double v[8];
     load_corners(vol, d, x, y, z, level, v);
     const int off = code_off(cc), nt = code_nt(cc);
@@ -293,22 +377,22 @@ __global__ __launch_bounds__(kMcThreads) void mc_emit_verts(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(kMcThreads) void mc_emit_faces(McDims d, const unsigned* __restrict__ code,
-                                                            const uint2* __restrict__ block_tot,
-                                                            const uint2* __restrict__ block_base,
-                                                            const unsigned* __restrict__ vid, int* __restrict__ faces) {
-  __shared__ unsigned s_wave[kMcThreads / 64];
-  if (block_tot[blockIdx.x].x == 0) return;             // no triangle in this block's 1024 cell slots
-  unsigned carry = block_base[blockIdx.x].x;
+__global__ __launch_bounds__(kEmitThreads) void mc_emit_faces(McDims d, const unsigned* __restrict__ compact,
+                                                              const uint2* __restrict__ block_tot, const uint2* __restrict__ block_seg,
+                                                              const uint2* __restrict__ super_base, const unsigned* __restrict__ vid,
+                                                              int* __restrict__ faces) {
+  const uint2 seg = block_seg[blockIdx.x];
+  if (seg.y == 0) return;                               // no active cell in this block's 1024 cell slots
+  unsigned carry = block_first_ids(d, blockIdx.x, super_base, block_tot).x;
   const long long base = (long long)blockIdx.x * kMcChunk;
-  for (int i = 0; i < kMcCellsPerThread; ++i) {
-    const long long cell = base + i * kMcThreads + threadIdx.x;
-    const unsigned cc = cell < d.nslots ? code[cell] : 0;
-    const unsigned tri0 = block_excl_scan(code_nt(cc), s_wave, carry);
+  for (unsigned i0 = 0; i0 < seg.y; i0 += kEmitThreads) {
+    const unsigned i = i0 + threadIdx.x;
+    const unsigned cc = i < seg.y ? compact[seg.x + i] : 0;
     const int nt = code_nt(cc);
+    const unsigned tri0 = wave_excl_scan(nt, carry);
     if (nt == 0) continue;
     int x, y, z;
-    cell_coords(d, cell, x, y, z);
+    cell_coords(d, base + (cc >> 22), x, y, z);
     const int off = code_off(cc);
     for (int t = 0; t < nt; ++t) {
       int* f = faces + 3 * (size_t)(tri0 + t);
@@ -322,7 +406,7 @@ __global__ __launch_bounds__(kMcThreads) void mc_emit_faces(McDims d, const unsi
 
 struct McLayout {
   McDims d;
-  size_t off_code, off_sums, off_base, off_minmax, off_vid, total;
+  size_t off_super, off_sbase, off_tot, off_seg, off_compact, off_vid, total, zero_bytes;
 };
 
 static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
@@ -334,15 +418,33 @@ static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
   d.cxp = (d.cx + 3) & ~3;
   d.nslots = (long long)d.cxp * d.cy * d.cz;
   d.nblocks = (int)((d.nslots + kMcChunk - 1) / kMcChunk);
+  d.sb_shift = 0;
+  while ((1ll << (2 * d.sb_shift)) < d.nblocks) ++d.sb_shift;          // 2^shift >= sqrt(nblocks)
+  d.nsuper = (d.nblocks + (1 << d.sb_shift) - 1) >> d.sb_shift;
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = align(sizeof(McHeader));
-  L.off_code = o; o = align(o + sizeof(unsigned) * (size_t)d.nblocks * kMcChunk);
-  L.off_sums = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
-  L.off_base = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
-  L.off_minmax = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_super = o; o = align(o + sizeof(McSuper) * (size_t)d.nsuper);
+  L.zero_bytes = o;                                                   // header + super-block slots are zeroed per volume
+  L.off_sbase = o; o = align(o + sizeof(uint2) * (size_t)d.nsuper);
+  L.off_tot = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_seg = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_compact = o; o = align(o + sizeof(unsigned) * (size_t)d.nblocks * kMcChunk);      // worst case: every cell active
   L.off_vid = o; o = align(o + sizeof(unsigned) * 4 * (size_t)n0 * n1 * n2);
   L.total = o;
   return true;
+}
+
+static int mc_count_enqueue(const float* vol, const McLayout& L, double level, void* ws, unsigned* result_mapped, hipStream_t st) {
+  char* w = (char*)ws;
+  ASDF_HIP(hipMemsetAsync(w, 0, L.zero_bytes, st));
+  float level_f = (float)level;                 // largest float <= level: for a float c, (double)c > level <=> c > level_f
+  if ((double)level_f > level) level_f = std::nextafterf(level_f, -INFINITY);
+  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, level_f, (McHeader*)w, (McSuper*)(w + L.off_super),
+                     (uint2*)(w + L.off_tot), (uint2*)(w + L.off_seg), (unsigned*)(w + L.off_compact));
+  hipLaunchKernelGGL(mc_finalize, dim3(1), dim3(1024), 0, st, (const McSuper*)(w + L.off_super), (uint2*)(w + L.off_sbase), L.d.nsuper,
+                     (McHeader*)w, result_mapped);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
 }
 
 }  // namespace asdf
@@ -358,31 +460,38 @@ int asdf_mc_workspace_bytes(int32_t n0, int32_t n1, int32_t n2, size_t* bytes) {
   return ASDF_OK;
 }
 
+int asdf_mc_count_enqueue(const float* vol, int32_t n0, int32_t n1, int32_t n2, double level, void* ws, size_t ws_bytes,
+                          uint32_t* result_mapped, void* stream) {
+  McLayout L;
+  if (!vol || !ws || !mc_layout(n0, n1, n2, L)) return ASDF_EINVAL;
+  if (ws_bytes < L.total) return ASDF_ENOSPC;
+  return mc_count_enqueue(vol, L, level, ws, result_mapped, (hipStream_t)stream);
+}
+
+int asdf_mc_result_status(const uint32_t result[4], double level) {
+  if (!result) return ASDF_EINVAL;
+  // skimage: ValueError when level is outside [min, max]; RuntimeError when nothing was produced
+  const double lo = key_float(result[2]), hi = key_float(result[3]);
+  if (level < lo || level > hi) return ASDF_ERANGE;
+  if (result[0] == 0) return ASDF_ENOSURF;
+  return ASDF_OK;
+}
+
 int asdf_mc_count(const float* vol, int32_t n0, int32_t n1, int32_t n2, double level, void* ws, size_t ws_bytes,
                   uint32_t* num_verts, uint32_t* num_faces, void* stream) {
   McLayout L;
   if (!vol || !ws || !num_verts || !num_faces || !mc_layout(n0, n1, n2, L)) return ASDF_EINVAL;
   if (ws_bytes < L.total) return ASDF_ENOSPC;
   hipStream_t st = (hipStream_t)stream;
-  char* w = (char*)ws;
-  McHeader* hdr = (McHeader*)w;
-  uint4* code4 = (uint4*)(w + L.off_code);
-  uint2* sums = (uint2*)(w + L.off_sums);
-  uint2* base = (uint2*)(w + L.off_base);
-  uint2* minmax = (uint2*)(w + L.off_minmax);
-  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code4, sums, minmax);
-  hipLaunchKernelGGL(mc_scan_blocks, dim3(1), dim3(1024), 0, st, sums, base, minmax, L.d.nblocks, hdr);
-  ASDF_HIP(hipGetLastError());
+  const int rc = mc_count_enqueue(vol, L, level, ws, nullptr, st);
+  if (rc != ASDF_OK) return rc;
   McHeader h;
-  ASDF_HIP(hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+  ASDF_HIP(hipMemcpyAsync(&h, ws, sizeof(h), hipMemcpyDeviceToHost, st));
   ASDF_HIP(hipStreamSynchronize(st));
   *num_verts = h.total_verts;
   *num_faces = h.total_tris;
-  // skimage: ValueError when level is outside [min, max]; RuntimeError when nothing was produced
-  const double lo = key_float(h.min_key), hi = key_float(h.max_key);
-  if (level < lo || level > hi) return ASDF_ERANGE;
-  if (h.total_verts == 0) return ASDF_ENOSURF;
-  return ASDF_OK;
+  const uint32_t r[4] = {h.total_verts, h.total_tris, h.min_key, h.max_key};
+  return asdf_mc_result_status(r, level);
 }
 
 int asdf_mc_emit(const float* vol, int32_t n0, int32_t n1, int32_t n2, double level, void* ws, size_t ws_bytes,
@@ -392,12 +501,13 @@ int asdf_mc_emit(const float* vol, int32_t n0, int32_t n1, int32_t n2, double le
   if (ws_bytes < L.total) return ASDF_ENOSPC;
   hipStream_t st = (hipStream_t)stream;
   char* w = (char*)ws;
-  unsigned* code = (unsigned*)(w + L.off_code);
-  uint2* sums = (uint2*)(w + L.off_sums);
-  uint2* base = (uint2*)(w + L.off_base);
+  const unsigned* compact = (const unsigned*)(w + L.off_compact);
+  const uint2* tot = (const uint2*)(w + L.off_tot);
+  const uint2* seg = (const uint2*)(w + L.off_seg);
+  const uint2* sbase = (const uint2*)(w + L.off_sbase);
   unsigned* vid = (unsigned*)(w + L.off_vid);
-  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, code, sums, base, vid, verts);
-  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, L.d, code, sums, base, vid, faces);
+  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, vol, L.d, level, compact, tot, seg, sbase, vid, verts);
+  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, L.d, compact, tot, seg, sbase, vid, faces);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }

@@ -59,6 +59,8 @@ struct DecodeParams {
   const int* idx;           // kGridSubset: [<= P] linear lattice indices
   const int* count_dev;     // kGridSubset: number of listed points (device word; P is the capacity)
   int grid_mode;            // kGridSubset: kGridReference / kGridInteger of the lattice
+  int* fixup_flag;          // kGridSubset with bbox: the outputs REPLACE earlier values - the box is patched in place (a voxel
+                            // that turns negative extends it) and *fixup_flag is raised when one turns non-negative
   int* status;              // decoder-owned status record: [0] += lanes whose activations left the fp16 range (K1h only)
   long long P;              // number of query points
   int N;                    // grid resolution (P == N^3 for grid modes)

@@ -300,6 +300,23 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       const bool is_hand = head == 0;
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
+        if (p.mode == kGridSubset && p.bbox) {
+          // refinement of an existing volume: patch the negative-voxel box for every sign change instead of recounting
+          auto patch = [&](float* vol, float now, int* rec) {
+            const bool was = vol[po] < 0.0f, is = now < 0.0f;
+            if (was == is) return;
+            if (is) {
+              const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
+              atomicMin(rec + 0, i0); atomicMin(rec + 1, i1); atomicMin(rec + 2, i2);
+              atomicMax(rec + 3, i0); atomicMax(rec + 4, i1); atomicMax(rec + 5, i2);
+              atomicAdd(rec + 6, 1);
+            } else {
+              atomicExch(p.fixup_flag, 1);        // the box may have to shrink: the caller recounts
+            }
+          };
+          if (out) patch(out, sdf, p.bbox + (is_hand ? 0 : 8));
+          if (combined && p.sdf1) patch(p.sdf1, sdfb, p.bbox + 8);
+        }
         if (out) out[po] = sdf;
         if (combined && p.sdf1) p.sdf1[po] = sdfb;
       }
@@ -322,7 +339,7 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
           if (p.labels) p.labels[pi] = best;
         }
       }
-      if (p.bbox && valid && half == 0 && p.mode != kPointList) {
+      if (p.bbox && valid && half == 0 && p.mode != kPointList && p.mode != kGridSubset) {
         const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
         if (sdf < 0.0f) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);

@@ -73,7 +73,7 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     midpoint(key, result), if given, is called for sample k between queuing pass 2 of sample k+1 and pass 1 of sample
     k+2: GPU work it enqueues (the eval-mode ICP of sample k's hand mesh) lands between two decoder passes instead of
     behind both, and its host part is covered by the pass that is already running."""
-    from .marching_cubes import marching_cubes_device
+    from .marching_cubes import marching_cubes_begin, marching_cubes_finish
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
     from .utils.utils import bind_sample, decoder_for
     it = iter(samples)
@@ -129,11 +129,13 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
             bind(sample)
             rebound = True
             r["vol_hand"], r["vol_obj"], bbox2 = hip.decode_grid(N, r["origin"], float(r["voxel_size"]), mode, want_bbox=True, hand=hb, obj=ob)
+        # count phases of both volumes first (no host synchronisation), then one wait, then the emits
+        tickets = {part: marching_cubes_begin(r["vol_" + part], 0.0, slot) for slot, (part, on) in enumerate((("hand", hb), ("obj", ob))) if on}
         for part, on in (("hand", hb), ("obj", ob)):
             r["V_" + part] = r["F_" + part] = 0
             if on:
                 try:
-                    v, f = marching_cubes_device(r["vol_" + part], 0.0)
+                    v, f = marching_cubes_finish(tickets[part])
                 except (ValueError, RuntimeError) as e:         # the reference logs and skips (utils/mesh.py:353-358)
                     r["mc_error_" + part] = str(e)
                     continue

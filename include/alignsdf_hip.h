@@ -190,6 +190,14 @@ int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doub
                   size_t workspace_bytes, uint32_t* num_verts, uint32_t* num_faces, void* stream);
 int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                  size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
+/* The count phase without any host synchronisation: classify + reduce are enqueued and the last kernel writes
+ * result[0] = V, result[1] = F, result[2..3] = order-preserving keys of the volume's min / max into result_mapped -
+ * device-accessible HOST memory (hipHostMalloc / a pinned torch tensor; NULL = header only).  The caller records an event,
+ * keeps queuing (the count of the next volume, ...), waits on the event when it needs the sizes, maps them to skimage's
+ * two failure modes with asdf_mc_result_status (ASDF_ERANGE / ASDF_ENOSURF / ASDF_OK), allocates and calls asdf_mc_emit. */
+int asdf_mc_count_enqueue(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
+                          size_t workspace_bytes, uint32_t* result_mapped, void* stream);
+int asdf_mc_result_status(const uint32_t result[4], double level);
 
 /* ---- Largest-component filter of utils/mesh.py:371-381 (trimesh.graph.split(only_watertight=True) + largest area) on
  * a marching-cubes surface: verts_dev [V][3] fp32 lattice-unit vertices, faces_dev [F][3] int32.  Faces are adjacent when
