@@ -83,10 +83,13 @@ __host__ inline float key_float(unsigned k) {
 }
 
 __device__ __forceinline__ void cell_coords(const McDims& d, long long slot, int& x, int& y, int& z) {
-  x = (int)(slot % d.cxp);
-  const long long r = slot / d.cxp;
-  y = (int)(r % d.cy);
-  z = (int)(r / d.cy);
+  // 32-bit arithmetic (mc_layout bounds the slot count): a 64-bit division is a ~100-instruction routine on this ISA, and
+  // two of them per thread were most of mc_classify's instruction stream
+  const unsigned s = (unsigned)slot, cxp = (unsigned)d.cxp, cy = (unsigned)d.cy;
+  const unsigned r = s / cxp;
+  x = (int)(s - r * cxp);
+  z = (int)(r / cy);
+  y = (int)(r - (unsigned)z * cy);
 }
 
 // Is cell (x,y,z) the first cell in scan order that touches cell-local edge e ?
@@ -411,7 +414,7 @@ struct McLayout {
 
 static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
   if (n0 < 2 || n1 < 2 || n2 < 2) return false;
-  if ((long long)n0 * n1 * n2 > (1ll << 31)) return false;
+  if ((long long)n0 * n1 * n2 > (1ll << 31) || (long long)((n2 + 2) & ~3) * n1 * n0 >= (1ll << 32)) return false;
   McDims& d = L.d;
   d.nx = n2; d.ny = n1; d.nz = n0;
   d.cx = n2 - 1; d.cy = n1 - 1; d.cz = n0 - 1;
