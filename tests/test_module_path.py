@@ -73,3 +73,47 @@ def test_variant_through_the_sample_pipeline_and_files(tmp_path):
     assert stats["hand"][1] > 100 and stats["obj"][1] > 100 and (tmp_path / "s_hand.ply").exists() and (tmp_path / "s_obj.ply").exists()
     out = list(pipelined_two_pass(dec, specs, [(k, latent.cuda(), None, None) for k in range(2)], 32))
     assert [k for k, _ in out] == [0, 1] and all(r["F_hand"] == stats["hand"][1] and r["F_obj"] == stats["obj"][1] for _, r in out)
+
+
+def test_model_output_adapter_contract():
+    """model_output_code_source: decode_model_output's return triple -> the (latent, mano, obj) the drivers consume."""
+    from alignsdf_amd.frontend import model_output_code_source
+    m, o = syn.pose_inputs(0)
+    mano = {k: torch.from_numpy(v) for k, v in m.items()}
+    mano.update(verts=torch.zeros(1, 778, 3), joints=torch.zeros(1, 21, 3), shape=torch.zeros(1, 10), pcas=torch.zeros(1, 15))
+    obj = {k: torch.from_numpy(v) for k, v in o.items()}
+    src = model_output_code_source(lambda name, i: (torch.from_numpy(syn.latent_code(i)).double(), mano, obj), device="cpu")
+    lat, mm, oo = src("00000012", 3)
+    assert lat.dtype == torch.float32 and lat.shape == (1, 256) and set(mm) == {"global_trans", "rot_center", "joints"} and set(oo) == {"obj_trans"}
+    lat, mm, oo = model_output_code_source(lambda name, i: (torch.zeros(1, 256), None, None), device="cpu")("x", 0)
+    assert mm is None and oo is None
+
+
+def test_resnet18_like_shapes_cpu():
+    from alignsdf_amd.frontend import ResNet18Like
+    enc = ResNet18Like().eval()
+    with torch.no_grad():
+        z = enc(torch.zeros(1, 3, 64, 64))
+    assert z.shape == (1, 256) and sum(p.numel() for p in enc.parameters()) > 11_000_000
+
+
+@pytest.mark.gpu
+def test_encoder_in_the_sample_pipeline():
+    """Codes produced on the device by an encoder in the loop (no host synchronisation) give the same surfaces as the same
+    codes fed as resident tensors."""
+    from alignsdf_amd.frontend import ResNet18Like, encoder_code_source
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass
+    specs = syn.specs_for("nerf3")
+    dec = HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
+    torch.manual_seed(1)
+    enc = ResNet18Like().cuda().eval()
+    imgs = [torch.rand(1, 3, 128, 128) for _ in range(3)]
+    src = encoder_code_source(enc, lambda name, i: imgs[i])
+    with torch.no_grad():
+        fixed = [enc(im.cuda()).clone() for im in imgs]
+    a = list(pipelined_two_pass(dec, specs, ((i, *src("s", i)) for i in range(3)), 32))
+    b = list(pipelined_two_pass(dec, specs, ((i, fixed[i], None, None) for i in range(3)), 32))
+    for (_, ra), (_, rb) in zip(a, b):        # (the convolutions need not be bit-reproducible from call to call)
+        assert (ra["vol_hand"] - rb["vol_hand"]).abs().max().item() <= 1e-5 and abs(ra["F_obj"] - rb["F_obj"]) <= 16
+    dec.close()
