@@ -48,3 +48,22 @@ def test_ply_roundtrip(tmp_path):
     assert np.array_equal(v2, v) and np.array_equal(f2, f)
     head = open(tmp_path / "a.ply", "rb").read(200).decode("ascii", "ignore")
     assert head.startswith("ply\nformat binary_little_endian 1.0") and "property list uchar int vertex_indices" in head
+
+
+def test_surface_sampler_is_area_weighted_and_uniform_inside_faces():
+    """The seeded stand-in for trimesh.sample.sample_surface (utils/mesh.py:336 of the reference samples 30 000 points
+    with it, unseeded): faces picked in proportion to their area, points uniform inside a face, always on the face."""
+    from alignsdf_amd.icp import sample_surface
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [3, 0, 5], [3, 3, 5], [0, 3, 5.0]])
+    f = np.array([[0, 1, 2], [3, 4, 5]])                  # areas 0.5 and 4.5, planes z = 0 and z = 5
+    n = 200000
+    p = sample_surface(v, f, n, 3)
+    on0, on1 = p[:, 2] == 0.0, p[:, 2] == 5.0
+    assert np.all(on0 | on1)
+    assert abs(on0.mean() - 0.1) < 4 * np.sqrt(0.1 * 0.9 / n)
+    q = p[on0][:, :2]                                     # uniform on the unit right triangle: E[x] = E[y] = 1/3, E[xy] = 1/12
+    assert np.all(q >= 0) and np.all(q.sum(1) <= 1 + 1e-12)
+    m = len(q)
+    assert np.all(np.abs(q.mean(0) - 1 / 3) < 5 * np.sqrt(1 / 18) / np.sqrt(m))
+    assert abs((q[:, 0] * q[:, 1]).mean() - 1 / 12) < 5 * 0.08 / np.sqrt(m)
+    assert np.array_equal(p, sample_surface(v, f, n, 3)) and not np.array_equal(p, sample_surface(v, f, n, 4))
