@@ -9,14 +9,14 @@
 //
 // Round-2 chain (three streaming kernels + one single-block reduction; round 1 wrote a 4-byte code for EVERY cell and
 // scanned 16 k block totals in one workgroup - 262 us per 256^3 volume, 3x the algorithmic traffic):
-//   K3 mc_classify     one thread per 4 x-consecutive cells (float4 corner-row loads): MC33 case selection
-//                      (mc33_common.h).  Only ACTIVE cells leave the kernel: each workgroup compacts its active cells
-//                      (in scan order) into a segment of a global list it reserves with one atomicAdd, and adds its
-//                      triangle / vertex totals and the volume's min / max to one of ~sqrt(#blocks) super-block slots.
-//                      HBM traffic = the 4 N^3 volume read.
-//   K4 mc_finalize     ONE workgroup over the super-block slots (128 at N = 256): grand totals, min / max, exclusive
-//                      bases per super-block; publishes (V, F, min, max) to the header and - without any host
-//                      synchronisation - to mapped pinned host memory when the caller passed some.
+//   K3 mc_classify     one thread per 4 x-consecutive cells (float4 corner-row loads): sign patterns, tiling of an active
+//                      cell from one table word (mc33_direct.h) or, for the ambiguous MC33 cases, the deciders of
+//                      mc33_common.h.  Only ACTIVE cells leave the kernel: each workgroup compacts its active cells (in
+//                      scan order) into its own 1024 slots of a list and writes one record per block (triangle / vertex
+//                      totals, active count, min / max).  No atomics.  HBM traffic = the 4 N^3 volume read.
+//   K4 mc_finalize     ONE workgroup over the block records: totals per super-block (~sqrt(#blocks) blocks each), their
+//                      exclusive bases, grand totals, min / max; publishes (V, F, min, max) to the header and - without
+//                      any host synchronisation - to mapped pinned host memory when the caller passed some.
 //   K5 mc_emit_verts   one wave per non-empty block: base = super-block base + the totals of the blocks in front of it
 //                      inside the super-block (a 128-term wave sum), wave scan over the block's active cells -> vertex
 //                      ids; fp64 interpolation of the owned vertices (as the routine does); ids published per grid edge
@@ -32,6 +32,7 @@
 
 #define MC33_TABLE_QUAL __device__ const
 #include "mc33_common.h"
+#include "mc33_direct.h"
 
 namespace asdf {
 
@@ -52,13 +53,7 @@ struct McHeader {          // first 64 bytes of the workspace
   unsigned total_verts;
   unsigned min_key;        // order-preserving keys of the volume's min / max
   unsigned max_key;
-  unsigned active_total;   // reservation counter of the compacted active-cell list
-  unsigned pad[11];
-};
-
-struct McSuper {           // one slot per super-block (zero-initialised): sums by atomicAdd, min as max of the complement;
-  unsigned tris, verts, inv_min_key, max_key;      // `active` reserves segments of the super-block's own region of the
-  unsigned active, pad[3];                         // compacted list (one hot counter for all blocks serialised them: 70 us)
+  unsigned pad[12];
 };
 
 struct McDims {
@@ -69,6 +64,7 @@ struct McDims {
   int nblocks;
   int sb_shift;            // a super-block = 2^sb_shift consecutive blocks (about sqrt(nblocks))
   int nsuper;
+  double inv_cxp, inv_cy;  // reciprocals for cell_coords
 };
 
 __device__ __forceinline__ unsigned float_key(float f) {
@@ -82,14 +78,57 @@ __host__ inline float key_float(unsigned k) {
   return f;
 }
 
+// n / dv for n < 2^32 through one fp64 multiply with the host-computed reciprocal and a one-step correction (a 32-bit
+// integer division is a ~25-instruction VALU sequence here, a 64-bit one ~100; two per thread were most of mc_classify's
+// instruction stream in round 1).  (double)n is exact and the product is within 2^-52 relative of n / dv, so the truncated
+// quotient is off by at most one, and only next to a multiple of dv.
+__device__ __forceinline__ unsigned div_u32(unsigned n, unsigned dv, double inv, unsigned& rem) {
+  unsigned q = (unsigned)((double)n * inv);
+  int r = (int)(n - q * dv);
+  if (r < 0) { --q; r += (int)dv; }
+  else if (r >= (int)dv) { ++q; r -= (int)dv; }
+  rem = (unsigned)r;
+  return q;
+}
+
 __device__ __forceinline__ void cell_coords(const McDims& d, long long slot, int& x, int& y, int& z) {
-  // 32-bit arithmetic (mc_layout bounds the slot count): a 64-bit division is a ~100-instruction routine on this ISA, and
-  // two of them per thread were most of mc_classify's instruction stream
-  const unsigned s = (unsigned)slot, cxp = (unsigned)d.cxp, cy = (unsigned)d.cy;
-  const unsigned r = s / cxp;
-  x = (int)(s - r * cxp);
-  z = (int)(r / cy);
-  y = (int)(r - (unsigned)z * cy);
+  unsigned ux, uy;
+  const unsigned r = div_u32((unsigned)slot, (unsigned)d.cxp, d.inv_cxp, ux);
+  z = (int)div_u32(r, (unsigned)d.cy, d.inv_cy, uy);
+  x = (int)ux;
+  y = (int)uy;
+}
+
+// wave64 inclusive scan on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast:15 into rows
+// 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions with a DPP operand, where the __shfl form is six
+// ds_bpermute (LDS pipe) + address arithmetic + select.  Lane 63 holds the wave total.
+#define ASDF_DPP(old, v, ctrl, rows) (unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ unsigned wave_incl_sum(unsigned v) {
+  v += ASDF_DPP(0, v, 0x111, 0xf);
+  v += ASDF_DPP(0, v, 0x112, 0xf);
+  v += ASDF_DPP(0, v, 0x114, 0xf);
+  v += ASDF_DPP(0, v, 0x118, 0xf);
+  v += ASDF_DPP(0, v, 0x142, 0xa);
+  v += ASDF_DPP(0, v, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {       // result in lane 63
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x111, 0xf));
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x112, 0xf));
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x114, 0xf));
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x118, 0xf));
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x142, 0xa));
+  v = min(v, ASDF_DPP(0xffffffffu, v, 0x143, 0xc));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {       // result in lane 63
+  v = max(v, ASDF_DPP(0, v, 0x111, 0xf));
+  v = max(v, ASDF_DPP(0, v, 0x112, 0xf));
+  v = max(v, ASDF_DPP(0, v, 0x114, 0xf));
+  v = max(v, ASDF_DPP(0, v, 0x118, 0xf));
+  v = max(v, ASDF_DPP(0, v, 0x142, 0xa));
+  v = max(v, ASDF_DPP(0, v, 0x143, 0xc));
+  return v;
 }
 
 // Is cell (x,y,z) the first cell in scan order that touches cell-local edge e ?
@@ -104,6 +143,42 @@ __device__ __forceinline__ bool owns_edge(int e, int x, int y, int z) {
   if (axis != 2) first = first && (dz == 1 || z == 0);
   return first;
 }
+
+// bit e set <=> cell (x,y,z) owns its edge e (bit 12: the cell-centre vertex, always the cell's own)
+__device__ __forceinline__ unsigned owned_edge_mask(int x, int y, int z) {
+  unsigned own = 1u << 12;
+#pragma unroll
+  for (int e = 0; e < 12; ++e) own |= owns_edge(e, x, y, z) ? 1u << e : 0u;
+  return own;
+}
+
+// The 3 * nt edge ids of a tiling (nt <= 12) as 4-bit fields, 12 per 64-bit word (= 4 triangles), unused fields 15.
+// All byte loads of a word are issued together: walking kMcTiles entry by entry is a chain of dependent ~1 us memory
+// round trips (up to 15 of them for an ordinary cell), which is what an active cell cost in all three kernels.
+struct TilePack {
+  unsigned long long w[3];
+};
+__device__ __forceinline__ TilePack load_tiling(int off, int nt) {
+  TilePack t;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    unsigned long long w = ~0ull;
+    if (nt > 4 * g) {
+      unsigned e[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) e[k] = 12 * g + k < 3 * nt ? (unsigned)kMcTiles[off + 12 * g + k] : 15u;
+      unsigned lo = 0, hi = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lo |= e[k] << (4 * k);
+#pragma unroll
+      for (int k = 8; k < 12; ++k) hi |= e[k] << (4 * (k - 8));
+      w = ((unsigned long long)(hi | 0xffff0000u) << 32) | lo;
+    }
+    t.w[g] = w;
+  }
+  return t;
+}
+__device__ __forceinline__ unsigned tile_edge(unsigned long long w, int k) { return (unsigned)(w >> (4 * k)) & 15u; }
 
 __device__ __forceinline__ void load_corners(const float* vol, const McDims& d, int x, int y, int z, double level, double* v) {
   const float* p0 = vol + ((size_t)z * d.ny + y) * d.nx + x;
@@ -126,11 +201,16 @@ __device__ __forceinline__ void load_row5(const float* __restrict__ row, int x0,
   }
 }
 
-__global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restrict__ vol, McDims d, double level, float level_f, McHeader* hdr,
-                                                          McSuper* __restrict__ super, uint2* __restrict__ block_tot,
-                                                          uint2* __restrict__ block_seg, unsigned* __restrict__ compact) {
+#ifndef ASDF_MC_WAVES
+#define ASDF_MC_WAVES 0
+#endif
+__global__ __launch_bounds__(kMcThreads)
+#if ASDF_MC_WAVES
+__attribute__((amdgpu_waves_per_eu(ASDF_MC_WAVES, ASDF_MC_WAVES)))
+#endif
+void mc_classify(const float* __restrict__ vol, McDims d, double level, float level_f, uint2* __restrict__ block_tot,
+                 uint2* __restrict__ block_seg, uint2* __restrict__ block_minmax, unsigned* __restrict__ compact) {
   __shared__ unsigned s_tri[kMcThreads / 64], s_vert[kMcThreads / 64], s_min[kMcThreads / 64], s_max[kMcThreads / 64], s_act[kMcThreads / 64];
-  __shared__ unsigned s_seg;
   unsigned ntri = 0, nvert = 0, nact = 0;
   float lo = INFINITY, hi = -INFINITY;
   unsigned cc[4] = {0, 0, 0, 0};
@@ -148,56 +228,96 @@ __global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restric
     const float* rows[4] = {r00, r00 + d.nx, r00 + (size_t)d.ny * d.nx, r00 + (size_t)d.ny * d.nx + d.nx};
     float a[4][5];
     const bool neighbour = vec && lane < 63 && x0 + 4 < d.cxp;     // lane + 1 holds (x0 + 4 .. x0 + 7) of the same rows
+    if (vec) {
+      // ALL loads first, then the cross-lane moves: with one `if (vec)` per row the compiler put an s_waitcnt vmcnt(0) in
+      // front of every row's cross-lane move, i.e. four memory latencies in series per thread - that, not bandwidth or the
+      // instruction count, was what kept this kernel at ~100 us in the first half of round 2
+      float4 q[4];
+      float t5[4];
+      const bool own5 = live && !neighbour && x0 + 4 < d.nx;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (vec) {
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) q = *reinterpret_cast<const float4*>(rows[r] + x0);
-        a[r][0] = q.x; a[r][1] = q.y; a[r][2] = q.z; a[r][3] = q.w;
-        const float nxt = __shfl_down(q.x, 1);
-        a[r][4] = neighbour ? nxt : ((live && x0 + 4 < d.nx) ? rows[r][x0 + 4] : 0.0f);
-      } else {
+      for (int r = 0; r < 4; ++r) {
+        q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) q[r] = *reinterpret_cast<const float4*>(rows[r] + x0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t5[r] = own5 ? rows[r][x0 + 4] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r][0] = q[r].x; a[r][1] = q[r].y; a[r][2] = q[r].z; a[r][3] = q[r].w;
+        // wave_shl:1 - lane l receives lane l + 1's value (one v_mov with a DPP operand; lane 63 keeps `old`)
+        const float nxt = __uint_as_float(ASDF_DPP(0, __float_as_uint(q[r].x), 0x130, 0xf));
+        a[r][4] = neighbour ? nxt : t5[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < 5; ++i) a[r][i] = (live && x0 + i < d.nx) ? rows[r][x0 + i] : 0.0f;
-      }
     }
     if (live) {
       // Sign bits of the 20 loaded values in fp32: c > level (in double, as the routine compares) <=> c > level_f, with
-      // level_f the largest float <= level (computed on the host).  A cell is active iff its 8 corner bits are mixed.
-      // The volume's min / max is taken over the loaded values once, not per cell corner (this kernel is VALU-bound: the
-      // fp64 compare + min + max per corner per cell of round 1 were 3/4 of its instructions).
+      // level_f the largest float <= level (computed on the host).
       unsigned bits[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         bits[r] = 0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          if (x0 + i < d.nx) { lo = fminf(lo, a[r][i]); hi = fmaxf(hi, a[r][i]); }      // (entries beyond the row are padding)
-          bits[r] |= (a[r][i] > level_f ? 1u : 0u) << i;
-        }
+        for (int i = 0; i < 5; ++i) bits[r] |= (a[r][i] > level_f ? 1u : 0u) << i;
       }
+      // The volume's min / max: every value is element 0..3 of corner row 0 of exactly one thread, except the last row of
+      // a slice / the last slice (rows 1 / 2 / 3 of the threads next to them) and, when the row length is not a multiple of
+      // 4, possibly its last value (element 4 of the row's last thread).  (This kernel is VALU-bound: min + max over all 20
+      // loaded values - each value seen by four threads - and the per-corner fp64 form of round 1 before it were most of
+      // the instructions of a wave without an active cell.)
+      const bool tail = x0 + 4 < d.nx && x0 + 4 >= d.cxp;
+      auto row_minmax = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (vec || x0 + i < d.nx) { lo = fminf(lo, a[r][i]); hi = fmaxf(hi, a[r][i]); }
+        if (tail) { lo = fminf(lo, a[r][4]); hi = fmaxf(hi, a[r][4]); }
+      };
+      row_minmax(0);
+      if (y == d.cy - 1) row_minmax(1);
+      if (z == d.cz - 1) { row_minmax(2); if (y == d.cy - 1) row_minmax(3); }
+      // a cell is active iff its 8 corner bits are mixed: for the four cells at once, bit i of `any | any >> 1` = a corner of
+      // cell i is above the level, bit i of `all & all >> 1` = all of them are
+      const unsigned any = bits[0] | bits[1] | bits[2] | bits[3], all = bits[0] & bits[1] & bits[2] & bits[3];
+      const int ncell = min(4, d.cx - x0);                   // <= 0 for the padding group of a row
+      const unsigned active = ncell > 0 ? ((any | (any >> 1)) & ~(all & (all >> 1)) & ((1u << ncell) - 1)) : 0u;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int x = x0 + i;
-        if (x >= d.cx) break;
-        const unsigned m0 = (bits[0] >> i) & 3, m1 = (bits[1] >> i) & 3, m2 = (bits[2] >> i) & 3, m3 = (bits[3] >> i) & 3;
-        if ((m0 | m1 | m2 | m3) != 0 && (m0 & m1 & m2 & m3) != 3) {
-          // corners v0..v7: (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) and the same at z+1
-          const float c[8] = {a[0][i], a[0][i + 1], a[1][i + 1], a[1][i], a[2][i], a[2][i + 1], a[3][i + 1], a[3][i]};
-          // the deciders index the corner array dynamically (it lives in scratch): only active cells pay for it
-          double v[8];
+        if ((active >> i) & 1) {
+          // corner-sign pattern in the routine's corner order v0..v7: (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z), the same at z+1
+          const unsigned index = ((bits[0] >> i) & 1) | (((bits[0] >> (i + 1)) & 1) << 1) | (((bits[1] >> (i + 1)) & 1) << 2) |
+                                 (((bits[1] >> i) & 1) << 3) | (((bits[2] >> i) & 1) << 4) | (((bits[2] >> (i + 1)) & 1) << 5) |
+                                 (((bits[3] >> (i + 1)) & 1) << 6) | (((bits[3] >> i) & 1) << 7);
+          // The MC33 cases without a test - nearly every active cell of a smooth surface - take their tiling from one
+          // table word.  The deciders of the other cases are ~3000 instructions of divergent control flow (4 unrolled
+          // copies here) that a wave walks through even if one lane needs one branch of it: with every active cell sent
+          // through them, the waves that hold an active cell (30 % of them) cost as much as all the rest of the kernel.
+          const uint2 dm = *reinterpret_cast<const uint2*>(kMcDirect[index]);
+          const unsigned direct = dm.x;
+          unsigned used = dm.y;                 // cell-local edges the tiling references
+          int off = (int)(direct & 0x3fffu), nt = (int)(direct >> 14);
+          if (direct == 0xffffffffu) {
+            const float c[8] = {a[0][i], a[0][i + 1], a[1][i + 1], a[1][i], a[2][i], a[2][i + 1], a[3][i + 1], a[3][i]};
+            // the deciders index the corner array dynamically (it lives in scratch): only these cells pay for it
+            double v[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = (double)c[k] - level;
-          int off;
-          const int nt = mc33_select_tiling(v, &off);
-          int nv = 0;
-          unsigned seen = 0;
-          for (int k = 0; k < 3 * nt; ++k) {
-            const int e = kMcTiles[off + k];
-            if (seen & (1u << e)) continue;
-            seen |= 1u << e;
-            if (e == 12 || owns_edge(e, x, y, z)) ++nv;
+            for (int k = 0; k < 8; ++k) v[k] = (double)c[k] - level;
+            nt = mc33_select_tiling(v, &off);
+            const TilePack tp = load_tiling(off, nt);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+              if (nt <= 4 * g) break;
+#pragma unroll
+              for (int k = 0; k < 12; ++k) used |= 1u << tile_edge(tp.w[g], k);
+            }
           }
+          // new vertices of this cell = the distinct edges its triangles reference that the cell owns
+          const int nv = __popc(used & 0x1fffu & owned_edge_mask(x, y, z));      // new vertices = referenced edges the cell owns
           if (nt > 0) {                       // ("impossible case 13" cells emit nothing and are not listed)
             cc[i] = code_pack(off, nt, nv) | ((unsigned)(4 * threadIdx.x + i) << 22);
             ntri += nt; nvert += nv; ++nact;
@@ -207,41 +327,29 @@ __global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restric
     }
   }
   // workgroup totals + exclusive scan of the active counts (thread order = scan order)
-  unsigned klo = float_key(lo), khi = float_key(hi);
-  unsigned inc = nact;
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const unsigned t = __shfl_up(inc, m);
-    if (lane >= m) inc += t;
+  const unsigned klo = wave_min_u32(float_key(lo)), khi = wave_max_u32(float_key(hi));      // lane 63
+  unsigned inc = 0;
+  if (__ballot(nact != 0)) {            // (wave-uniform) about 70 % of the waves of an SDF volume hold no active cell
+    inc = wave_incl_sum(nact);
+    ntri = wave_incl_sum(ntri);
+    nvert = wave_incl_sum(nvert);
   }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    ntri += __shfl_xor(ntri, m); nvert += __shfl_xor(nvert, m);
-    klo = min(klo, (unsigned)__shfl_xor((int)klo, m)); khi = max(khi, (unsigned)__shfl_xor((int)khi, m));
-  }
-  if (lane == 63) s_act[w] = inc;
-  if (lane == 0) { s_tri[w] = ntri; s_vert[w] = nvert; s_min[w] = klo; s_max[w] = khi; }
+  if (lane == 63) { s_act[w] = inc; s_tri[w] = ntri; s_vert[w] = nvert; s_min[w] = klo; s_max[w] = khi; }
   __syncthreads();
+  // No atomics: a block's totals, its min / max and its active-cell count go to per-block records (mc_finalize reduces
+  // them), and its compacted cells to the block's OWN 1024 slots of the list.  (The first round-2 form reserved list
+  // segments and accumulated totals / min / max with atomics on ~sqrt(#blocks) super-block slots: the two min / max
+  // atomics of every block alone were 20 of its 52 us, the three of a non-empty block another 14 of the 37 us that the
+  // active cells of a volume cost.)
   if (threadIdx.x == 0) {
     unsigned t = 0, vv = 0, a2 = 0xffffffffu, b2 = 0, act = 0;
     for (int i = 0; i < kMcThreads / 64; ++i) { t += s_tri[i]; vv += s_vert[i]; a2 = min(a2, s_min[i]); b2 = max(b2, s_max[i]); act += s_act[i]; }
-    McSuper* sp = super + (blockIdx.x >> d.sb_shift);
-    atomicMax(&sp->inv_min_key, ~a2);
-    atomicMax(&sp->max_key, b2);
-    unsigned seg = 0;
-    if (act) {
-      // the super-block's region of the list starts at (first block of the super-block) * kMcChunk: room for every cell
-      seg = (unsigned)(((blockIdx.x >> d.sb_shift) << d.sb_shift) * kMcChunk) + atomicAdd(&sp->active, act);
-      atomicAdd(&sp->tris, t);
-      atomicAdd(&sp->verts, vv);
-    }
     block_tot[blockIdx.x] = make_uint2(t, vv);
-    block_seg[blockIdx.x] = make_uint2(seg, act);
-    s_seg = seg;
+    block_seg[blockIdx.x] = make_uint2(blockIdx.x * (unsigned)kMcChunk, act);
+    block_minmax[blockIdx.x] = make_uint2(a2, b2);
   }
-  __syncthreads();
   if (nact) {
-    unsigned pos = s_seg + inc - nact;
+    unsigned pos = blockIdx.x * (unsigned)kMcChunk + inc - nact;
     for (int k = 0; k < w; ++k) pos += s_act[k];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -249,42 +357,48 @@ __global__ __launch_bounds__(kMcThreads) void mc_classify(const float* __restric
   }
 }
 
-// One workgroup over the super-block slots: grand totals, volume min / max, exclusive bases per super-block.
-__global__ __launch_bounds__(1024) void mc_finalize(const McSuper* __restrict__ super, uint2* __restrict__ super_base, int nsuper,
-                                                    McHeader* hdr, unsigned* result_mapped) {
+// One workgroup over the per-block records: totals per super-block (a wave each), their exclusive bases, the grand totals
+// and the volume's min / max.
+__global__ __launch_bounds__(1024) void mc_finalize(const uint2* __restrict__ block_tot, const uint2* __restrict__ block_minmax, McDims d,
+                                                    uint2* __restrict__ super_base, McHeader* hdr, unsigned* result_mapped) {
+  __shared__ uint2 s_sum[1024];
   __shared__ uint2 s_wave[16];
   __shared__ uint2 s_carry;
   __shared__ unsigned s_lo[16], s_hi[16];
   if (threadIdx.x == 0) s_carry = make_uint2(0, 0);
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned klo = 0xffffffffu, khi = 0;
-  for (int start = 0; start < nsuper; start += 1024) {
-    const int i = start + threadIdx.x;
-    uint2 v = make_uint2(0, 0);
-    if (i < nsuper) { const McSuper s = super[i]; v = make_uint2(s.tris, s.verts); klo = min(klo, ~s.inv_min_key); khi = max(khi, s.max_key); }
-    uint2 inc = v;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const unsigned a = __shfl_up(inc.x, m), b = __shfl_up(inc.y, m);
-      if (lane >= m) { inc.x += a; inc.y += b; }
+  for (int start = 0; start < d.nsuper; start += 1024) {
+    // totals of super-blocks start .. start + 1023: wave w takes every 16th
+    for (int k = w; k < 1024 && start + k < d.nsuper; k += 16) {
+      const int first = (start + k) << d.sb_shift, last = min(first + (1 << d.sb_shift), d.nblocks);
+      unsigned t = 0, v = 0;
+      for (int b = first + lane; b < last; b += 64) {
+        const uint2 tv = block_tot[b], mm = block_minmax[b];
+        t += tv.x; v += tv.y;
+        klo = min(klo, mm.x); khi = max(khi, mm.y);
+      }
+      t = wave_incl_sum(t); v = wave_incl_sum(v);
+      if (lane == 63) s_sum[k] = make_uint2(t, v);
     }
+    __syncthreads();
+    const int i = start + threadIdx.x;
+    const uint2 v = i < d.nsuper ? s_sum[threadIdx.x] : make_uint2(0, 0);
+    const uint2 inc = make_uint2(wave_incl_sum(v.x), wave_incl_sum(v.y));
     if (lane == 63) s_wave[w] = inc;
     __syncthreads();
     uint2 pre = s_carry;
     for (int k = 0; k < w; ++k) { pre.x += s_wave[k].x; pre.y += s_wave[k].y; }
-    if (i < nsuper) super_base[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
+    if (i < d.nsuper) super_base[i] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = make_uint2(pre.x + inc.x, pre.y + inc.y);
     __syncthreads();
   }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    klo = min(klo, (unsigned)__shfl_xor((int)klo, m)); khi = max(khi, (unsigned)__shfl_xor((int)khi, m));
-  }
-  if (lane == 0) { s_lo[w] = klo; s_hi[w] = khi; }
+  klo = wave_min_u32(klo); khi = wave_max_u32(khi);
+  if (lane == 63) { s_lo[w] = klo; s_hi[w] = khi; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    klo = s_lo[0]; khi = s_hi[0];
     for (int k = 1; k < 16; ++k) { klo = min(klo, s_lo[k]); khi = max(khi, s_hi[k]); }
     hdr->total_tris = s_carry.x; hdr->total_verts = s_carry.y; hdr->min_key = klo; hdr->max_key = khi;
     if (result_mapped) {
@@ -303,23 +417,17 @@ __device__ __forceinline__ uint2 block_first_ids(const McDims& d, int block, con
   const int first = (block >> d.sb_shift) << d.sb_shift;
   uint2 acc = make_uint2(0, 0);
   for (int b = first + lane; b < block; b += 64) { const uint2 t = block_tot[b]; acc.x += t.x; acc.y += t.y; }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); }
+  acc.x = __builtin_amdgcn_readlane(wave_incl_sum(acc.x), 63);
+  acc.y = __builtin_amdgcn_readlane(wave_incl_sum(acc.y), 63);
   const uint2 sb = super_base[block >> d.sb_shift];
   return make_uint2(sb.x + acc.x, sb.y + acc.y);
 }
 
 // exclusive scan of `val` over one wave plus running carry
 __device__ __forceinline__ unsigned wave_excl_scan(unsigned val, unsigned& carry) {
-  const int lane = threadIdx.x & 63;
-  unsigned inc = val;
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const unsigned a = __shfl_up(inc, m);
-    if (lane >= m) inc += a;
-  }
+  const unsigned inc = wave_incl_sum(val);
   const unsigned out = carry + inc - val;
-  carry += __shfl(inc, 63);
+  carry += __builtin_amdgcn_readlane(inc, 63);
   return out;
 }
 
@@ -347,12 +455,16 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __res
     double v[8];
     load_corners(vol, d, x, y, z, level, v);
     const int off = code_off(cc), nt = code_nt(cc);
-    unsigned seen = 0;
-    for (int k = 0; k < 3 * nt; ++k) {
-      const int e = kMcTiles[off + k];
-      if (seen & (1u << e)) continue;
-      seen |= 1u << e;
-      if (!(e == 12 || owns_edge(e, x, y, z))) continue;
+    const TilePack tp = load_tiling(off, nt);
+    unsigned todo = owned_edge_mask(x, y, z);           // owned edges not emitted yet: ids follow the order of first reference
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+     if (nt <= 4 * g) break;
+     const unsigned long long tw = tp.w[g];
+     for (int k = 0; k < 12; ++k) {
+      const int e = (int)tile_edge(tw, k);
+      if (!((todo >> e) & 1)) continue;                 // (15 = unused field: never owned)
+      todo &= ~(1u << e);
       double fx = 0, fy = 0, fz = 0, ff = 0;
       if (e == 12) {
 #pragma unroll
@@ -376,6 +488,7 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __res
       o[2] = (float)((double)x + fx / ff);
       vid[vid_slot(d, e, x, y, z)] = id;
       ++id;
+     }
     }
   }
 }
@@ -396,20 +509,33 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_faces(McDims d, const un
     if (nt == 0) continue;
     int x, y, z;
     cell_coords(d, base + (cc >> 22), x, y, z);
-    const int off = code_off(cc);
-    for (int t = 0; t < nt; ++t) {
-      int* f = faces + 3 * (size_t)(tri0 + t);
-      // 'descent' orientation: the routine reverses every face
-      f[2] = (int)vid[vid_slot(d, kMcTiles[off + 3 * t + 0], x, y, z)];
-      f[1] = (int)vid[vid_slot(d, kMcTiles[off + 3 * t + 1], x, y, z)];
-      f[0] = (int)vid[vid_slot(d, kMcTiles[off + 3 * t + 2], x, y, z)];
+    const TilePack tp = load_tiling(code_off(cc), nt);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (nt <= 4 * g) break;
+      // the (up to) 12 id look-ups of four triangles are issued together
+      unsigned ids[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int e = (int)tile_edge(tp.w[g], k);
+        ids[k] = e != 15 ? vid[vid_slot(d, e, x, y, z)] : 0u;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (4 * g + t >= nt) break;
+        int* f = faces + 3 * (size_t)(tri0 + 4 * g + t);
+        // 'descent' orientation: the routine reverses every face
+        f[2] = (int)ids[3 * t + 0];
+        f[1] = (int)ids[3 * t + 1];
+        f[0] = (int)ids[3 * t + 2];
+      }
     }
   }
 }
 
 struct McLayout {
   McDims d;
-  size_t off_super, off_sbase, off_tot, off_seg, off_compact, off_vid, total, zero_bytes;
+  size_t off_sbase, off_tot, off_seg, off_minmax, off_compact, off_vid, total;
 };
 
 static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
@@ -424,13 +550,14 @@ static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
   d.sb_shift = 0;
   while ((1ll << (2 * d.sb_shift)) < d.nblocks) ++d.sb_shift;          // 2^shift >= sqrt(nblocks)
   d.nsuper = (d.nblocks + (1 << d.sb_shift) - 1) >> d.sb_shift;
+  d.inv_cxp = 1.0 / (double)d.cxp;
+  d.inv_cy = 1.0 / (double)d.cy;
   auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t o = align(sizeof(McHeader));
-  L.off_super = o; o = align(o + sizeof(McSuper) * (size_t)d.nsuper);
-  L.zero_bytes = o;                                                   // header + super-block slots are zeroed per volume
   L.off_sbase = o; o = align(o + sizeof(uint2) * (size_t)d.nsuper);
   L.off_tot = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
   L.off_seg = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
+  L.off_minmax = o; o = align(o + sizeof(uint2) * (size_t)d.nblocks);
   L.off_compact = o; o = align(o + sizeof(unsigned) * (size_t)d.nblocks * kMcChunk);      // worst case: every cell active
   L.off_vid = o; o = align(o + sizeof(unsigned) * 4 * (size_t)n0 * n1 * n2);
   L.total = o;
@@ -439,13 +566,12 @@ static bool mc_layout(int n0, int n1, int n2, McLayout& L) {
 
 static int mc_count_enqueue(const float* vol, const McLayout& L, double level, void* ws, unsigned* result_mapped, hipStream_t st) {
   char* w = (char*)ws;
-  ASDF_HIP(hipMemsetAsync(w, 0, L.zero_bytes, st));
   float level_f = (float)level;                 // largest float <= level: for a float c, (double)c > level <=> c > level_f
   if ((double)level_f > level) level_f = std::nextafterf(level_f, -INFINITY);
-  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, level_f, (McHeader*)w, (McSuper*)(w + L.off_super),
-                     (uint2*)(w + L.off_tot), (uint2*)(w + L.off_seg), (unsigned*)(w + L.off_compact));
-  hipLaunchKernelGGL(mc_finalize, dim3(1), dim3(1024), 0, st, (const McSuper*)(w + L.off_super), (uint2*)(w + L.off_sbase), L.d.nsuper,
-                     (McHeader*)w, result_mapped);
+  hipLaunchKernelGGL(mc_classify, dim3(L.d.nblocks), dim3(kMcThreads), 0, st, vol, L.d, level, level_f, (uint2*)(w + L.off_tot),
+                     (uint2*)(w + L.off_seg), (uint2*)(w + L.off_minmax), (unsigned*)(w + L.off_compact));
+  hipLaunchKernelGGL(mc_finalize, dim3(1), dim3(1024), 0, st, (const uint2*)(w + L.off_tot), (const uint2*)(w + L.off_minmax), L.d,
+                     (uint2*)(w + L.off_sbase), (McHeader*)w, result_mapped);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }
