@@ -165,6 +165,49 @@ __global__ __launch_bounds__(256) void collect_near_level_kernel(const float* __
   }
 }
 
+// The candidates of the box-only sweep: voxels whose one-plane value v is not decided by the error bound (-tau <= v < tau)
+// for a head, and which lie outside that head's box of certainly negative voxels (v < -tau) - only those can move the box.
+// Both heads of a listed voxel are re-evaluated exactly.
+__global__ __launch_bounds__(256) void collect_box_candidates_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, float tau,
+                                                                     const int* __restrict__ bbox, int* idx, int* count, int cap, int* status) {
+  const long long n = (long long)N * N * N;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int box[2][7];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) box[h][k] = bbox[8 * h + k];
+  auto outside = [&](int h, int i0, int i1, int i2) {
+    return box[h][6] == 0 || i0 < box[h][0] || i0 > box[h][3] || i1 < box[h][1] || i1 > box[h][4] || i2 < box[h][2] || i2 > box[h][5];
+  };
+  auto open = [&](float v) { return v >= -tau && v < tau; };
+  auto hit = [&](long long i) {
+    const int k = atomicAdd(count, 1);
+    if (k < cap) idx[k] = (int)i;
+    else if (status) atomicAdd(status + 1, 1);
+  };
+  const bool vec = (N & 3) == 0;
+  const long long items = vec ? n / 4 : n;
+  for (long long q = t0; q < items; q += stride) {
+    const long long i = vec ? 4 * q : q;
+    const int i2 = (int)(i % N), i1 = (int)((i / N) % N), i0 = (int)((i / N) / N);
+    float va[4] = {1.f, 1.f, 1.f, 1.f}, vb[4] = {1.f, 1.f, 1.f, 1.f};
+    if (vec) {
+      if (a) { const float4 t = reinterpret_cast<const float4*>(a)[q]; va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; }
+      if (b) { const float4 t = reinterpret_cast<const float4*>(b)[q]; vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w; }
+    } else {
+      if (a) va[0] = a[i];
+      if (b) vb[0] = b[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!vec && k > 0) break;
+      if ((a && open(va[k]) && outside(0, i0, i1, i2 + k)) || (b && open(vb[k]) && outside(1, i0, i1, i2 + k))) hit(i + k);
+    }
+  }
+}
+
 __global__ void bbox_reinit_keep_flags_kernel(int* bbox, const int* flag) {   // words 7 / 15 (the fp16 range report) survive
   if (flag && *flag == 0) return;
   const int i = threadIdx.x;
@@ -193,6 +236,7 @@ struct asdf_decoder {
   int num_class;
   // split-half image (pack_decoder_f16; kp == 2 only, null otherwise) and the arithmetic in use
   float* stream16;
+  float* stream16_hi;   // the high planes alone (1 KiB records): weight stream of the one-plane kernel (asdf_decode_grid_box)
   float* cst16;
   float s2[ASDF_MAX_HEADS];
   int math;
@@ -231,7 +275,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 114; }
+int asdf_version(void) { return 115; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -262,7 +306,7 @@ int asdf_device_count(void) {
 
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
-  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16};
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi};
   for (float* b : bufs) (void)hipFree(b);
   (void)hipFree(d->status);
   (void)hipFree(d->near_idx);
@@ -313,6 +357,14 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     up(&d->cst16, hp.cst16);
     if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->kp == 2) {
+      // records of [plane hi / lo][lane][8 halves] -> the hi halves alone, same record order
+      const size_t nrec = hp.stream16.size() / 1024;
+      std::vector<uint16_t> hi(nrec * 512);
+      for (size_t r = 0; r < nrec; ++r) std::memcpy(&hi[r * 512], &hp.stream16[r * 1024], 512 * sizeof(uint16_t));
+      e = hipMalloc((void**)&d->stream16_hi, hi.size() * sizeof(uint16_t));
+      if (e == hipSuccess) e = hipMemcpy(d->stream16_hi, hi.data(), hi.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    }
     for (int h = 0; h < kHeads; ++h) {
       d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
       for (int l = 0; l < 3; ++l) { d->sw[h][l] = h < spec->num_heads ? hp.sw[h][l] : 1.0f; d->sx[h][l] = kActScale; }
@@ -489,6 +541,52 @@ int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float 
   p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
   return launch_decode(d, p, (hipStream_t)stream);
+}
+
+int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
+                         float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream) {
+  if (!d || !origin || !bbox_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
+  if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
+  if (!d->stream16_hi || !d->sample_bound) return ASDF_EINVAL;        // affine point features only (kp == 2)
+  const bool two_out = d->spec.num_heads == 1;
+  if (two_out ? !(scratch_hand_dev && scratch_obj_dev) : !(scratch_hand_dev || scratch_obj_dev)) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  DecodeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sdf0 = scratch_hand_dev; p.sdf1 = scratch_obj_dev; p.bbox = bbox_dev;
+  p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
+  p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
+  p.stream = d->stream16_hi; p.cst = d->cst16; p.status = d->status;
+  p.first_mlp = 0; p.num_mlps = d->spec.num_heads; p.pf = d->spec.point_feats[0];
+  if (!two_out) {
+    if (!p.sdf1) p.num_mlps = 1;
+    else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
+  }
+  p.neg_thr = -tau;                                                   // the fused box takes the CERTAINLY negative voxels
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
+  if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
+  k1h_box_launch(two_out, p, grid, st);
+  if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
+  d->ev_start = d->ev_stop = nullptr;
+  // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
+  ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
+  ASDF_HIP(hipMemsetAsync(d->status + 2, 0, 2 * sizeof(int), st));    // [2] contradiction flag, [3] largest |exact - one-plane|
+  const long long items = (N & 3) == 0 ? p.P / 4 : p.P;
+  const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+  hipLaunchKernelGGL(collect_box_candidates_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, N, tau, p.bbox, d->near_idx,
+                     d->near_count, kNearCap, d->status);
+  DecodeParams q = p;
+  q.stream = d->stream; q.cst = d->cst; q.fixup_flag = d->status + 2;
+  q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
+  const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
+  k1_launch(d->kp, two_out, q, rgrid, st);
+  ASDF_HIP(hipGetLastError());
+  // the status record of this call travels with the boxes: one read-back for the caller
+  ASDF_HIP(hipMemcpyAsync(bbox_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));
+  ASDF_HIP(hipMemcpyAsync(bbox_dev + 17, d->near_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+  return ASDF_OK;
 }
 
 int asdf_decode_points(asdf_decoder_t* d, const float* xyz_dev, int64_t M, float* sdf_hand_dev, float* sdf_obj_dev,

@@ -62,6 +62,9 @@ struct DecodeParams {
   int* fixup_flag;          // kGridSubset with bbox: the outputs REPLACE earlier values - the box is patched in place (a voxel
                             // that turns negative extends it) and *fixup_flag is raised when one turns non-negative
   int* status;              // decoder-owned status record: [0] += lanes whose activations left the fp16 range (K1h only)
+  float neg_thr;            // a voxel counts as negative for the fused box when sdf < neg_thr: 0 for the ordinary sweeps, -tau
+                            // for the one-plane sweep of asdf_decode_grid_box (certainly negative); kGridSubset patches
+                            // compare the value they replace against it
   long long P;              // number of query points
   int N;                    // grid resolution (P == N^3 for grid modes)
   int mode;

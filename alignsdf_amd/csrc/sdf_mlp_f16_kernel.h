@@ -60,21 +60,57 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 
 // The split-half stream of a head is a flat sequence of (tile, K-block) records of 2 KiB ([plane hi / lo][lane][8 halves]),
 // 1024 of them; a stage is ASDF16_STAGE_KB consecutive records of one tile, so the stage size is the kernel's choice.
+//
+// PL = number of fp16 planes per operand.  2 is the split-half arithmetic above.  1 keeps only the high plane - plain fp16
+// operands, ONE MFMA per product sum, fp16-class results (errors of a few 1e-4 on the synthetic decoders): the kernel of
+// the box-only coarse sweep (asdf_decode_grid_box), whose output is consumed only through the bounding box of its
+// negative voxels and is re-evaluated exactly wherever that box could depend on the error.  Its weight stream is the
+// high planes alone (1 KiB records), so a 16-K-block stage is 16 KiB.
 constexpr int kS16Kb = ASDF16_STAGE_KB;
-constexpr int kS16Floats = kS16Kb * 512;             // floats per stage
 constexpr int kS16Head = 1024 / kS16Kb;              // stages per head
-constexpr int kS16Pieces = kS16Kb / 2;               // 1 KiB LDS-DMA pieces per wave per stage
-constexpr int kS16WaveFloats = kS16Floats / kWaves;  // a wave's share of a stage
-constexpr int kRing16Floats = kRing * kS16Floats;
+template <int PL>
+struct S16 {
+  static constexpr int kFloats = kS16Kb * 256 * PL;        // floats per stage
+  static constexpr int kPieces = kS16Kb * PL / 4;          // 1 KiB LDS-DMA pieces per wave per stage
+  static constexpr int kWaveFloats = kFloats / kWaves;     // a wave's share of a stage
+  static constexpr int kRingFloats = kRing * kFloats;
+  static constexpr int kMfmas = PL == 2 ? 3 : 1;           // MFMAs per K-block
+  // A fragments are read from LDS this many K-blocks ahead of their MFMAs: the read latency (~100 cycles) has to fit in the
+  // MFMA time of that distance - one K-block of three MFMAs (96 cycles), or three K-blocks of one
+  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : 3 * ASDF16_PREFETCH;
+  static_assert(kPieces == 4 || kPieces == 8, "stage size");
+};
+constexpr int kS16Floats = S16<2>::kFloats;
+constexpr int kS16Pieces = S16<2>::kPieces;
+constexpr int kS16WaveFloats = S16<2>::kWaveFloats;
+constexpr int kRing16Floats = S16<2>::kRingFloats;
 // LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
 constexpr int kWrecInts = 20;    // per wave: two 8-int negative-voxel records + the largest plane value of layers 0..2 (+ pad)
-constexpr int lds_bytes_f16(int kp) { return (kRing16Floats + cst_offsets(kp).floats) * 4 + kWaves * kWrecInts * 4; }
+constexpr int lds_bytes_f16(int kp, int planes = 2) {
+  return (kRing * kS16Kb * 256 * planes + cst_offsets(kp).floats) * 4 + kWaves * kWrecInts * 4;
+}
 constexpr int kLdsBytesF16 = lds_bytes_f16(2);
+constexpr int kLdsBytesF16P1 = lds_bytes_f16(2, 1);
 static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 
 // relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
 // amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
+template <int PL = 2>
 __device__ __forceinline__ void split_part(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax, int e) {
+  if (PL == 1) {
+    // one plane: part e converts the NEIGHBOURING accumulator registers 2 e, 2 e + 1 (both land in one packed fp16 register,
+    // one v_cvt_pk), about 5 VALU instructions - a part has to fit the shadow of the ONE MFMA of its K-block here
+    const float t0 = __int_as_float(max(__float_as_int(acc[2 * e]), 0)) * mul;
+    const float t1 = __int_as_float(max(__float_as_int(acc[2 * e + 1]), 0)) * mul;
+#ifndef ASDF16_NO_RANGE_CHECK
+    amax = fmaxf(amax, fmaxf(t0, t1));
+    asm volatile("" : "+v"(amax));
+#endif
+    h8& d = e < 4 ? hi0 : hi1;
+    d[(2 * e) & 7] = (_Float16)t0;
+    d[((2 * e) & 7) + 1] = (_Float16)t1;
+    return;
+  }
   const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
   const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
 #ifndef ASDF16_NO_RANGE_CHECK
@@ -83,16 +119,19 @@ __device__ __forceinline__ void split_part(const f32x16& acc, float mul, h8& hi0
   const _Float16 a = (_Float16)t0, b = (_Float16)t1;
   hi0[e] = a;
   hi1[e] = b;
-  lo0[e] = (_Float16)(t0 - (float)a);
-  lo1[e] = (_Float16)(t1 - (float)b);
+  if (PL == 2) {
+    lo0[e] = (_Float16)(t0 - (float)a);
+    lo1[e] = (_Float16)(t1 - (float)b);
+  }
 #ifndef ASDF16_NO_RANGE_CHECK
   asm volatile("" : "+v"(amax));      // keep the running maximum where it is computed (see dot_w4's pin in sdf_mlp_kernel.h)
 #endif
 }
 
+template <int PL = 2>
 __device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split_part(acc, mul, hi0, lo0, hi1, lo1, amax, e);
+  for (int e = 0; e < 8; ++e) split_part<PL>(acc, mul, hi0, lo0, hi1, lo1, amax, e);
 }
 
 // a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
@@ -136,37 +175,39 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 // s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
 // ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, class Pre, class Epi>
+template <int KB, int Q, int SLOT, int ABL, int PL, class Pre, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
-                                        h8 (&ah)[ASDF16_PREFETCH], h8 (&al)[ASDF16_PREFETCH], Pre&& pre, Epi&& epi) {
-  constexpr int PF = ASDF16_PREFETCH;
+                                        h8 (&ah)[S16<PL>::kPrefetch], h8 (&al)[S16<PL>::kPrefetch], Pre&& pre, Epi&& epi) {
+  constexpr int PF = S16<PL>::kPrefetch;
   constexpr int BKB = ASDF16_BARRIER_KB;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
-  const float* src = next_src + wave * kS16WaveFloats + lane * 4;
-  const unsigned dst = lds_ring_base + (nslot * kS16Floats + wave * kS16WaveFloats) * 4;
-  const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * kS16Floats) + lane;
-  const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * kS16Floats) + lane;
+  using SG = S16<PL>;
+  const float* src = next_src + wave * SG::kWaveFloats + lane * 4;
+  const unsigned dst = lds_ring_base + (nslot * SG::kFloats + wave * SG::kWaveFloats) * 4;
+  const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * SG::kFloats) + lane;
+  const h8* nxt = reinterpret_cast<const h8*>(ring + ((SLOT + 1) % kRing) * SG::kFloats) + lane;
   h8 bufh[kS16Kb + PF], bufl[kS16Kb + PF];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) { bufh[i] = ah[i]; bufl[i] = al[i]; }
+  for (int i = 0; i < PF; ++i) { bufh[i] = ah[i]; if (PL == 2) bufl[i] = al[i]; }
 #pragma unroll
   for (int kb = 0; kb < kS16Kb; ++kb) {
     if (kb == BKB && !(ABL & 1)) {
       // my pieces of stage (this + 1) were issued 2.5 stages ago; only those of (this + 2) may stay in flight
-      if (kS16Pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (SG::kPieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     }
-    bufh[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 0) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 0) * 64];
-    bufl[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 1) * 64];
+    bufh[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * PL + 0) * 64] : nxt[((kb + PF - kS16Kb) * PL + 0) * 64];
+    if (PL == 2) bufl[kb + PF] = kb + PF < kS16Kb ? cur[((kb + PF) * 2 + 1) * 64] : nxt[((kb + PF - kS16Kb) * 2 + 1) * 64];
     pre(kb);
 #if ASDF16_LOADS_FIRST
     __builtin_amdgcn_sched_barrier(0);
 #endif
     constexpr int base = Q * kS16Kb;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < SG::kMfmas; ++j) {
+      if (PL == 1) acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc); else
 #if ASDF16_MFMA_ORDER == 0
       // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
       acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
@@ -177,8 +218,8 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
       // W_lo . x_hi, W_hi . x_hi, W_hi . x_lo
       acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
 #endif
-      const int m = (kb - BKB) * 3 + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
-      if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < kS16Pieces) {
+      const int m = (kb - BKB) * SG::kMfmas + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
+      if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
         else if (m == 2) dma_piece<2>(src, dst);
@@ -198,19 +239,20 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
     if (ASDF16_LOADS_FIRST || (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1)) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; al[i] = bufl[kS16Kb + i]; }
+  for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; if (PL == 2) al[i] = bufl[kS16Kb + i]; }
 }
 
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
 // MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
 // constants block is 40 / 75 KiB).
-template <bool TWO_OUT, int ABL = 0, int KP = 2>
+template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
-  static_assert(lds_bytes_f16(KP) <= 160 * 1024, "LDS budget");
+  using SG = S16<PL>;
+  static_assert(lds_bytes_f16(KP, PL) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
-  float* cst = smem + kRing16Floats;
+  float* cst = smem + SG::kRingFloats;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -237,24 +279,24 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
       for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
     }
-    const float* sbase0 = p.stream + (size_t)head * kS16Head * kS16Floats;
+    const float* sbase0 = p.stream + (size_t)head * kS16Head * SG::kFloats;
 #pragma unroll
     for (int s = 0; s < ((ABL & 33) ? kRing : kRing - 1); ++s) {
-      const float* src = sbase0 + (size_t)s * kS16Floats + wave * kS16WaveFloats + lane * 4;
-      const unsigned dst = lds_ring_base + (s * kS16Floats + wave * kS16WaveFloats) * 4;
+      const float* src = sbase0 + (size_t)s * SG::kFloats + wave * SG::kWaveFloats + lane * 4;
+      const unsigned dst = lds_ring_base + (s * SG::kFloats + wave * SG::kWaveFloats) * 4;
 #pragma unroll
-      for (int c = 0; c < kS16Pieces; ++c) lds_dma16(src + c * 256, dst + c * 1024);
+      for (int c = 0; c < SG::kPieces; ++c) lds_dma16(src + c * 256, dst + c * 1024);
     }
     if (ABL & 33) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // my pieces of stage 0 (and my constants loads): those of stages 1 and 2 may stay in flight
-    if (kS16Pieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (SG::kPieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();                                      // everybody's pieces of stage 0, and the constants
-    h8 ah[ASDF16_PREFETCH], al[ASDF16_PREFETCH];
+    h8 ah[SG::kPrefetch], al[SG::kPrefetch];
 #pragma unroll
-    for (int i = 0; i < ASDF16_PREFETCH; ++i) {
-      ah[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 0) * 64];
-      al[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 1) * 64];
+    for (int i = 0; i < SG::kPrefetch; ++i) {
+      ah[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * PL + 0) * 64];
+      if (PL == 2) al[i] = (reinterpret_cast<const h8*>(ring) + lane)[(i * 2 + 1) * 64];
     }
     // accumulator -> next layer's planes: S_x of the produced activations / (S_w S_x) of the accumulator (powers of two)
     const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3], mul0 = hc[CL::kB4 + 4];
@@ -284,7 +326,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const float* sbase = sbase0;
       asm volatile("" : "+s"(sbase));
       auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3
-        return sbase + (size_t)(s < kS16Head ? s : s - kS16Head) * kS16Floats;
+        return sbase + (size_t)(s < kS16Head ? s : s - kS16Head) * SG::kFloats;
       };
 
       // LDS reads that feed a tile are issued half a tile (or one K-block) ahead of their first use - `pre` slots of
@@ -325,7 +367,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         f32x16 acc = kPreloadPf ? acc0[t & 1] : load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
-        split_tile(acc, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
+        split_tile<PL>(acc, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
       };
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
@@ -342,7 +384,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
-  stage16<KB, Q, SLOT, ABL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
+  stage16<KB, Q, SLOT, ABL, PL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
       h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
@@ -367,7 +409,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
           pin_acc(acc1[(t - 1) & 1]);
-          split_part(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax1, c);
+          split_part<PL>(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax1, c);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
@@ -406,10 +448,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
             pin_acc(acc2[(t - 1) & 1]);
-            split_part(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax2, c);
+            split_part<PL>(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax2, c);
           } else {
             pin_acc(acc1[(kTilesL1 - 1) & 1]);
-            split_part(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
+            split_part<PL>(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
                        h1l[2 * kTilesL1 - 1], amax1, c);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
         };
@@ -471,7 +513,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             next_w4();
           } else {
             pin_acc(acc2[(kTilesHidden - 1) & 1]);
-            split_part(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
+            split_part<PL>(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
                        h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c);  // K-blocks 30, 31: end of this tile
           }
         };
@@ -547,8 +589,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             rec[6] += n; rec[7] += extra;
           }
         };
-        fold(valid && half == 0 && sdf < 0.0f, wrec, bad);
-        if (TWO_OUT) fold(valid && half == 0 && sdfb < 0.0f, wrec + 8, 0);
+        fold(valid && half == 0 && sdf < p.neg_thr, wrec, bad);
+        if (TWO_OUT) fold(valid && half == 0 && sdfb < p.neg_thr, wrec + 8, 0);
       } else {
         const unsigned long long m = __ballot(bad);
         if (m && lane == 0) wrec[7] += __popcll(m);

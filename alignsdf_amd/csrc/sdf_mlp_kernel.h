@@ -303,7 +303,10 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         if (p.mode == kGridSubset && p.bbox) {
           // refinement of an existing volume: patch the negative-voxel box for every sign change instead of recounting
           auto patch = [&](float* vol, float now, int* rec) {
-            const bool was = vol[po] < 0.0f, is = now < 0.0f;
+            const float before = vol[po];
+            const bool was = before < p.neg_thr, is = now < 0.0f;
+            // the largest change this pass made to a value (float bits): the measured error of the arithmetic it corrects
+            if (p.status) atomicMax(p.status + 3, __float_as_int(fabsf(now - before)));
             if (was == is) return;
             if (is) {
               const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);

@@ -94,7 +94,12 @@ def main(argv=None):
     p.add_argument("--data_root", default="data")
     p.add_argument("--cube_dim", type=int, default=128)
     p.add_argument("--split", dest="split_filename", default=None, help="default: input/<task>.json like the reference")
+    p.add_argument("--coarse", choices=["exact", "box"], default=None,
+                   help="coarse pass: an ordinary sweep (default) or the box-only one-plane sweep with exact re-evaluation of "
+                        "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
     args = p.parse_args(argv)
+    if args.coarse:
+        os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     names = json.load(open(split))["filenames"]
     specs, decoder = rc.load_experiment(args.experiment_directory)

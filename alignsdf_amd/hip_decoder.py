@@ -16,6 +16,7 @@ from . import _native
 
 
 DEFAULT_MATH = "f16x3"
+DEFAULT_COARSE = "exact"      # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
 
 
 def _effective(module_sd, name):
@@ -168,7 +169,17 @@ class HipSdfDecoder:
         self._calibrated = False     # activation scales still at their default
         self._recalibrations = 0
         self.refine_tau = 4e-6
+        # coarse pass of the two-pass flow: "exact" = an ordinary sweep, "box" = the one-plane box-only sweep
+        # (asdf_decode_grid_box) with exact re-evaluation of the voxels that can move the box; ASDF_COARSE overrides
+        self.coarse_mode = os.environ.get("ASDF_COARSE", DEFAULT_COARSE)
+        if self.coarse_mode not in ("exact", "box"):
+            raise ValueError("ASDF_COARSE must be 'exact' or 'box', not %r" % self.coarse_mode)
+        self._box_tau = None         # error allowance of the one-plane values, calibrated per decoder (and per scale set)
+        self._box_epoch = -1
+        self._box_failures = 0
+        self.box_stats = {"box": 0, "exact": 0, "fallback": 0, "max_err": 0.0, "max_candidates": 0}
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
+        self.box_event_log = None  # the same for the one-plane kernel of the box-only coarse sweep
 
     def set_math(self, math):
         """Select the arithmetic of the hidden GEMMs ("f32" / "f16x3"); raises for NeRF-encoded decoders and f16x3."""
@@ -360,6 +371,103 @@ class HipSdfDecoder:
                 self._recover(int(st[0]), st)
                 launch()
         return hand, obj, bbox
+
+    # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
+    # per-head boxes of its negative voxels.  begin() enqueues, finish() reads the record back (the one host
+    # synchronisation the zoom cube needs anyway) and repeats the sweep where a guard asks for it.
+    def _box_usable(self):
+        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features
+
+    def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
+        if self.combined:
+            hand = obj = True
+        sh = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
+        so = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
+        rec = torch.empty(32, dtype=torch.int32, device=self.device)
+        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
+        with torch.cuda.device(self.device):
+            ev = None
+            if self.box_event_log is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                ev[1].record()
+                _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
+                                                                   ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
+            _native.check(self._L.asdf_decode_grid_box(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
+                                                       ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
+                                                       so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()),
+                          "asdf_decode_grid_box")
+            if ev is not None:
+                self.box_event_log.append(ev)
+        return rec, sh, so
+
+    def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
+        """Enqueue the coarse pass of one sample; returns a ticket for coarse_finish."""
+        args = (N, origin3, voxel_size, grid_mode, hand, obj)
+        if self._box_usable() and self._box_tau is not None and self._box_epoch == self._recalibrations:
+            rec, sh, so = self._box_launch(*args, self._box_tau)
+            return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so)}
+        h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
+        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o)}
+
+    def coarse_finish(self, ticket):
+        """int32[16] host record of the coarse pass (words 0..5 / 8..13: boxes of the negative voxels; 6 / 14: non-zero
+        iff there is one).  Synchronises with the sweep; a sweep whose guards fired is repeated here - the decoder must
+        still be bound to the ticket's sample."""
+        N, origin3, voxel_size, grid_mode, hand, obj = ticket["args"]
+        if ticket["kind"] == "box":
+            r = ticket["rec"].cpu().numpy()
+            b = r[:16]
+            bad = int(b[7]) + int(b[15])
+            err = float(np.int32(r[19]).view(np.float32))
+            cand = int(r[17])
+            self.box_stats["max_err"] = max(self.box_stats["max_err"], err)
+            self.box_stats["max_candidates"] = max(self.box_stats["max_candidates"], cand)
+            if not bad and cand <= 65536 and not int(r[18]) and err <= 0.5 * self._box_tau:
+                self.box_stats["box"] += 1
+                return b
+            import logging
+            self.box_stats["fallback"] += 1
+            if bad:
+                self._recover(bad)                  # new activation scales: the allowance is re-calibrated with them
+            else:
+                logging.warning("box-only coarse sweep not accepted (candidates %d, contradiction %d, error %.3g against "
+                                "allowance %.3g): repeated as an ordinary sweep", cand, int(r[18]), err, self._box_tau)
+                self._box_failures += 1
+                if err > 0.5 * self._box_tau:
+                    self._box_tau = min(4.0 * err, 0.25)
+                if self._box_failures >= 3:
+                    logging.warning("box-only coarse sweep switched off for this decoder")
+                    self.coarse_mode = "exact"
+            h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
+            ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "no_calibration": True}
+        b = ticket["rec"].cpu().numpy()
+        keep = ticket["keep"]
+        while self.fall_back_if_overflowed(b):      # split-half planes out of fp16 range: re-calibrated, or at last fp32
+            h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
+            b, keep = bbox.cpu().numpy(), (h, o)
+        self.box_stats["exact"] += 1
+        if self._box_usable() and not ticket.get("no_calibration") and (self._box_tau is None or self._box_epoch != self._recalibrations):
+            self._calibrate_box(ticket["args"], keep)
+        return b
+
+    def _calibrate_box(self, args, exact_vols):
+        """Error allowance of the one-plane sweep for this decoder and scale set: 4 x the largest |one-plane - split-half|
+        over every voxel of one whole coarse sweep (2 x N^3 values).  Later sweeps are accepted only while the error seen
+        on their re-evaluated voxels stays under half of it."""
+        import logging
+        rec, sh, so = self._box_launch(*args, 1e-7)            # (a tiny allowance: next to no candidates, plain one-plane values)
+        err = 0.0
+        for fast, exact in zip((sh, so), exact_vols):
+            if fast is not None and exact is not None:
+                err = max(err, float((fast - exact).abs().max().item()))
+        self._box_epoch = self._recalibrations
+        if not np.isfinite(err) or 4.0 * err > 0.05:
+            logging.warning("box-only coarse sweep: one-plane error %.3g too large, switched off for this decoder", err)
+            self.coarse_mode = "exact"
+            return
+        self._box_tau = max(4.0 * err, 1e-6)
+        logging.info("box-only coarse sweep: one-plane error %.3g, allowance %.3g", err, self._box_tau)
 
     def decode_points(self, xyz):
         """Both heads on explicit normalised points [M,3]. Returns (hand [M], obj [M]) device tensors."""

@@ -157,6 +157,14 @@ class TorchModuleDecoder:
                     scores[head:head + CHUNK] = c
         return hand, obj, scores
 
+    def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
+        """The coarse pass of the two-pass flow (same interface as HipSdfDecoder.coarse_begin; always an ordinary sweep)."""
+        h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
+        return {"rec": bbox, "keep": (h, o)}
+
+    def coarse_finish(self, ticket):
+        return ticket["rec"].cpu().numpy()
+
     def decode_points(self, xyz):
         h, o, _ = self._decode(xyz.detach().to(self.device, torch.float32).contiguous())
         return h, o

@@ -266,11 +266,9 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     voxel_size = 2.0 / (N - 1)
     # a branch that is switched off is neither meshed nor used for the zoom cube (utils/mesh.py:239-247), so its
     # head is not evaluated at all (the reference computes and discards it)
-    _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)
-    b = bbox.cpu().numpy()
-    while hip.fall_back_if_overflowed(b):       # split-half planes out of fp16 range: re-calibrated (or, at last, on the
-        _, _, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch)   # fp32 kernel)
-        b = bbox.cpu().numpy()
+    # coarse pass: consumed only through its boxes (ordinary sweep, or the box-only sweep when the decoder is set to it);
+    # a sweep whose range / error guards fired is repeated inside coarse_finish
+    b = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], voxel_size, mode, hand=hand_branch, obj=obj_branch))
     boxes = []
     if hand_branch:
         boxes.append((b[0:3], b[3:6], int(b[6])))

@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--no-other-math", action="store_true", help="skip the second full record under the other arithmetic")
     ap.add_argument("--math", default=None, choices=["f32", "f16x3"],
                     help="arithmetic of the hidden GEMMs (default: the product's default, split-half fp16 MFMA)")
+    ap.add_argument("--coarse", default=None, choices=["exact", "box"],
+                    help="coarse pass of the two-pass flow in the timed region: an ordinary sweep, or the box-only one-plane "
+                         "sweep with exact re-evaluation of the box candidates (default: the product's default)")
+    ap.add_argument("--no-other-coarse", action="store_true", help="skip the second full record under the other coarse pass")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -288,6 +292,8 @@ def main():
     dec = HipSdfDecoder(syn.full_state_dict(args.tag), 256, specs["PointFeatSize"], specs["EncodeStyle"], device=dev)
     if args.math is not None:
         dec.set_math(args.math)
+    if args.coarse is not None:
+        dec.coarse_mode = args.coarse
     # 64 distinct synthetic samples, resident on the device before timing
     codes = []
     for s in range(64):
@@ -312,7 +318,7 @@ def main():
     def run(first, count):
         out = []
         for i, r in pipelined_two_pass(dec, specs, sample_stream(first, count), N):
-            out.append((i, r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"]))
+            out.append((i, r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"], tuple(r["origin"]), float(r["voxel_size"])))
         return out
 
     def timed(first, count, warmup):
@@ -322,7 +328,7 @@ def main():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        dec.event_log = []
+        dec.event_log, dec.box_event_log = [], []
         t0 = time.perf_counter()
         done = run(first, count)
         torch.cuda.synchronize(dev)
@@ -330,9 +336,13 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         events, dec.event_log = dec.event_log, None
+        box_events, dec.box_event_log = dec.box_event_log, None
+        timed.box_ms = [e[0].elapsed_time(e[1]) for e in box_events]      # launches of the one-plane kernel, if any ran
         return elapsed, [e[0].elapsed_time(e[1]) for e in events], done
 
     elapsed, k1_ms, done = timed(args.warmup, args.steps, args.warmup)
+    main_box_ms = list(timed.box_ms)
+    main_coarse = dec.coarse_mode if dec._box_usable() else "exact"
     records = [dict(index=rank * args.steps + k, V_hand=d[1], F_hand=d[2], V_obj=d[3], F_obj=d[4], milliseconds=0.0)
                for k, d in enumerate(done)]
     if world > 1:
@@ -352,7 +362,7 @@ def main():
     peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     exec_flop = N ** 3 * 2 * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
 
-    other = parity = mc_line = None
+    other = parity = mc_line = other_coarse = None
     if world == 1:
         last_sample = sample_id(args.warmup + args.steps - 1)
         lat, mano, obj = codes[last_sample]
@@ -389,6 +399,20 @@ def main():
             other = {"math": dec.math, "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * e2 / args.steps, "value": 2 * args.steps / e2,
                      "unit": "meshes/s", "launch_ms": float(np.mean(k2_ms)), "dtype": "f32" if split else "f32 as 2 x f16 planes"}
             dec.set_math(math0)
+        # ---- the other coarse pass as a full record over the SAME samples: zoom cubes and surfaces must come out identical
+        if not args.no_other_coarse and split and not dec.nerf_features:
+            dec.coarse_mode = "exact" if main_coarse == "box" else "box"
+            e3, k3_ms, done3 = timed(args.warmup, args.steps, max(args.warmup, 2))
+            same_cubes = sum(1 for a, b in zip(done, done3) if a[5] == b[5] and a[6] == b[6])
+            same_vf = sum(1 for a, b in zip(done, done3) if a[1:5] == b[1:5])
+            other_coarse = {"coarse": dec.coarse_mode if dec._box_usable() or dec.coarse_mode == "exact" else "exact (box switched itself off)",
+                            "steps": args.steps, "ms_per_step": 1e3 * e3 / args.steps, "value": 2 * args.steps / e3, "unit": "meshes/s",
+                            "launch_ms_pass2_kernel": float(np.mean(k3_ms)) if k3_ms else None,
+                            "launch_ms_one_plane_kernel": float(np.mean(timed.box_ms)) if timed.box_ms else None,
+                            "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
+                            "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
+                            "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
+            dec.coarse_mode = main_coarse
         # ---- marching cubes chain (K3-K6) on the last sample's volumes: HBM roofline of the second kernel family
         from alignsdf_amd import marching_cubes as mcmod
         r = vols.get(math0) or decode_two_pass(True, True, dec, lat, mano, obj, specs, N)
@@ -472,6 +496,11 @@ def main():
             result["parity_in_run"] = parity
         if other is not None:
             result["other_math"] = other
+        result["config"]["coarse_pass"] = main_coarse
+        if main_box_ms:
+            result["roofline"]["launch_ms_one_plane_kernel"] = float(np.mean(main_box_ms))
+        if other_coarse is not None:
+            result["other_coarse_pass"] = other_coarse
         if world == 1 and not args.no_cpu_baseline:
             # one extra GPU sample (outside every timed region) with its pass-1 volumes kept for the CPU zoom-cube leg
             sid = 0

@@ -102,6 +102,28 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
 int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
                      float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream);
 
+/* The bounding boxes of asdf_decode_grid WITHOUT its volumes: the coarse pass of the reference's two-pass flow
+ * (utils/mesh.py:27-63) is consumed only through get_higher_res_cube (utils/mesh.py:198-256), i.e. through the per-head
+ * box of its negative voxels, so it need not be evaluated to fp32 accuracy everywhere.  This entry point
+ *   1. sweeps the lattice with ONE fp16 plane per operand (one MFMA per product sum: about a third of the time of the
+ *      split-half sweep; values good to a few 1e-4) and takes the box of the voxels that are negative by more than tau;
+ *   2. lists the voxels a head leaves undecided (-tau <= value < tau) that lie outside that head's box - only those can
+ *      move it - and re-evaluates them on the fp32 MFMA chain (the arithmetic of ASDF_MATH_F32); every one that is
+ *      negative extends the box.
+ * bbox_dev (int32[32], required): words 0..15 then hold exactly the min / max words asdf_decode_grid would have produced,
+ * PROVIDED the one-plane values are within tau of the exact ones; word [6] / [14] is non-zero iff the head has a negative
+ * voxel (it is not the count), [7] / [15] the fp16 range report as usual.  The proviso is checked on every call where it
+ * matters - on the re-evaluated voxels - and the outcome travels in words 16..31, a copy of the decoder's status record
+ * taken behind the call: [16 + 3] = largest |exact - one-plane| seen (float bits), [16 + 2] != 0 = a voxel taken as
+ * certainly negative was not, [16 + 1] = number of candidates (more than 65536: not all were re-evaluated).  A caller must
+ * treat [7] / [15] / [18] != 0, [17] > 65536 or [19] > tau / 2 as "repeat with asdf_decode_grid"
+ * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also calibrate tau per decoder from a whole-volume
+ * comparison with the split-half sweep).
+ * scratch_*_dev: N^3 floats per evaluated head (same NULL rules as asdf_decode_grid); contents afterwards: one-plane
+ * values, exact ones at the re-evaluated voxels.  Affine point features only (ASDF_EINVAL otherwise). */
+int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
+                         float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream);
+
 /* Bounding box of the voxels with value < 0 of one [n0][n1][n2] fp32 device volume, as int32[16] on the
  * device (record 0 only: [0..2] min index per axis, [3..5] max index per axis, [6] count; min = INT_MAX and
  * max = -1 when the count is 0).  Replaces torch.nonzero + min/max in get_higher_res_cube
@@ -150,7 +172,8 @@ int asdf_decoder_time_next_sweep(asdf_decoder_t* dec, void* event_start, void* e
 /* Range report of the split-half arithmetic that does NOT depend on a bbox buffer: every ASDF_MATH_F16X3 launch of this
  * decoder adds the number of (point, lane-half) pairs whose hidden activations left the fp16 range (or whose output is not
  * in [-1, 1]) to a device word the decoder owns.  Copies the record to out_host[16] ([0] = that count, [1] = near-level
- * voxels beyond the refinement list's capacity, [4..6] / [8..10] = the largest fp16-plane value x S_x handed to the
+ * voxels (asdf_decode_grid_box: candidates) beyond the re-evaluation list's capacity, [2] = scratch flag of the last
+ * re-evaluation (a voxel left the negative set), [3] = largest |new - old| value of the last re-evaluation (float bits), [4..6] / [8..10] = the largest fp16-plane value x S_x handed to the
  * conversion for the activation vectors h0 / h1 / h2 of MLP 0 / MLP 1, as float bit patterns, the rest reserved),
  * optionally clears it, and synchronises `stream`.  A caller that sweeps without a bbox buffer (deep_sdf/mesh.py:14-61
  * has no zoom pass) checks this once per volume and repeats the sweep under ASDF_MATH_F32 when the count is non-zero. */

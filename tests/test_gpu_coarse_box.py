@@ -1,0 +1,130 @@
+"""The box-only coarse sweep (asdf_decode_grid_box, HipSdfDecoder.coarse_begin / coarse_finish with coarse_mode "box"):
+the coarse pass of the two-pass flow (utils/mesh.py:27-63) is consumed only through get_higher_res_cube
+(utils/mesh.py:198-256), i.e. through the box of its negative voxels.  One fp16 plane per operand + exact re-evaluation
+of every voxel that could move the box must give the SAME boxes - hence the same zoom cube, hence bit-identical
+pass-2 volumes - as the ordinary sweep, and must notice when it cannot."""
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(tag):
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    specs = syn.specs_for(tag)
+    return HipSdfDecoder(syn.full_state_dict(tag), 256, specs["PointFeatSize"], specs["EncodeStyle"]), specs
+
+
+def _bind(hip, specs, sample):
+    from alignsdf_amd.utils.utils import sample_embedding
+    mano = obj = None
+    if specs["EncodeStyle"] != "nerf":
+        m, o = syn.pose_inputs(sample)
+        mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()}
+        obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
+    hip.set_sample(torch.from_numpy(syn.latent_code(sample)).cuda(), sample_embedding(specs, mano, obj, hip.combined))
+
+
+def _boxes(b):
+    return [int(v) for v in b[0:6]] + [int(v) for v in b[8:14]] + [int(b[6] != 0), int(b[14] != 0)]
+
+
+@pytest.mark.parametrize("tag,N", [("nerf3", 64), ("nerf3", 128), ("nerf3", 256), ("comb3", 96), ("hand6", 64), ("obj6", 64)])
+def test_boxes_equal_the_ordinary_sweep(tag, N):
+    hip, specs = _decoder(tag)
+    hip.coarse_mode = "box"
+    vs = 2.0 / (N - 1)
+    for sample in range(5):
+        _bind(hip, specs, sample)
+        got = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+        want = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)[2].cpu().numpy()
+        assert _boxes(got) == _boxes(want), (sample, got, want)
+    # the first sample calibrated the allowance on an ordinary sweep, the others ran the one-plane kernel and were accepted
+    assert hip.box_stats["box"] == 4 and hip.box_stats["exact"] == 1 and hip.box_stats["fallback"] == 0, hip.box_stats
+    assert 0.0 < hip._box_tau < 0.05 and hip.box_stats["max_err"] <= 0.5 * hip._box_tau
+    assert hip.range_violations() == 0
+    hip.close()
+
+
+def test_single_branch_and_a_zoom_lattice():
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode = "box"
+    N = 96
+    for sample, (hand, obj) in enumerate([(True, True), (True, False), (False, True), (True, False)]):
+        _bind(hip, specs, sample)
+        for origin, vs in (([-1.0, -1.0, -1.0], 2.0 / (N - 1)), ([-0.62, -0.36, -0.37], 1.21 / (N - 1))):
+            got = hip.coarse_finish(hip.coarse_begin(N, origin, vs, hand=hand, obj=obj))
+            want = hip.decode_grid(N, origin, vs, hand=hand, obj=obj)[2].cpu().numpy()
+            assert _boxes(got) == _boxes(want)
+    assert hip.box_stats["box"] >= 6 and hip.box_stats["fallback"] == 0
+    hip.close()
+
+
+def test_two_pass_flow_is_bit_identical():
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    specs = syn.specs_for("nerf3")
+    N = 128
+    out = {}
+    for mode in ("exact", "box"):
+        dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+        from alignsdf_amd.utils.utils import decoder_for
+        hip = decoder_for(dec, specs)
+        hip.coarse_mode = mode
+        res = []
+        for sample in range(3):
+            lat = torch.from_numpy(syn.latent_code(sample)).cuda()
+            r = decode_two_pass(True, True, dec, lat, None, None, specs, N)
+            res.append((r["origin"], float(r["voxel_size"]), r["vol_hand"].clone(), r["vol_obj"].clone()))
+        out[mode] = res
+        if mode == "box":
+            assert hip.box_stats["box"] == 2 and hip.box_stats["fallback"] == 0
+    for a, b in zip(out["exact"], out["box"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def test_an_allowance_that_is_too_small_is_noticed_and_the_sweep_repeated():
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode = "box"
+    N = 96
+    vs = 2.0 / (N - 1)
+    _bind(hip, specs, 0)
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))          # calibration
+    honest = hip._box_tau
+    hip._box_tau = honest / 64.0            # pretend the arithmetic were 64 x better than it is
+    for sample in range(1, 4):
+        _bind(hip, specs, sample)
+        got = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+        want = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)[2].cpu().numpy()
+        assert _boxes(got) == _boxes(want)
+        if hip.box_stats["fallback"]:
+            break
+    # the error seen on the re-evaluated voxels exceeded half the allowance: that sweep was not trusted, the allowance grew
+    assert hip.box_stats["fallback"] >= 1 and hip._box_tau > honest / 64.0
+    hip.close()
+
+
+def test_box_entry_point_argument_checks(native_lib):
+    import ctypes
+    hip, specs = _decoder("nerf9")          # NeRF-encoded features: no one-plane kernel
+    _bind(hip, specs, 0)
+    rec = torch.zeros(32, dtype=torch.int32, device="cuda")
+    vol = torch.zeros(32 ** 3, dtype=torch.float32, device="cuda")
+    org = (ctypes.c_float * 3)(-1.0, -1.0, -1.0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = native_lib
+    assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), vol.data_ptr(), vol.data_ptr(), rec.data_ptr(), st) == -1
+    hip.coarse_mode = "box"
+    assert not hip._box_usable()            # ... and the Python layer runs ordinary sweeps for it
+    hip.close()
+    hip, specs = _decoder("nerf3")
+    _bind(hip, specs, 0)
+    for tau in (0.0, -1.0, 0.5, float("nan")):
+        assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(tau), vol.data_ptr(), vol.data_ptr(), rec.data_ptr(), st) == -1
+    assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), vol.data_ptr(), vol.data_ptr(), None, st) == -1
+    assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), None, None, rec.data_ptr(), st) == -1
+    hip.close()

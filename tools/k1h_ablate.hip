@@ -15,9 +15,13 @@ using namespace asdf;
 #ifndef ABL_LIST
 #define ABL_LIST X(0) X(32) X(1) X(16) X(4)
 #endif
+#ifndef PLANES
+#define PLANES 2        // 1 = the one-plane kernel of the box-only coarse sweep
+#endif
+constexpr int kLds = PLANES == 1 ? kLdsBytesF16P1 : kLdsBytesF16;
 __device__ unsigned long long g_ticks[2];
 #define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { \
-    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n>(p); \
+    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES>(p); \
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
@@ -45,10 +49,10 @@ int main(int argc, char** argv) {
   DecodeParams p{}; p.stream = stream; p.cst = cst; p.sdf0 = o0; p.sdf1 = o1; p.P = P; p.N = N; p.mode = kGridReference;
   p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0; p.bbox = bbox;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  const double flop = (double)P * 2 * 3145728.0;
-  printf("PREFETCH %d  BARRIER_KB %d  data %s\n", ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
-#define X(n) { (void)hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16); \
-    float best = 1e9; double ghz = 0; for (int it = 0; it < 4; ++it) { (void)hipEventRecord(e0); hipLaunchKernelGGL(k_abl_##n, dim3(256), dim3(256), kLdsBytesF16, 0, p); \
+  const double flop = (double)P * 2 * 3145728.0 / (PLANES == 1 ? 3 : 1);
+  printf("PLANES %d  PREFETCH %d  BARRIER_KB %d  data %s\n", PLANES, ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
+#define X(n) { (void)hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \
+    float best = 1e9; double ghz = 0; for (int it = 0; it < 4; ++it) { (void)hipEventRecord(e0); hipLaunchKernelGGL(k_abl_##n, dim3(256), dim3(256), kLds, 0, p); \
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); \
       unsigned long long t[2]; (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), 16); \
       if (ms < best) { best = ms; ghz = (double)(t[1] - t[0]) / (ms * 1e6); } } \
