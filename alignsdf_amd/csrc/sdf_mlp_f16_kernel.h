@@ -242,6 +242,14 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
   for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; if (PL == 2) al[i] = bufl[kS16Kb + i]; }
 }
 
+// Timing instrumentation of tools/k1h_ablate.hip (-DASDF16_SEGMENT_TIMES): shader-clock stamps of wave 0 of workgroup 0 at
+// the layer boundaries of its third tile of MLP 0 go to g_seg[] (declared by the tool).  Not compiled into the product.
+#ifdef ASDF16_SEGMENT_TIMES
+#define ASDF16_MARK(k) do { __builtin_amdgcn_sched_barrier(0); seg_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ASDF16_MARK(k) do { } while (0)
+#endif
+
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
 // MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
 // constants block is 40 / 75 KiB).
@@ -303,6 +311,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef ASDF16_SEGMENT_TIMES
+      long long seg_t[8];
+#endif
+      ASDF16_MARK(0);
       const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
       const bool valid = pi < p.P;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
@@ -386,6 +398,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
   stage16<KB, Q, SLOT, ABL, PL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
+      ASDF16_MARK(1);
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
       h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesL1; ++t) { h1h[t] = h0h[t]; h1l[t] = h0l[t]; }
@@ -432,6 +445,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #endif
       }
 
+      ASDF16_MARK(2);
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
@@ -483,6 +497,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #endif
       }
 
+      ASDF16_MARK(3);
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
       float part = 0.0f, partb = 0.0f;
       // accumulator registers 2 c, 2 c + 1 of a finished tile into the last-layer dot product(s), weights from (w4c, w4bc)
@@ -539,6 +554,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         }
 #endif
       }
+      ASDF16_MARK(4);
       // the last tile's epilogue has no MFMA stream to hide under
 #pragma unroll
       for (int c = 0; c < kEpiChunks; ++c) {
@@ -595,6 +611,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         const unsigned long long m = __ballot(bad);
         if (m && lane == 0) wrec[7] += __popcll(m);
       }
+      ASDF16_MARK(5);
+#ifdef ASDF16_SEGMENT_TIMES
+      if (blockIdx.x == 0 && wave == 0 && lane == 0 && slot == 0 && tile == (long long)blockIdx.x + 2 * gridDim.x)
+        for (int k = 0; k < 6; ++k) g_seg[k] = (unsigned long long)seg_t[k];
+      if (blockIdx.x == 0 && wave == 0 && lane == 0 && slot == 0 && tile == (long long)blockIdx.x + 3 * gridDim.x) g_seg[6] = (unsigned long long)seg_t[0];
+#endif
     }   // tiles
 
     if (lane == 0) {

@@ -124,3 +124,17 @@ def test_hand_built_meshes_with_non_manifold_and_duplicate_elements():
     v3, f3 = _tetra(4, (7, 7, 7), 1.0)
     c = _compare_raw(v1 + v3, f1 + f3)
     assert c[2] == 2 and c[3] == 0
+
+
+def test_the_documented_deviation_from_trimesh_fill_holes():
+    """DESIGN.md 4 (K8 contract): trimesh.graph.split(only_watertight=True) hands a component that is not watertight to
+    `fill_holes` first, which can close a triangular or quadrilateral hole and then KEEP the component; K8 (and the oracle)
+    do not repair - such a component is dropped.  Marching-cubes surfaces are closed or clipped by the cube (boundary loops
+    of dozens of edges), so the case does not arise on the path; this test pins what happens if it ever did."""
+    big_v, big_f = _tetra(0, (0, 0, 0), 5.0)          # the largest surface ...
+    mid_v, mid_f = _tetra(4, (20, 20, 20), 2.0)
+    small_v, small_f = _tetra(8, (40, 40, 40), 1.0)
+    # ... with one face removed: a triangular hole (trimesh would fill it and keep the large component)
+    c = _compare_raw(big_v + mid_v + small_v, big_f[:3] + mid_f + small_f)
+    assert c[2] == 2                                   # two watertight components: the open one does not count
+    assert c[0] == 4 and c[1] == 4                     # kept: the middle tetrahedron

@@ -10,6 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifdef ASDF16_SEGMENT_TIMES
+__device__ unsigned long long g_seg[8];
+#endif
 #include "sdf_mlp_f16_kernel.h"
 using namespace asdf;
 #ifndef ABL_LIST
@@ -25,6 +28,27 @@ __device__ unsigned long long g_ticks[2];
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
+#ifdef ASDF16_SEGMENT_TIMES
+// shader-clock cycles of the segments of one tile of one wave, next to the MFMA time the segment's instructions need
+static void seg_report() {
+  unsigned long long g[8];
+  (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_seg), sizeof(g));
+  const double f = PLANES == 1 ? 1.0 / 3.0 : 1.0;
+  const char* name[5] = {"coordinates + layer-0 tiles 0..7", "layer 1 (+ layer-0 tiles 8..15)", "layer 2", "layer 3", "last epilogue, tanh, stores, box fold"};
+  const double ideal[5] = {8 * 2 * 64.0, 8 * 32 * 96.0 * f + 8 * 2 * 64.0, 16 * 16 * 96.0 * f + 16 * 2 * 64.0, 16 * 32 * 96.0 * f, 0.0};
+  double tot = 0, toti = 0;
+  for (int k = 0; k < 5; ++k) {
+    const double c = (double)(g[k + 1] - g[k]);
+    printf("    %-40s %8.0f cycles   MFMA time of its instructions %8.0f   (%5.1f %%)\n", name[k], c, ideal[k], ideal[k] > 0 ? 100.0 * ideal[k] / c : 0.0);
+    tot += c; toti += ideal[k];
+  }
+  printf("    %-40s %8.0f cycles   %8.0f   (%5.1f %%);  tile period (start to start of the next) %.0f cycles\n", "one tile of one MLP", tot, toti, 100.0 * toti / tot,
+         (double)(g[6] - g[0]) / 1.0);
+}
+#define SEG_REPORT seg_report();
+#else
+#define SEG_REPORT
+#endif
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 128;
   const char* data = argc > 2 ? argv[2] : "small";
@@ -56,7 +80,7 @@ int main(int argc, char** argv) {
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); \
       unsigned long long t[2]; (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), 16); \
       if (ms < best) { best = ms; ghz = (double)(t[1] - t[0]) / (ms * 1e6); } } \
-    printf("ABL %2d  N=%d  %.3f ms  %.0f TF/s f16 MFMA (%.1f%% of 2516)  wg0 ticks/wall = %.3f GHz  err=%d\n", n, N, best, flop / best / 1e9, flop / best / 1e9 / 25.166, ghz, (int)hipGetLastError()); }
+    SEG_REPORT printf("ABL %2d  N=%d  %.3f ms  %.0f TF/s f16 MFMA (%.1f%% of 2516)  wg0 ticks/wall = %.3f GHz  err=%d\n", n, N, best, flop / best / 1e9, flop / best / 1e9 / 25.166, ghz, (int)hipGetLastError()); }
   ABL_LIST
 #undef X
   return 0;
