@@ -128,3 +128,35 @@ def test_box_entry_point_argument_checks(native_lib):
     assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), vol.data_ptr(), vol.data_ptr(), None, st) == -1
     assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), None, None, rec.data_ptr(), st) == -1
     hip.close()
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "nerf9"])
+def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
+    """ASDF_COARSE=box through the product's entry points (decoder_for -> pipelined_two_pass): cubes, volumes and meshes of
+    every sample are those of the ordinary coarse pass - for the ObMan decoder, the MANO-aligned DexYCB decoder (affine point
+    features) and a NeRF-encoded decoder, which has no one-plane kernel and silently keeps ordinary sweeps."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass, synthetic_code_source
+    from alignsdf_amd.utils.utils import decoder_for
+    specs = syn.specs_for(tag)
+    src = synthetic_code_source(tag, "cuda")
+    N = 64
+    samples = [(i,) + src("s%d" % i, i) for i in (0, 3, 7, 11, 20, 21)]
+    out = {}
+    for mode in ("exact", "box"):
+        monkeypatch.setenv("ASDF_COARSE", mode)
+        dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()})
+        out[mode] = {k: r for k, r in pipelined_two_pass(dec, specs, iter(samples), N)}
+        hip = decoder_for(dec, specs, samples[0][2])
+        assert hip.coarse_mode == mode
+        if mode == "box":
+            if tag != "nerf9":
+                assert hip.box_stats["box"] == len(samples) - 1 and hip.box_stats["fallback"] == 0, hip.box_stats
+            else:
+                assert hip.box_stats["box"] == 0
+    for k, a in out["exact"].items():
+        b = out["box"][k]
+        assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
+        for part in ("hand", "obj"):
+            assert torch.equal(a["vol_" + part], b["vol_" + part])
+            assert torch.equal(a["verts_" + part], b["verts_" + part]) and torch.equal(a["faces_" + part], b["faces_" + part])
