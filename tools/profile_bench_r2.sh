@@ -11,7 +11,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$i -- python bench.py --steps 2 --warmup 0 $ARGS > /dev/null 2> $O/pmc_$i.err
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$i -- python bench.py --steps 2 --warmup 0 $ARGS --no-other-coarse > /dev/null 2> $O/pmc_$i.err
 done
 python3 - <<PY
 import csv, glob, collections, json, hashlib, os
