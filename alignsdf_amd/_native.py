@@ -17,12 +17,12 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 115        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 116        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
     "asdf_version", "asdf_strerror", "asdf_last_hip_error", "asdf_device_count", "asdf_decoder_create",
-    "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_grid_box", "asdf_decode_points", "asdf_neg_bbox",
+    "asdf_decoder_destroy", "asdf_decoder_set_sample", "asdf_decode_grid", "asdf_decode_grid_box", "asdf_decode_grid_band", "asdf_decode_points", "asdf_neg_bbox",
     "asdf_mc_workspace_bytes", "asdf_mc_count", "asdf_mc_emit", "asdf_icp_workspace_bytes", "asdf_icp_ts",
     "asdf_debug_pack_host", "asdf_decoder_set_classifier", "asdf_decode_points_cls",
     "asdf_icp_ts_enqueue", "asdf_icp_ts_result", "asdf_chamfer",
@@ -85,6 +85,7 @@ def lib():
     L.asdf_decoder_set_sample.argtypes = [vp, vp, vp, vp]
     L.asdf_decode_grid.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, vp, vp, vp, vp]
     L.asdf_decode_grid_box.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]
+    L.asdf_decode_grid_band.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]
     L.asdf_decode_points.argtypes = [vp, vp, i64, vp, vp, vp]
     L.asdf_decoder_set_classifier.argtypes = [vp, vp, vp, i32]
     L.asdf_decode_points_cls.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]

@@ -208,6 +208,78 @@ __global__ __launch_bounds__(256) void collect_box_candidates_kernel(const float
   }
 }
 
+// The narrow-band fine sweep (asdf_decode_grid_band).  Marching cubes reads a cell's eight corner values only if the cell is
+// active, and otherwise only their signs.  With one-plane values v known to lie within tau of the exact ones, a cell CAN be
+// active only if its corners' one-plane signs are mixed or one of them is undecided (|v| < tau): for those cells all eight
+// corners are marked for exact re-evaluation; every other cell is inactive whatever the error, and its corners are never read.
+// One thread per 4 x-consecutive cells, like mc_classify: 4 corner rows of 5 values.
+__global__ __launch_bounds__(256) void band_mark_kernel(const float* __restrict__ vol, int N, float tau, unsigned char* __restrict__ mark) {
+  const int cx = N - 1, cxp = (cx + 3) & ~3, groups = cxp >> 2;
+  const long long total = (long long)groups * cx * cx;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const int x0 = (int)(g % groups) * 4;
+    const long long r = g / groups;
+    const int y = (int)(r % cx), z = (int)(r / cx);
+    const float* r00 = vol + ((size_t)z * N + y) * N;
+    const float* rows[4] = {r00, r00 + N, r00 + (size_t)N * N, r00 + (size_t)N * N + N};
+    unsigned pos[4], neg[4];           // bit i: value i of the row is certainly positive / certainly negative
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pos[q] = neg[q] = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        if (x0 + i < N) {
+          const float v = rows[q][x0 + i];
+          pos[q] |= (v >= tau ? 1u : 0u) << i;
+          neg[q] |= (v < -tau ? 1u : 0u) << i;
+        } else {
+          pos[q] |= 1u << i; neg[q] |= 1u << i;      // beyond the row: neutral for the AND reductions below, cells there are masked off
+        }
+      }
+    }
+    // a cell is certainly inactive iff all 8 corners are certainly positive, or all certainly negative
+    const unsigned ap = pos[0] & pos[1] & pos[2] & pos[3], an = neg[0] & neg[1] & neg[2] & neg[3];
+    const int ncell = min(4, cx - x0);
+    const unsigned inactive = (ap & (ap >> 1)) | (an & (an >> 1));
+    const unsigned cand = ~inactive & ((1u << ncell) - 1);
+    if (!cand) continue;
+    // corners of the candidate cells: columns x0 + i and x0 + i + 1 of the four rows
+    const unsigned cols = (cand | (cand << 1)) & 0x1fu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned char* m = mark + (rows[q] - vol);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if ((cols >> i) & 1) m[x0 + i] = 1;
+    }
+  }
+}
+
+// marked voxels -> index list (order arbitrary); *count counts all of them, also those beyond cap
+__global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* __restrict__ mark, long long n, int* idx, int* count, int cap) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q * 16 < n; q += stride) {
+    if (q * 16 + 16 <= n) {
+      const uint4 w = reinterpret_cast<const uint4*>(mark)[q];
+      if (!(w.x | w.y | w.z | w.w)) continue;
+      const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c += __popc(ww[k] & 0x01010101u);
+      int at = atomicAdd(count, c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((ww[k] >> (8 * b)) & 1) { if (at < cap) idx[at] = (int)(q * 16 + 4 * k + b); ++at; }
+    } else {
+      for (long long i = q * 16; i < n; ++i)
+        if (mark[i]) { const int at = atomicAdd(count, 1); if (at < cap) idx[at] = (int)i; }
+    }
+  }
+}
+
 __global__ void bbox_reinit_keep_flags_kernel(int* bbox, const int* flag) {   // words 7 / 15 (the fp16 range report) survive
   if (flag && *flag == 0) return;
   const int i = threadIdx.x;
@@ -256,8 +328,14 @@ struct asdf_decoder {
   float refine_tau;
   int* near_idx;    // [kNearCap] lattice indices
   int* near_count;  // device word
+  // narrow-band fine sweep (asdf_decode_grid_band): voxel marks and the per-head re-evaluation lists, allocated on first use
+  unsigned char* band_mark;
+  size_t band_mark_bytes;
+  int* band_idx;    // [2][kBandCap]
+  int* band_count;  // [2] device words
 };
 static constexpr int kNearCap = 1 << 16;
+static constexpr int kBandCap = 1 << 21;     // voxels per head the narrow-band sweep re-evaluates at most (12 % of 256^3)
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
 static bool spec_supported(const asdf_decoder_spec_t* s) {
@@ -275,7 +353,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 115; }
+int asdf_version(void) { return 116; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -307,6 +385,9 @@ int asdf_device_count(void) {
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
   float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi};
+  if (d->band_mark) (void)hipFree(d->band_mark);
+  if (d->band_idx) (void)hipFree(d->band_idx);
+  if (d->band_count) (void)hipFree(d->band_count);
   for (float* b : bufs) (void)hipFree(b);
   (void)hipFree(d->status);
   (void)hipFree(d->near_idx);
@@ -586,6 +667,67 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   // the status record of this call travels with the boxes: one read-back for the caller
   ASDF_HIP(hipMemcpyAsync(bbox_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));
   ASDF_HIP(hipMemcpyAsync(bbox_dev + 17, d->near_count, sizeof(int), hipMemcpyDeviceToDevice, st));
+  return ASDF_OK;
+}
+
+int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
+                          float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
+  if (!d || !origin || !rec_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
+  if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
+  if (!d->stream16_hi || !d->sample_bound || d->spec.num_heads != 2) return ASDF_EINVAL;      // SeparateDecoder, affine features
+  if (!sdf_hand_dev && !sdf_obj_dev) return ASDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = (long long)N * N * N;
+  if (!d->band_idx) {
+    ASDF_HIP(hipMalloc((void**)&d->band_idx, 2 * (size_t)kBandCap * sizeof(int)));
+    ASDF_HIP(hipMalloc((void**)&d->band_count, 2 * sizeof(int)));
+  }
+  if (d->band_mark_bytes < (size_t)P + 16) {
+    if (d->band_mark) ASDF_HIP(hipFree(d->band_mark));
+    d->band_mark = nullptr; d->band_mark_bytes = 0;
+    ASDF_HIP(hipMalloc((void**)&d->band_mark, (size_t)P + 16));
+    d->band_mark_bytes = (size_t)P + 16;
+  }
+  DecodeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = rec_dev;      // (the box words are by-products; 7 / 15 carry the range report)
+  p.P = P; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
+  p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
+  p.stream = d->stream16_hi; p.cst = d->cst16; p.status = d->status;
+  p.first_mlp = 0; p.num_mlps = 2; p.pf = d->spec.point_feats[0];
+  if (!p.sdf1) p.num_mlps = 1;
+  else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+  const long long ntiles = (P + kWgPts - 1) / kWgPts;
+  const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
+  if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
+  k1h_box_launch(false, p, grid, st);
+  if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
+  d->ev_start = d->ev_stop = nullptr;
+  ASDF_HIP(hipMemsetAsync(d->band_count, 0, 2 * sizeof(int), st));
+  ASDF_HIP(hipMemsetAsync(d->status + 2, 0, 2 * sizeof(int), st));    // [3]: largest |exact - one-plane| of this call
+  float* vols[2] = {sdf_hand_dev, sdf_obj_dev};
+  for (int h = 0; h < 2; ++h) {
+    if (!vols[h]) continue;
+    ASDF_HIP(hipMemsetAsync(d->band_mark, 0, (size_t)P, st));
+    const long long groups = (long long)(((N - 1) + 3) >> 2) * (N - 1) * (N - 1);
+    const int mgrid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[h], N, tau, d->band_mark);
+    const long long items = (P + 15) / 16;
+    const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+    hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, d->band_idx + (size_t)h * kBandCap,
+                       d->band_count + h, kBandCap);
+    DecodeParams q = p;                 // exact values (fp32 MFMA chain) of this head at its marked voxels
+    q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr; q.neg_thr = 0.0f;
+    q.sdf0 = h == 0 ? vols[0] : nullptr; q.sdf1 = h == 1 ? vols[1] : nullptr;
+    q.first_mlp = h; q.num_mlps = 1;
+    q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->band_idx + (size_t)h * kBandCap; q.count_dev = d->band_count + h; q.P = kBandCap;
+    const int rgrid = kBandCap / kWgPts < d->num_cus ? kBandCap / kWgPts : d->num_cus;
+    k1_launch(d->kp, false, q, rgrid, st);
+  }
+  ASDF_HIP(hipGetLastError());
+  ASDF_HIP(hipMemcpyAsync(rec_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));
+  ASDF_HIP(hipMemcpyAsync(rec_dev + 28, d->band_count, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
   return ASDF_OK;
 }
 

@@ -300,6 +300,11 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       const bool is_hand = head == 0;
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
+        if (p.mode == kGridSubset && p.status && !p.bbox) {
+          // re-evaluation without a box to patch (the narrow-band fine sweep): only the measured error of what it replaces
+          if (out) atomicMax(p.status + 3, __float_as_int(fabsf(sdf - out[po])));
+          if (combined && p.sdf1) atomicMax(p.status + 3, __float_as_int(fabsf(sdfb - p.sdf1[po])));
+        }
         if (p.mode == kGridSubset && p.bbox) {
           // refinement of an existing volume: patch the negative-voxel box for every sign change instead of recounting
           auto patch = [&](float* vol, float now, int* rec) {

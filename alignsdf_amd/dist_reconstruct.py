@@ -97,9 +97,14 @@ def main(argv=None):
     p.add_argument("--coarse", choices=["exact", "box"], default=None,
                    help="coarse pass: an ordinary sweep (default) or the box-only one-plane sweep with exact re-evaluation of "
                         "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
+    p.add_argument("--fine", choices=["exact", "band"], default=None,
+                   help="fine pass: an ordinary sweep (default) or the narrow-band sweep (one fp16 plane, the corners of every cell "
+                        "that can be active re-evaluated on the fp32 chain: the meshes of the fp32 chain, ~2x faster with --coarse box)")
     args = p.parse_args(argv)
     if args.coarse:
         os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
+    if args.fine:
+        os.environ["ASDF_FINE"] = args.fine
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     names = json.load(open(split))["filenames"]
     specs, decoder = rc.load_experiment(args.experiment_directory)

@@ -17,6 +17,8 @@ from . import _native
 
 DEFAULT_MATH = "f16x3"
 DEFAULT_COARSE = "exact"      # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
+DEFAULT_FINE = "exact"        # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
+BAND_CAP = 1 << 21
 
 
 def _effective(module_sd, name):
@@ -174,6 +176,14 @@ class HipSdfDecoder:
         self.coarse_mode = os.environ.get("ASDF_COARSE", DEFAULT_COARSE)
         if self.coarse_mode not in ("exact", "box"):
             raise ValueError("ASDF_COARSE must be 'exact' or 'box', not %r" % self.coarse_mode)
+        # fine pass: "exact" = an ordinary sweep, "band" = one-plane sweep + exact re-evaluation of the corners of every cell
+        # that can be active (asdf_decode_grid_band) - for volumes that go to marching cubes and nowhere else
+        self.fine_mode = os.environ.get("ASDF_FINE", DEFAULT_FINE)
+        if self.fine_mode not in ("exact", "band"):
+            raise ValueError("ASDF_FINE must be 'exact' or 'band', not %r" % self.fine_mode)
+        self._band_failures = 0
+        self._band_skip = False      # the next fine_begin runs an ordinary sweep (a band sweep was just refused)
+        self.band_stats = {"band": 0, "exact": 0, "fallback": 0, "max_err": 0.0, "max_marked": 0}
         self._box_tau = None         # error allowance of the one-plane values, calibrated per decoder (and per scale set)
         self._box_epoch = -1
         self._box_failures = 0
@@ -447,9 +457,83 @@ class HipSdfDecoder:
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
             b, keep = bbox.cpu().numpy(), (h, o)
         self.box_stats["exact"] += 1
-        if self._box_usable() and not ticket.get("no_calibration") and (self._box_tau is None or self._box_epoch != self._recalibrations):
+        # the error allowance of the one-plane kernel (shared by the box-only coarse sweep and the narrow-band fine sweep) is
+        # calibrated here, on the coarse lattice, while the decoder is bound to this sample
+        if (self._box_usable() or self._band_usable()) and not ticket.get("no_calibration") and (
+                self._box_tau is None or self._box_epoch != self._recalibrations):
             self._calibrate_box(ticket["args"], keep)
         return b
+
+    # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else
+    def _band_usable(self):
+        return self.fine_mode == "band" and self.math == "f16x3" and not self.nerf_features and not self.combined
+
+    def fine_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True, mc_only=False):
+        """Enqueue the fine pass; returns (sdf_hand, sdf_obj, ticket).  The caller hands the ticket to fine_needs_repeat
+        before it trusts the volumes (one read-back, at the point where it synchronises for marching cubes anyway).
+        mc_only=True declares that the volumes go to marching cubes at level 0 and nowhere else: only then may a decoder
+        set to fine_mode "band" deliver them exact next to the surface and sign-correct elsewhere."""
+        args = (N, origin3, voxel_size, grid_mode, hand, obj)
+        if (mc_only and self._band_usable() and not self._band_skip and self._box_tau is not None
+                and self._box_epoch == self._recalibrations):
+            vh = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
+            vo = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
+            rec = torch.empty(32, dtype=torch.int32, device=self.device)
+            org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
+            with torch.cuda.device(self.device):
+                ev = None
+                if self.box_event_log is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                    ev[1].record()
+                    _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
+                                                                       ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
+                _native.check(self._L.asdf_decode_grid_band(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
+                                                            ctypes.c_float(float(self._box_tau)), vh.data_ptr() if vh is not None else None,
+                                                            vo.data_ptr() if vo is not None else None, rec.data_ptr(), self._stream()),
+                              "asdf_decode_grid_band")
+                if ev is not None:
+                    self.box_event_log.append(ev)
+            return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau}
+        self._band_skip = False
+        vh, vo, bbox2 = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj)
+        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2}
+
+    def fine_needs_repeat(self, ticket):
+        """True when the fine pass has to be repeated (the decoder must be bound to its sample again first): its range or
+        error guards fired and the decoder has been re-calibrated / switched so that the repeat is trustworthy."""
+        if ticket is None:
+            return False
+        if ticket["kind"] == "band":
+            r = ticket["rec"].cpu().numpy()
+            bad = int(r[7]) + int(r[15])
+            err = float(np.int32(r[19]).view(np.float32))
+            marked = max(int(r[28]), int(r[29]))
+            self.band_stats["max_err"] = max(self.band_stats["max_err"], err)
+            self.band_stats["max_marked"] = max(self.band_stats["max_marked"], marked)
+            if not bad and marked <= BAND_CAP and err <= 0.5 * ticket["tau"]:
+                self.band_stats["band"] += 1
+                return False
+            import logging
+            self.band_stats["fallback"] += 1
+            if bad:
+                self._recover(bad)
+            else:
+                logging.warning("narrow-band fine sweep not accepted (marked %d, error %.3g against allowance %.3g): repeated as an "
+                                "ordinary sweep", marked, err, ticket["tau"])
+                self._band_failures += 1
+                if err > 0.5 * ticket["tau"] and self._box_tau is not None:
+                    self._box_tau = min(max(self._box_tau, 4.0 * err), 0.25)
+                if self._band_failures >= 3:
+                    logging.warning("narrow-band fine sweep switched off for this decoder")
+                    self.fine_mode = "exact"
+            self._band_skip = True
+            return True
+        rec = ticket["rec"]
+        if rec is not None and self.fall_back_if_overflowed(rec.cpu().numpy()):
+            return True
+        self.band_stats["exact"] += 1
+        return False
 
     def _calibrate_box(self, args, exact_vols):
         """Error allowance of the one-plane sweep for this decoder and scale set: 4 x the largest |one-plane - split-half|
@@ -463,8 +547,8 @@ class HipSdfDecoder:
                 err = max(err, float((fast - exact).abs().max().item()))
         self._box_epoch = self._recalibrations
         if not np.isfinite(err) or 4.0 * err > 0.05:
-            logging.warning("box-only coarse sweep: one-plane error %.3g too large, switched off for this decoder", err)
-            self.coarse_mode = "exact"
+            logging.warning("one-plane sweeps: error %.3g too large, switched off for this decoder", err)
+            self.coarse_mode = self.fine_mode = "exact"
             return
         self._box_tau = max(4.0 * err, 1e-6)
         logging.info("box-only coarse sweep: one-plane error %.3g, allowance %.3g", err, self._box_tau)

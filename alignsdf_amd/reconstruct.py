@@ -113,21 +113,21 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         b = hip.coarse_finish(ticket)
         boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
         nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
-        # under the split-half arithmetic pass 2 carries a bbox record too: its word 7 / 15 is the fp16 range report,
-        # read (for free) behind the marching-cubes size read-back in surfaces()
-        vh, vo, bbox2 = hip.decode_grid(N, norg.tolist(), nvs.item(), mode, want_bbox=hip.math == "f16x3", hand=hb, obj=ob)
-        return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b, "bbox2": bbox2}
+        # the fine pass carries a guard record (fp16 range report; error check of the narrow-band sweep): read behind the
+        # marching-cubes size read-back in surfaces().  The volumes go to marching cubes only (mc_only).
+        vh, vo, ticket = hip.fine_begin(N, norg.tolist(), nvs.item(), mode, hand=hb, obj=ob, mc_only=True)
+        return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b, "fine_ticket": ticket}
 
     def surfaces(r, sample):
         """Marching cubes (and the label pass) of one sample; returns True when the decoder was re-bound to it."""
         rebound = False
-        bbox2 = r.pop("bbox2", None)
-        while bbox2 is not None and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
-            # pass 2 left the fp16 range: the decoder has been re-calibrated (or switched to the fp32 kernel); repeat this
-            # sample's pass 2
+        ticket = r.pop("fine_ticket", None)
+        while hip.fine_needs_repeat(ticket):
+            # pass 2 left the fp16 range (the decoder has been re-calibrated, or switched to the fp32 kernel) or its
+            # narrow-band form was not accepted: repeat this sample's pass 2
             bind(sample)
             rebound = True
-            r["vol_hand"], r["vol_obj"], bbox2 = hip.decode_grid(N, r["origin"], float(r["voxel_size"]), mode, want_bbox=True, hand=hb, obj=ob)
+            r["vol_hand"], r["vol_obj"], ticket = hip.fine_begin(N, r["origin"], float(r["voxel_size"]), mode, hand=hb, obj=ob, mc_only=True)
         # count phases of both volumes first (no host synchronisation), then one wait, then the emits
         tickets = {part: marching_cubes_begin(r["vol_" + part], 0.0, slot) for slot, (part, on) in enumerate((("hand", hb), ("obj", ob))) if on}
         for part, on in (("hand", hb), ("obj", ob)):
@@ -191,7 +191,8 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
     from .marching_cubes import marching_cubes_device
     hand_branch, obj_branch = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
     t0 = time.perf_counter()
-    r = mesh_utils.decode_two_pass(hand_branch, obj_branch, decoder, latent, mano_results, obj_results, specs, N, grid_mode)
+    r = mesh_utils.decode_two_pass(hand_branch, obj_branch, decoder, latent, mano_results, obj_results, specs, N, grid_mode,
+                                   mc_only=True)
     rec = {"V_hand": 0, "F_hand": 0, "V_obj": 0, "F_obj": 0}
     if mesh_filename is not None:
         stats = {}
@@ -341,9 +342,14 @@ def main(argv=None):
     p.add_argument("--coarse", choices=["exact", "box"], default=None,
                    help="coarse pass: an ordinary sweep (default) or the box-only one-plane sweep with exact re-evaluation of "
                         "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
+    p.add_argument("--fine", choices=["exact", "band"], default=None,
+                   help="fine pass: an ordinary sweep (default) or the narrow-band sweep (one fp16 plane, the corners of every cell "
+                        "that can be active re-evaluated on the fp32 chain: the meshes of the fp32 chain, ~2x faster with --coarse box)")
     args = p.parse_args(argv)
     if args.coarse:
         os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
+    if args.fine:
+        os.environ["ASDF_FINE"] = args.fine
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     output_dir = os.path.join(args.model_directory, "Eval_" + args.task)
     os.makedirs(output_dir, exist_ok=True)

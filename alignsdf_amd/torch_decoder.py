@@ -165,6 +165,14 @@ class TorchModuleDecoder:
     def coarse_finish(self, ticket):
         return ticket["rec"].cpu().numpy()
 
+    def fine_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True, mc_only=False):
+        """The fine pass (same interface as HipSdfDecoder.fine_begin; always an ordinary sweep, nothing to guard)."""
+        h, o, _ = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=False, hand=hand, obj=obj)
+        return h, o, None
+
+    def fine_needs_repeat(self, ticket):
+        return False
+
     def decode_points(self, xyz):
         h, o, _ = self._decode(xyz.detach().to(self.device, torch.float32).contiguous())
         return h, o

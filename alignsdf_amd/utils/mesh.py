@@ -256,10 +256,11 @@ def write_label_outputs(vertices, faces, labels, ply_filename_hand, offset, scal
 
 
 def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode="reference",
-                    cam_intr=None):
+                    cam_intr=None, mc_only=False):
     """Pass 1 on [-1,1]^3, zoom cube, pass 2 (utils/mesh.py:21-121) entirely on the device.
     Returns dict(vol_hand, vol_obj device tensors of pass 2, voxel_size 0-dim fp32 tensor, origin list,
-    bbox int32[16] of pass 1)."""
+    bbox int32[16] of pass 1).  mc_only=True declares that the volumes are handed to marching cubes and nothing else: a
+    decoder set to the narrow-band fine sweep (ASDF_FINE=band) may then deliver them exact next to the surface only.""" 
     hip = decoder_for(decoder, specs, mano_results)
     bind_sample(hip, specs, latent_vec, mano_results, obj_results, cam_intr)
     mode = GRID_MODES[grid_mode]
@@ -275,13 +276,13 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
     if obj_branch:
         boxes.append((b[8:11], b[11:14], int(b[14])))
     new_voxel_size, new_origin = zoom_cube_from_bboxes(boxes, N, voxel_size)
-    # the split-half arithmetic reports fp16 range violations through the bbox record: ask for it in pass 2 as well
-    guard = hip.math == "f16x3"
-    vol_hand, vol_obj, bbox2 = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=guard,
-                                               hand=hand_branch, obj=obj_branch)
-    while guard and hip.fall_back_if_overflowed(bbox2.cpu().numpy()):
-        vol_hand, vol_obj, bbox2 = hip.decode_grid(N, new_origin.tolist(), new_voxel_size.item(), mode, want_bbox=True,
-                                                   hand=hand_branch, obj=obj_branch)
+    # fine pass: an ordinary sweep (range report through its bbox record), or - when the decoder is set to it and the caller
+    # declares that the volumes go to marching cubes only - the narrow-band sweep; either is repeated if its guards fired
+    for _ in range(6):
+        vol_hand, vol_obj, ticket = hip.fine_begin(N, new_origin.tolist(), new_voxel_size.item(), mode, hand=hand_branch, obj=obj_branch,
+                                                   mc_only=mc_only)
+        if not hip.fine_needs_repeat(ticket):
+            break
     return {"vol_hand": vol_hand, "vol_obj": vol_obj, "voxel_size": new_voxel_size, "origin": new_origin.tolist(), "bbox": b}
 
 
@@ -299,7 +300,9 @@ def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, l
     (utils/mesh.py:137-184) and needs a decoder with a classifier head.  As in the reference, the object mesh is
     written with the hand mesh's ICP translation / scale as its offset / scale (utils/mesh.py:123-133,186-195)."""
     decoder.eval() if hasattr(decoder, "eval") else None
-    r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode, cam_intr)
+    # (the volumes go to marching cubes only: a decoder set to the narrow-band fine sweep may use it)
+    r = decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, obj_results, specs, N, grid_mode, cam_intr,
+                        mc_only=True)
     stats = {}
     if hand_branch:
         v, f, offset, scale = convert_sdf_samples_to_ply(r["vol_hand"], r["origin"], r["voxel_size"], filename + "_hand.ply", None,

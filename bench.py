@@ -230,7 +230,10 @@ def main():
     ap.add_argument("--coarse", default=None, choices=["exact", "box"],
                     help="coarse pass of the two-pass flow in the timed region: an ordinary sweep, or the box-only one-plane "
                          "sweep with exact re-evaluation of the box candidates (default: the product's default)")
-    ap.add_argument("--no-other-coarse", action="store_true", help="skip the second full record under the other coarse pass")
+    ap.add_argument("--fine", default=None, choices=["exact", "band"],
+                    help="fine pass in the timed region: an ordinary sweep, or the narrow-band sweep (one-plane values, exact "
+                         "re-evaluation of the corners of every cell that can be active; for marching cubes only)")
+    ap.add_argument("--no-other-coarse", action="store_true", help="skip the full records under the other coarse / fine passes")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -294,6 +297,8 @@ def main():
         dec.set_math(args.math)
     if args.coarse is not None:
         dec.coarse_mode = args.coarse
+    if args.fine is not None:
+        dec.fine_mode = args.fine
     # 64 distinct synthetic samples, resident on the device before timing
     codes = []
     for s in range(64):
@@ -343,6 +348,7 @@ def main():
     elapsed, k1_ms, done = timed(args.warmup, args.steps, args.warmup)
     main_box_ms = list(timed.box_ms)
     main_coarse = dec.coarse_mode if dec._box_usable() else "exact"
+    main_fine = dec.fine_mode if dec._band_usable() else "exact"
     records = [dict(index=rank * args.steps + k, V_hand=d[1], F_hand=d[2], V_obj=d[3], F_obj=d[4], milliseconds=0.0)
                for k, d in enumerate(done)]
     if world > 1:
@@ -362,7 +368,7 @@ def main():
     peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     exec_flop = N ** 3 * 2 * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
 
-    other = parity = mc_line = other_coarse = None
+    other = parity = mc_line = other_coarse = narrow_band = None
     if world == 1:
         last_sample = sample_id(args.warmup + args.steps - 1)
         lat, mano, obj = codes[last_sample]
@@ -413,6 +419,31 @@ def main():
                             "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
                             "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
             dec.coarse_mode = main_coarse
+            # ---- both passes on the one-plane kernel (box-only coarse + narrow-band fine sweep), same samples
+            if main_fine == "exact" and not dec.combined:
+                dec.coarse_mode, dec.fine_mode = "box", "band"
+                e4, k4_ms, done4 = timed(args.warmup, args.steps, max(args.warmup, 2))
+                same_cubes = sum(1 for a, b in zip(done, done4) if a[5] == b[5] and a[6] == b[6])
+                same_vf = sum(1 for a, b in zip(done, done4) if a[1:5] == b[1:5])
+                narrow_band = {"coarse": "box", "fine": "band" if dec._band_usable() else "exact (band switched itself off)",
+                               "steps": args.steps, "ms_per_step": 1e3 * e4 / args.steps, "value": 2 * args.steps / e4, "unit": "meshes/s",
+                               "launch_ms_one_plane_kernel": float(np.mean(timed.box_ms)) if timed.box_ms else None,
+                               "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
+                               "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
+                               "band_stats": dict(dec.band_stats), "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
+                # the meshes of the band volumes against those of the fp32 MFMA chain (the arithmetic the band re-evaluates
+                # on), vertex for vertex, on the parity sample
+                if "f32" in vols and dec._band_usable():
+                    rb = decode_two_pass(True, True, dec, lat, mano, obj, specs, N, mc_only=True)
+                    eq = []
+                    for part in ("hand", "obj"):
+                        vb, fb = marching_cubes_device(rb["vol_" + part], 0.0)
+                        ve, fe = marching_cubes_device(vols["f32"]["vol_" + part], 0.0)
+                        eq.append(bool(torch.equal(vb, ve) and torch.equal(fb, fe)))
+                    narrow_band["meshes_bit_identical_to_fp32_chain"] = eq
+                    narrow_band["sign_differences_to_fp32_chain"] = int(((rb["vol_hand"] < 0) != (vols["f32"]["vol_hand"] < 0)).sum() +
+                                                                        ((rb["vol_obj"] < 0) != (vols["f32"]["vol_obj"] < 0)).sum())
+                dec.coarse_mode, dec.fine_mode = main_coarse, main_fine
         # ---- marching cubes chain (K3-K6) on the last sample's volumes: HBM roofline of the second kernel family
         from alignsdf_amd import marching_cubes as mcmod
         r = vols.get(math0) or decode_two_pass(True, True, dec, lat, mano, obj, specs, N)
@@ -497,10 +528,13 @@ def main():
         if other is not None:
             result["other_math"] = other
         result["config"]["coarse_pass"] = main_coarse
+        result["config"]["fine_pass"] = main_fine
         if main_box_ms:
             result["roofline"]["launch_ms_one_plane_kernel"] = float(np.mean(main_box_ms))
         if other_coarse is not None:
             result["other_coarse_pass"] = other_coarse
+        if narrow_band is not None:
+            result["one_plane_sweeps"] = narrow_band
         if world == 1 and not args.no_cpu_baseline:
             # one extra GPU sample (outside every timed region) with its pass-1 volumes kept for the CPU zoom-cube leg
             sid = 0

@@ -124,6 +124,23 @@ int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], floa
 int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                          float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream);
 
+/* asdf_decode_grid for a volume that is consumed by marching cubes ONLY (the fine pass of utils/mesh.py:82-121 followed by
+ * utils/mesh.py:354): marching cubes reads the eight corner values of a cell only if the cell is active, and otherwise only
+ * their signs.  This entry point
+ *   1. sweeps the lattice with ONE fp16 plane per operand (as asdf_decode_grid_box);
+ *   2. per head, marks the corners of every cell that can be active given |one-plane - exact| < tau - the cells whose corners
+ *      are not all >= tau or all < -tau - (a few percent of the lattice next to the surface) and
+ *   3. re-evaluates exactly those voxels of that head on the fp32 MFMA chain, in place.
+ * Afterwards every voxel a marching-cubes pass at level 0 reads the VALUE of holds what asdf_decode_grid (ASDF_MATH_F32 at the
+ * re-evaluated voxels) delivers, and every other voxel has the right SIGN: the meshes are identical, vertex for vertex;
+ * the volume away from the surface holds fp16-class values and must not be used for anything else.
+ * rec_dev (int32[32], required): [7] / [15] fp16 range report, [16 + 3] largest |exact - one-plane| over the re-evaluated
+ * voxels (float bits), [28] / [29] voxels marked for the hand / object head (more than 2^21: not all were re-evaluated).
+ * A caller must repeat with asdf_decode_grid when [7] / [15] != 0, [28] or [29] > 2^21, or [19] > tau / 2
+ * (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  SeparateDecoder with affine point features only. */
+int asdf_decode_grid_band(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
+                          float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
+
 /* Bounding box of the voxels with value < 0 of one [n0][n1][n2] fp32 device volume, as int32[16] on the
  * device (record 0 only: [0..2] min index per axis, [3..5] max index per axis, [6] count; min = INT_MAX and
  * max = -1 when the count is 0).  Replaces torch.nonzero + min/max in get_higher_res_cube

@@ -160,3 +160,89 @@ def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
         for part in ("hand", "obj"):
             assert torch.equal(a["vol_" + part], b["vol_" + part])
             assert torch.equal(a["verts_" + part], b["verts_" + part]) and torch.equal(a["faces_" + part], b["faces_" + part])
+
+
+# ---- the narrow-band fine sweep (asdf_decode_grid_band, fine_mode "band"): for volumes that go to marching cubes only
+
+@pytest.mark.parametrize("tag,N", [("nerf3", 64), ("nerf3", 128), ("both9", 96), ("nerf3", 256)])
+def test_band_volumes_give_the_identical_meshes(tag, N):
+    """Exact values at every corner of every cell that can be active, the right sign everywhere else: marching cubes must
+    return the very same vertices and faces as on the volumes of the fp32 MFMA chain (ASDF_MATH_F32), whose values the
+    re-evaluated voxels hold - and the faces of the default split-half volumes, with vertices moved by the 1e-7-class
+    difference of the two arithmetics."""
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    hip, specs = _decoder(tag)
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    vs = 2.0 / (N - 1)
+    lattice = ([-0.62, -0.36, -0.37], 1.21 / (N - 1))
+    for sample in range(4):
+        _bind(hip, specs, sample)
+        hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))            # sample 0: calibrates the allowance
+        bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], mc_only=True)
+        repeat = hip.fine_needs_repeat(ticket)
+        if sample == 0:
+            assert ticket["kind"] == "exact" or not repeat
+        assert not repeat, hip.band_stats
+        sh, so, _ = hip.decode_grid(N, lattice[0], lattice[1])                   # the default (split-half) volumes
+        hip.set_math("f32")
+        eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1])                   # the fp32 MFMA chain: what the band re-evaluates on
+        hip.set_math("f16x3")
+        for b, e, s16 in ((bh, eh, sh), (bo, eo, so)):
+            assert int(((b < 0) != (e < 0)).sum()) == 0 and int(((b < 0) != (s16 < 0)).sum()) == 0       # every sign
+            vb, fb = marching_cubes_device(b, 0.0)
+            ve, fe = marching_cubes_device(e, 0.0)
+            assert torch.equal(fb, fe) and torch.equal(vb, ve)                    # the fp32 chain's mesh, bit for bit
+            vs16, fs16 = marching_cubes_device(s16, 0.0)
+            assert torch.equal(fb, fs16) and (vb - vs16).abs().max().item() <= 2e-2   # the default mesh: same faces, vertices within 0.02 voxel
+    assert hip.band_stats["band"] >= 3
+    assert hip.band_stats["fallback"] == 0 and hip.band_stats["max_err"] <= 0.5 * hip._box_tau
+    assert 0 < hip.band_stats["max_marked"] < (1 << 21)
+    hip.close()
+
+
+def test_band_is_used_only_where_the_volumes_go_to_marching_cubes():
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from alignsdf_amd.utils.utils import decoder_for
+    specs = syn.specs_for("nerf3")
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+    hip = decoder_for(dec, specs)
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    N = 96
+    res = {}
+    for mc_only in (False, True, False, True):
+        for sample in (0, 1):
+            lat = torch.from_numpy(syn.latent_code(sample)).cuda()
+            r = decode_two_pass(True, True, dec, lat, None, None, specs, N, mc_only=mc_only)
+            res.setdefault((mc_only, sample), r)
+    assert hip.band_stats["band"] >= 3                      # the mc_only calls (after the calibration) ran the band sweep
+    for sample in (0, 1):
+        a, b = res[(False, sample)], res[(True, sample)]
+        assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
+        # a caller that did not declare mc_only got ordinary volumes: bit-equal to a decoder that never heard of the mode
+        plain = decoder_for(build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()}), specs)
+        plain_r = decode_two_pass(True, True, plain._module if hasattr(plain, "_module") else dec, torch.from_numpy(syn.latent_code(sample)).cuda(),
+                                  None, None, specs, N)
+        assert torch.equal(a["vol_hand"], plain_r["vol_hand"]) and torch.equal(a["vol_obj"], plain_r["vol_obj"])
+        assert not torch.equal(a["vol_hand"], b["vol_hand"])                      # the band volume differs away from the surface
+        assert int(((a["vol_hand"] < 0) != (b["vol_hand"] < 0)).sum()) == 0
+
+
+def test_band_refused_when_the_allowance_is_understated():
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    N = 96
+    vs = 2.0 / (N - 1)
+    _bind(hip, specs, 0)
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+    honest = hip._box_tau
+    hip._box_tau = honest / 64.0
+    _bind(hip, specs, 1)
+    bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "band" and hip.fine_needs_repeat(ticket)             # error seen > half the allowance: refused
+    bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "exact" and not hip.fine_needs_repeat(ticket)        # the repeat is an ordinary sweep
+    eh, eo, _ = hip.decode_grid(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1))
+    assert torch.equal(bh, eh) and torch.equal(bo, eo)
+    assert hip.band_stats["fallback"] == 1 and hip._box_tau > honest / 64.0
+    hip.close()
