@@ -246,3 +246,50 @@ def test_band_refused_when_the_allowance_is_understated():
     assert torch.equal(bh, eh) and torch.equal(bo, eo)
     assert hip.band_stats["fallback"] == 1 and hip._box_tau > honest / 64.0
     hip.close()
+
+
+def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass, synthetic_code_source
+    from alignsdf_amd.utils.utils import decoder_for
+    # one head only
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    N = 96
+    lattice = ([-0.62, -0.36, -0.37], 1.21 / (N - 1))
+    _bind(hip, specs, 0)
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))
+    for hand, obj in ((True, False), (False, True)):
+        _bind(hip, specs, 2)
+        bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], hand=hand, obj=obj, mc_only=True)
+        assert ticket["kind"] == "band" and not hip.fine_needs_repeat(ticket)
+        assert (bh is None) == (not hand) and (bo is None) == (not obj)
+        hip.set_math("f32")
+        eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1], hand=hand, obj=obj)
+        hip.set_math("f16x3")
+        b, e = (bh, eh) if hand else (bo, eo)
+        vb, fb = marching_cubes_device(b, 0.0)
+        ve, fe = marching_cubes_device(e, 0.0)
+        assert torch.equal(vb, ve) and torch.equal(fb, fe)
+    hip.close()
+    # the product's pipeline with both one-plane sweeps against the ordinary run under the fp32 arithmetic
+    specs = syn.specs_for("nerf3")
+    src = synthetic_code_source("nerf3", "cuda")
+    samples = [(i,) + src("s%d" % i, i) for i in (0, 4, 8, 15, 16)]
+    out = {}
+    for name, env in (("fp32", {"ASDF_MATH": "f32"}), ("one_plane", {"ASDF_COARSE": "box", "ASDF_FINE": "band"})):
+        for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+        out[name] = {k: r for k, r in pipelined_two_pass(dec, specs, iter(samples), 64)}
+        if name == "one_plane":
+            hipd = decoder_for(dec, specs)
+            assert hipd.band_stats["band"] == len(samples) and hipd.band_stats["fallback"] == 0, hipd.band_stats      # (the coarse pass of sample 0 calibrated)
+    for k, a in out["fp32"].items():
+        b = out["one_plane"][k]
+        assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
+        for part in ("hand", "obj"):
+            assert torch.equal(a["verts_" + part], b["verts_" + part]) and torch.equal(a["faces_" + part], b["faces_" + part])
