@@ -7,7 +7,8 @@ namespace asdf {
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams p) { sdf_mlp_f16_body<false>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
 // one fp16 plane per operand, one MFMA per product sum: the box-only coarse sweep (asdf_decode_grid_box)
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 1>(p); }
+// (SeparateDecoder: two point groups per wave - 256 points per workgroup tile, every A fragment feeds two MFMAs)
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 1, 2>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true, 0, 2, 1>(p); }
 
 hipError_t k1h_prepare() {

@@ -68,16 +68,21 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 // high planes alone (1 KiB records), so a 16-K-block stage is 16 KiB.
 constexpr int kS16Kb = ASDF16_STAGE_KB;
 constexpr int kS16Head = 1024 / kS16Kb;              // stages per head
-template <int PL>
+// G = point groups per wave (one-plane kernel only): with G = 2 a wave carries 64 points as two groups of 32 whose
+// activations occupy the registers of the two planes of the split-half kernel; every A fragment read from LDS then feeds two
+// MFMAs (one per group).  The one-plane kernel with one group is LDS-bandwidth-bound: four waves reading 1 KiB of A
+// fragments per 32-cycle MFMA are exactly the 128 B / clk of the LDS, before the LDS-DMA writes.
+template <int PL, int G = 1>
 struct S16 {
   static constexpr int kFloats = kS16Kb * 256 * PL;        // floats per stage
   static constexpr int kPieces = kS16Kb * PL / 4;          // 1 KiB LDS-DMA pieces per wave per stage
   static constexpr int kWaveFloats = kFloats / kWaves;     // a wave's share of a stage
   static constexpr int kRingFloats = kRing * kFloats;
-  static constexpr int kMfmas = PL == 2 ? 3 : 1;           // MFMAs per K-block
+  static constexpr int kMfmas = PL == 2 ? 3 : G;           // MFMAs per K-block
   // A fragments are read from LDS this many K-blocks ahead of their MFMAs: the read latency (~100 cycles) has to fit in the
   // MFMA time of that distance - one K-block of three MFMAs (96 cycles), or three K-blocks of one
-  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : 3 * ASDF16_PREFETCH;
+  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : (G == 2 ? 2 : 3) * ASDF16_PREFETCH;
+  static_assert(PL == 2 ? G == 1 : (G == 1 || G == 2), "point groups");
   static_assert(kPieces == 4 || kPieces == 8, "stage size");
 };
 constexpr int kS16Floats = S16<2>::kFloats;
@@ -95,8 +100,22 @@ static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 
 // relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
 // amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
-template <int PL = 2>
-__device__ __forceinline__ void split_part(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax, int e) {
+// (g: -1 = everything, 0 / 1 = only the first / second point group's part - the two-group kernel issues them behind different MFMAs)
+template <int PL = 2, int G = 1>
+__device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
+                                           int e, int g = -1) {
+  if (PL == 1 && G == 2 && g != 0) {       // the second point group: its planes live where the low planes of the split-half kernel do
+    const float t0 = __int_as_float(max(__float_as_int(accb[2 * e]), 0)) * mul;
+    const float t1 = __int_as_float(max(__float_as_int(accb[2 * e + 1]), 0)) * mul;
+#ifndef ASDF16_NO_RANGE_CHECK
+    amax = fmaxf(amax, fmaxf(t0, t1));
+    asm volatile("" : "+v"(amax));
+#endif
+    h8& d = e < 4 ? lo0 : lo1;
+    d[(2 * e) & 7] = (_Float16)t0;
+    d[((2 * e) & 7) + 1] = (_Float16)t1;
+  }
+  if (PL == 1 && G == 2 && g == 1) return;
   if (PL == 1) {
     // one plane: part e converts the NEIGHBOURING accumulator registers 2 e, 2 e + 1 (both land in one packed fp16 register,
     // one v_cvt_pk), about 5 VALU instructions - a part has to fit the shadow of the ONE MFMA of its K-block here
@@ -128,10 +147,11 @@ __device__ __forceinline__ void split_part(const f32x16& acc, float mul, h8& hi0
 #endif
 }
 
-template <int PL = 2>
-__device__ __forceinline__ void split_tile(const f32x16& acc, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax) {
+template <int PL = 2, int G = 1>
+__device__ __forceinline__ void split_tile(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
+                                           int g = -1) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split_part<PL>(acc, mul, hi0, lo0, hi1, lo1, amax, e);
+  for (int e = 0; e < 8; ++e) split_part<PL, G>(acc, accb, mul, hi0, lo0, hi1, lo1, amax, e, g);
 }
 
 // a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
@@ -144,7 +164,7 @@ constexpr int kEpiChunks = 8;
 constexpr int kEpiShift = ASDF16_EPI_SHIFT;
 static_assert(kEpiShift + kEpiChunks <= ASDF16_STAGE_KB, "epilogue slots");
 struct NoOp16 {
-  __device__ __forceinline__ void operator()(int) const {}
+  __device__ __forceinline__ void operator()(int, int = -1) const {}
 };
 typedef NoOp16 NoEpilogue16;
 
@@ -175,14 +195,14 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 // s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
 // ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, int PL, class Pre, class Epi>
-__device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
+template <int KB, int Q, int SLOT, int ABL, int PL, int G, class Pre, class Epi>
+__device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
-                                        h8 (&ah)[S16<PL>::kPrefetch], h8 (&al)[S16<PL>::kPrefetch], Pre&& pre, Epi&& epi) {
-  constexpr int PF = S16<PL>::kPrefetch;
+                                        h8 (&ah)[S16<PL, G>::kPrefetch], h8 (&al)[S16<PL, G>::kPrefetch], Pre&& pre, Epi&& epi) {
+  constexpr int PF = S16<PL, G>::kPrefetch;
   constexpr int BKB = ASDF16_BARRIER_KB;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
-  using SG = S16<PL>;
+  using SG = S16<PL, G>;
   const float* src = next_src + wave * SG::kWaveFloats + lane * 4;
   const unsigned dst = lds_ring_base + (nslot * SG::kFloats + wave * SG::kWaveFloats) * 4;
   const h8* cur = reinterpret_cast<const h8*>(ring + SLOT * SG::kFloats) + lane;
@@ -207,7 +227,9 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
     constexpr int base = Q * kS16Kb;
 #pragma unroll
     for (int j = 0; j < SG::kMfmas; ++j) {
-      if (PL == 1) acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc); else
+      if (PL == 1 && j == 0) acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
+      else if (PL == 1) accb = ASDF_MFMA16(bufh[kb], xl[base + kb], accb);       // the second point group, same A fragment
+      else
 #if ASDF16_MFMA_ORDER == 0
       // W_hi . x_lo, W_lo . x_hi, W_hi . x_hi - small terms first
       acc = ASDF_MFMA16(j == 1 ? bufl[kb] : bufh[kb], j == 0 ? xl[base + kb] : xh[base + kb], acc);
@@ -233,8 +255,14 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
 #ifdef ASDF16_FENCE_EVERY_MFMA
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      if (PL == 1 && G == 2) {
+        // two point groups: each group's share of the deferred epilogue goes behind ONE of the two MFMAs (left to itself the
+        // scheduler issues both MFMAs back to back - the second waits a whole MFMA for the pipe - and then all the VALU work)
+        epi(kb, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    epi(kb);
+    if (!(PL == 1 && G == 2)) epi(kb);
     // K-block = scheduling region (hoisted, 16 K-blocks of A fragments do not fit the register file either)
     if (ASDF16_LOADS_FIRST || (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1)) __builtin_amdgcn_sched_barrier(0);
   }
@@ -253,10 +281,12 @@ __device__ __forceinline__ void stage16(f32x16& acc, const h8 (&xh)[KB], const h
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
 // MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
 // constants block is 40 / 75 KiB).
-template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2>
+template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
-  using SG = S16<PL>;
+  using SG = S16<PL, G>;
+  static_assert(G == 1 || (!TWO_OUT && KP == 2), "two point groups: SeparateDecoder with affine features");
+  constexpr int kTilePts = kWgPts * G;           // points per workgroup tile
   static_assert(lds_bytes_f16(KP, PL) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
@@ -267,7 +297,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
 
-  const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
+  const long long ntiles = (p.P + kTilePts - 1) / kTilePts;
   if ((long long)blockIdx.x >= ntiles) return;
 
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
@@ -315,13 +345,27 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       long long seg_t[8];
 #endif
       ASDF16_MARK(0);
-      const long long pi = tile * kWgPts + wave * kWavePts + (lane & 31);
+      const long long pi = tile * kTilePts + wave * (kWavePts * G) + (lane & 31);
       const bool valid = pi < p.P;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
       if (p.mode == kPointList) {
         if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
       } else {
         grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+      }
+      // second point group (G == 2): the next 32 points
+      const long long pib = pi + kWavePts;
+      const bool validb = G == 2 && pib < p.P;
+      float bpb[2] = {0.0f, 0.0f};
+      if (G == 2) {
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        if (p.mode == kPointList) {
+          if (validb) { y0 = p.xyz[pib * 3 + 0]; y1 = p.xyz[pib * 3 + 1]; y2 = p.xyz[pib * 3 + 2]; }
+        } else {
+          grid_point(validb ? pib : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, y0, y1, y2);
+        }
+        bpb[0] = half ? y1 : y0;
+        bpb[1] = half ? 0.0f : y2;
       }
       // largest plane value (x S_x) this lane hands to the fp16 conversion, per activation vector h0 / h1 / h2: >= 65504
       // is an overflow (range report); the maxima themselves go to the decoder's status record, from which the host
@@ -345,6 +389,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // stage16 - into registers that are dead at that point: the OTHER accumulator of the double buffer takes the next
       // tile's bias row, `pf2` its point-feature fragments, `w4n` the last-layer weights of the next epilogue part.
       f32x16 acc1[2], acc2[2], acc3[2];
+      f32x16 acc1b[2], acc2b[2], acc3b[2];      // G == 2: the accumulators of the second point group
       float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
       float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
       // (the 8 K-step form of PointFeatSize 15 has no registers to spare for these: it reads its fragments at the point of use)
@@ -375,11 +420,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int s = 0; s < KP; ++s) pf0[t & 1][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
       };
-      auto l0_compute = [&](int t) {
+      auto l0_compute = [&](int t, int g = -1) {
         f32x16 acc = kPreloadPf ? acc0[t & 1] : load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+        f32x16 accb = acc;
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane], bp[s], acc);
-        split_tile<PL>(acc, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
+        for (int s = 0; s < KP; ++s) {
+          const float af = kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane];
+          if (g != 1) acc = ASDF_MFMA(af, bp[s], acc);
+          if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
+        }
+        split_tile<PL, G>(acc, accb, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax, g);
       };
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
@@ -387,6 +437,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       constexpr int kL0Front = kS16Kb / 2 < kEpiChunks ? kTilesHidden : kS16Kb / 2;
       l0_load(0);
       acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+      if (G == 2) acc1b[0] = acc1[0];
 #pragma unroll
       for (int t = 0; t < kL0Front; ++t) {
         if (ASDF16_PRELOAD && t + 1 < kTilesHidden) { l0_load(t + 1); __builtin_amdgcn_sched_barrier(0); }
@@ -396,7 +447,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
-  stage16<KB, Q, SLOT, ABL, PL>(ACC, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
+  stage16<KB, Q, SLOT, ABL, PL, G>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       ASDF16_MARK(1);
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
@@ -405,29 +456,32 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
+        f32x16& accb = (G == 2 ? acc1b : acc1)[t & 1];
         if (!ASDF16_PRELOAD && t > 0) acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
         auto pre = [&](int kb) {       // first stage: the layer-0 tile of the NEXT K-block's epilogue slot
           const int c = kb - kEpiShift;
           if (t == 0 && ASDF16_PRELOAD && kL0Front < kTilesHidden && c >= 0 && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
         };
-        auto epi = [&](int kb) {
+        auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (t == 0) {
             if (kL0Front < kTilesHidden) {       // layer-0 tiles 8 .. 15: consumed by the next stage
-              l0_compute(kL0Front + c);
+              l0_compute(kL0Front + c, g);
               if (!ASDF16_PRELOAD && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
             }
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          pin_acc(acc1[(t - 1) & 1]);
-          split_part<PL>(acc1[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1], h1l[2 * (t - 1) + 1], amax1, c);
+          if (g != 1) pin_acc(acc1[(t - 1) & 1]);
+          if (G == 2 && g != 0) pin_acc(acc1b[(t - 1) & 1]);
+          split_part<PL, G>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
+                            h1l[2 * (t - 1) + 1], amax1, c, g);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
-          if (t + 1 < kTilesL1) acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16);
-          else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); load_pf2(0); }
+          if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
+          else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, pre, epi);
@@ -453,26 +507,40 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       auto l2_tile = [&](int t, auto slot_tag) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
+        f32x16& accb = (G == 2 ? acc2b : acc2)[t & 1];
         if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
 #pragma unroll
-        for (int s = 0; s < KP; ++s) acc = ASDF_MFMA(kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane], bp[s], acc);
-        auto epi = [&](int kb) {
+        for (int s = 0; s < KP; ++s) {
+          const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
+          acc = ASDF_MFMA(af, bp[s], acc);
+          if (G == 2) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
+        }
+        auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
-            pin_acc(acc2[(t - 1) & 1]);
-            split_part<PL>(acc2[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1], h2l[2 * (t - 1) + 1], amax2, c);
+            if (g != 1) pin_acc(acc2[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc(acc2b[(t - 1) & 1]);
+            split_part<PL, G>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
+                              h2l[2 * (t - 1) + 1], amax2, c, g);
           } else {
-            pin_acc(acc1[(kTilesL1 - 1) & 1]);
-            split_part<PL>(acc1[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2], h1h[2 * kTilesL1 - 1],
-                       h1l[2 * kTilesL1 - 1], amax1, c);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
+            if (g != 1) pin_acc(acc1[(kTilesL1 - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc(acc1b[(kTilesL1 - 1) & 1]);
+            split_part<PL, G>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
+                              h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, g);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
         };
         auto pre_last = [&](int c) {
           if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
-          if (t + 1 < kTilesHidden) { acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16); load_pf2(t + 1); }
-          else acc3[0] = load_bias16(hc + CL::kB3 + half * 16);
+          if (t + 1 < kTilesHidden) {
+            acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
+            if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
+            load_pf2(t + 1);
+          } else {
+            acc3[0] = load_bias16(hc + CL::kB3 + half * 16);
+            if (G == 2) acc3b[0] = acc3[0];
+          }
         };
         constexpr int S0 = 256 / kS16Kb;         // stages of layer 1
 #if ASDF16_STAGE_KB == 8
@@ -499,42 +567,52 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 
       ASDF16_MARK(3);
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
-      float part = 0.0f, partb = 0.0f;
+      float part = 0.0f, partb = 0.0f, partg = 0.0f;      // partg: the second point group's dot product (G == 2)
       // accumulator registers 2 c, 2 c + 1 of a finished tile into the last-layer dot product(s), weights from (w4c, w4bc)
-      auto dot_w4_part = [&](const f32x16& a, int c) {
+      auto dot_w4_part = [&](const f32x16& a, const f32x16& ab, int c, int g = -1) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
-          part = fmaf(v, w4c[r], part);
-          if (TWO_OUT) partb = fmaf(v, w4bc[r], partb);
+          if (g != 1) {
+            const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
+            part = fmaf(v, w4c[r], part);
+            if (TWO_OUT) partb = fmaf(v, w4bc[r], partb);
+          }
+          if (G == 2 && g != 0) partg = fmaf(__int_as_float(max(__float_as_int(ab[2 * c + r]), 0)), w4c[r], partg);
         }
         if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
+        if (G == 2) asm volatile("" : "+v"(part), "+v"(partg));
       };
 #pragma unroll
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
+        f32x16& accb = (G == 2 ? acc3b : acc3)[t & 1];
         if (!ASDF16_PRELOAD) acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
         auto pre = [&](int kb) {       // first stage: w4 of the next epilogue part
           const int c = kb - kEpiShift;
           if (t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
         };
-        auto epi = [&](int kb) {
+        auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) {
-            pin_acc(acc3[(t - 1) & 1]);
-            dot_w4_part(acc3[(t - 1) & 1], c);
-            next_w4();
+            if (g != 1) pin_acc(acc3[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc(acc3b[(t - 1) & 1]);
+            dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, g);
+            if (g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
           } else {
-            pin_acc(acc2[(kTilesHidden - 1) & 1]);
-            split_part<PL>(acc2[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2], h2l[2 * kTilesHidden - 2],
-                       h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c);  // K-blocks 30, 31: end of this tile
+            if (g != 1) pin_acc(acc2[(kTilesHidden - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc(acc2b[(kTilesHidden - 1) & 1]);
+            split_part<PL, G>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
+                              h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, g);  // K-blocks 30, 31: end of this tile
           }
         };
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
           if (c != ASDF16_PRE_KB) return;
-          if (ASDF16_PRELOAD && t + 1 < kTilesHidden) acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
+          if (ASDF16_PRELOAD && t + 1 < kTilesHidden) {
+            acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
+            if (G == 2) acc3b[(t + 1) & 1] = acc3[(t + 1) & 1];
+          }
           load_w4(t, 0);
           next_w4();
         };
@@ -559,7 +637,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
       for (int c = 0; c < kEpiChunks; ++c) {
         if (c + 1 < kEpiChunks) load_w4(kTilesHidden - 1, c + 1);
-        dot_w4_part(acc3[(kTilesHidden - 1) & 1], c);
+        dot_w4_part(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1], c);
         next_w4();
       }
 #undef ASDF_STAGE16
@@ -570,25 +648,37 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         partb += __shfl_xor(partb, 32);
         sdfb = tanhf(partb + hc[CL::kB4 + 1]);
       }
+      float sdfg = 0.0f;           // the second point group's output (G == 2)
+      if (G == 2) {
+        partg += __shfl_xor(partg, 32);
+        sdfg = tanhf(partg + hc[CL::kB4]);
+      }
       const bool is_hand = head == 0;
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
         if (out) out[pi] = sdf;
         if (TWO_OUT && p.sdf1) p.sdf1[pi] = sdfb;
       }
+      if (G == 2 && validb && half == 1) {       // lanes 32..63 store the second group: 64 consecutive floats per wave
+        float* out = is_hand ? p.sdf0 : p.sdf1;
+        if (out) out[pib] = sdfg;
+      }
       // every lane reports its own activations (the two halves of a wave hold different features of the same point):
       // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
       const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
-      const int bad = (valid && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)))) ? 1 : 0;
-      if (valid && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
+      const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)) ||
+                                            (G == 2 && !(fabsf(sdfg) <= 1.0f)))) ? 1 : 0;
+      if ((valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
         atomicMax(wrec + 16, __float_as_int(amax));
         atomicMax(wrec + 17, __float_as_int(amax1));
         atomicMax(wrec + 18, __float_as_int(amax2));
       }
       if (p.bbox && p.mode != kPointList) {
-        const int i2 = (int)(pi % p.N), i1 = (int)((pi / p.N) % p.N), i0 = (int)((pi / p.N) / p.N);
+        // with two point groups every lane folds ITS point: lanes 0..31 the first group's, lanes 32..63 the second's
+        const long long pf_ = (G == 2 && half == 1) ? pib : pi;
+        const int i2 = (int)(pf_ % p.N), i1 = (int)((pf_ / p.N) % p.N), i0 = (int)((pf_ / p.N) / p.N);
         auto fold = [&](bool neg, int* rec, int extra) {
           int a0 = neg ? i0 : 0x7fffffff, a1 = neg ? i1 : 0x7fffffff, a2 = neg ? i2 : 0x7fffffff;
           int b0 = neg ? i0 : -1, b1 = neg ? i1 : -1, b2 = neg ? i2 : -1, n = neg ? 1 : 0;
@@ -605,7 +695,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             rec[6] += n; rec[7] += extra;
           }
         };
-        fold(valid && half == 0 && sdf < p.neg_thr, wrec, bad);
+        if (G == 2) fold(half == 0 ? (valid && sdf < p.neg_thr) : (validb && sdfg < p.neg_thr), wrec, bad);
+        else fold(valid && half == 0 && sdf < p.neg_thr, wrec, bad);
         if (TWO_OUT) fold(valid && half == 0 && sdfb < p.neg_thr, wrec + 8, 0);
       } else {
         const unsigned long long m = __ballot(bad);

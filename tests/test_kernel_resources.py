@@ -55,6 +55,13 @@ def test_main_decoder_kernel_has_no_scratch(compiled):
         assert len(k) == 1 and k[0]["scratch"] == 0 and k[0]["occupancy"] == 1, (frag, k)
     k = [v for name, v in stats.items() if "25sdf_mlp_f16_nerf15_kernelE" in name]
     assert len(k) == 1 and k[0]["scratch"] <= 512, k
+    # the one-plane kernels of the box-only / narrow-band sweeps (opt-in paths): the CombinedDecoder form is scratch-free; the
+    # SeparateDecoder form carries two point groups per wave (the register footprint of the split-half kernel plus a second
+    # set of accumulators) and keeps a few dozen per-thread constants in scratch
+    k = [v for name, v in stats.items() if "29sdf_mlp_f16p1_combined_kernelE" in name]
+    assert len(k) == 1 and k[0]["scratch"] == 0 and k[0]["occupancy"] == 1, k
+    k = [v for name, v in stats.items() if "20sdf_mlp_f16p1_kernelE" in name]
+    assert len(k) == 1 and k[0]["scratch"] <= 256 and k[0]["vgpr"] + k[0]["agpr"] <= 512 and k[0]["occupancy"] == 1, k
     # the streaming kernels must not touch scratch either
     for k, v in stats.items():
         if "fold_sample" in k or "neg_bbox" in k:
@@ -78,3 +85,9 @@ def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
         inside = [i for i in scratch if mfma[0] < i < mfma[-1]]
         assert not inside, "%s: %d scratch accesses inside the MFMA stream, first at line %d: %s" % (
             mangled, len(inside), inside[0], body[inside[0]].strip())
+    # the two-group one-plane kernel: at most a handful of spill reloads between its 2048 MFMAs per tile (tile boundaries)
+    body = text[text.index("_ZN4asdf20sdf_mlp_f16p1_kernelENS_12DecodeParamsE:"):]
+    body = body[:body.index("s_endpgm")].splitlines()
+    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16" in l]
+    scratch = [i for i, l in enumerate(body) if "scratch_" in l and not l.strip().startswith(";")]
+    assert len(mfma) == 2048 and len([i for i in scratch if mfma[0] < i < mfma[-1]]) <= 8

@@ -21,10 +21,13 @@ using namespace asdf;
 #ifndef PLANES
 #define PLANES 2        // 1 = the one-plane kernel of the box-only coarse sweep
 #endif
+#ifndef GROUPS
+#define GROUPS 1        // 2 = two point groups per wave (one-plane kernel only)
+#endif
 constexpr int kLds = PLANES == 1 ? kLdsBytesF16P1 : kLdsBytesF16;
 __device__ unsigned long long g_ticks[2];
 #define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { \
-    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES>(p); \
+    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES, GROUPS>(p); \
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
@@ -33,9 +36,9 @@ ABL_LIST
 static void seg_report() {
   unsigned long long g[8];
   (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_seg), sizeof(g));
-  const double f = PLANES == 1 ? 1.0 / 3.0 : 1.0;
+  const double f = (PLANES == 1 ? 1.0 / 3.0 : 1.0) * GROUPS;      // (per workgroup tile: 128 x GROUPS points)
   const char* name[5] = {"coordinates + layer-0 tiles 0..7", "layer 1 (+ layer-0 tiles 8..15)", "layer 2", "layer 3", "last epilogue, tanh, stores, box fold"};
-  const double ideal[5] = {8 * 2 * 64.0, 8 * 32 * 96.0 * f + 8 * 2 * 64.0, 16 * 16 * 96.0 * f + 16 * 2 * 64.0, 16 * 32 * 96.0 * f, 0.0};
+  const double ideal[5] = {8 * 2 * 64.0 * GROUPS, 8 * 32 * 96.0 * f + 8 * 2 * 64.0 * GROUPS, 16 * 16 * 96.0 * f + 16 * 2 * 64.0 * GROUPS, 16 * 32 * 96.0 * f, 0.0};
   double tot = 0, toti = 0;
   for (int k = 0; k < 5; ++k) {
     const double c = (double)(g[k + 1] - g[k]);
@@ -74,7 +77,7 @@ int main(int argc, char** argv) {
   p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0; p.bbox = bbox;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const double flop = (double)P * 2 * 3145728.0 / (PLANES == 1 ? 3 : 1);
-  printf("PLANES %d  PREFETCH %d  BARRIER_KB %d  data %s\n", PLANES, ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
+  printf("GROUPS %d  PLANES %d  PREFETCH %d  BARRIER_KB %d  data %s\n", GROUPS, PLANES, ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
 #define X(n) { (void)hipFuncSetAttribute((const void*)k_abl_##n, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \
     float best = 1e9; double ghz = 0; for (int it = 0; it < 4; ++it) { (void)hipEventRecord(e0); hipLaunchKernelGGL(k_abl_##n, dim3(256), dim3(256), kLds, 0, p); \
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); \
