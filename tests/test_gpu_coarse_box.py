@@ -293,3 +293,34 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
         assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
         for part in ("hand", "obj"):
             assert torch.equal(a["verts_" + part], b["verts_" + part]) and torch.equal(a["faces_" + part], b["faces_" + part])
+
+
+def test_one_plane_sweeps_over_all_64_synthetic_samples():
+    """Every synthetic sample (the 64 the bench cycles through): box-only coarse sweep = the ordinary boxes, narrow-band
+    fine sweep = the fp32 chain's meshes, no sweep refused."""
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    N = 96
+    vs = 2.0 / (N - 1)
+    checked = 0
+    for sample in range(64):
+        _bind(hip, specs, sample)
+        b = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+        w = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)[2].cpu().numpy()
+        assert _boxes(b) == _boxes(w), sample
+        nvs, norg = zoom_cube_from_bboxes([(b[0:3], b[3:6], int(b[6])), (b[8:11], b[11:14], int(b[14]))], N, vs)
+        bh, bo, ticket = hip.fine_begin(N, norg.tolist(), nvs.item(), mc_only=True)
+        assert not hip.fine_needs_repeat(ticket), (sample, hip.band_stats)
+        hip.set_math("f32")
+        eh, eo, _ = hip.decode_grid(N, norg.tolist(), nvs.item())
+        hip.set_math("f16x3")
+        for bv, ev in ((bh, eh), (bo, eo)):
+            vb, fb = marching_cubes_device(bv, 0.0)
+            ve, fe = marching_cubes_device(ev, 0.0)
+            assert torch.equal(vb, ve) and torch.equal(fb, fe), sample
+            checked += 1
+    assert checked == 128 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+    assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 64
+    hip.close()
