@@ -35,15 +35,24 @@ def sample_surface(verts, faces, count, seed=0):
     by cumulative area, reflect barycentric pairs whose sum exceeds 1), driven by the repo's seeded generator."""
     v = np.asarray(verts, dtype=np.float64)
     f = np.asarray(faces, dtype=np.int64)
-    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
-    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    # areas of all faces (190 k per hand surface at N = 256) on column vectors: the same products, differences and sums as
+    # 0.5 * norm(cross(b - a, c - a)) - bit for bit - at a third of the time of the [F, 3] gathers + np.cross (this runs on
+    # the host between two decoder passes of the sample pipeline)
+    vx, vy, vz = np.ascontiguousarray(v[:, 0]), np.ascontiguousarray(v[:, 1]), np.ascontiguousarray(v[:, 2])
+    i0, i1, i2 = f[:, 0], f[:, 1], f[:, 2]
+    ax, ay, az = vx[i0], vy[i0], vz[i0]
+    e1x, e1y, e1z = vx[i1] - ax, vy[i1] - ay, vz[i1] - az
+    e2x, e2y, e2z = vx[i2] - ax, vy[i2] - ay, vz[i2] - az
+    cx, cy, cz = e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x
+    area = 0.5 * np.sqrt(cx * cx + cy * cy + cz * cz)
     cum = np.cumsum(area)
     pick = np.searchsorted(cum, synthetic.uniform((count,), 9100 + seed) * cum[-1])
     pick = np.minimum(pick, len(f) - 1)
     r = synthetic.uniform((count, 2), 9200 + seed)
     flip = r.sum(1) > 1.0
     r[flip] = np.abs(r[flip] - 1.0)
-    return a[pick] + (b[pick] - a[pick]) * r[:, :1] + (c[pick] - a[pick]) * r[:, 1:]
+    a, b, c = v[f[pick, 0]], v[f[pick, 1]], v[f[pick, 2]]          # only the picked faces
+    return a + (b - a) * r[:, :1] + (c - a) * r[:, 1:]
 
 
 def normalise_source(points_source, points_target):
