@@ -324,3 +324,44 @@ def test_one_plane_sweeps_over_all_64_synthetic_samples():
     assert checked == 128 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 64
     hip.close()
+
+
+@pytest.mark.parametrize("name", ["spread1e4", "huge", "tiny", "heavy_tails", "gain30", "latent_x10"])
+def test_one_plane_sweeps_on_adversarial_decoders(name):
+    """The decoders that attack the split-half arithmetic (tests/test_gpu_split_half_adversarial.py), through the one-plane
+    sweeps: whatever the one-plane error is on them, the outcome is either accepted AND right (boxes of the ordinary sweep,
+    meshes of the fp32 chain) or refused and repeated as an ordinary sweep - never a silently different cube or mesh."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from tests.test_gpu_split_half_adversarial import variant
+    sd, lat = variant(name)
+    hip = HipSdfDecoder(sd, 256, 3, "nerf")
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    hip.set_sample(torch.from_numpy(lat).cuda())
+    N = 64
+    vs = 2.0 / (N - 1)
+    for rep in range(3):
+        b = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+        w = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)[2].cpu().numpy()
+        assert _boxes(b) == _boxes(w), (name, rep, hip.box_stats)
+        for lattice in (([-1.0, -1.0, -1.0], vs), ([-0.9, -0.8, -0.85], 1.7 / (N - 1))):
+            for _ in range(4):
+                bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], mc_only=True)
+                if not hip.fine_needs_repeat(ticket):
+                    break
+            keep = hip.math
+            hip.set_math("f32")
+            eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1])
+            hip.set_math(keep)
+            for bv, ev in ((bh, eh), (bo, eo)):
+                assert int(((bv < 0) != (ev < 0)).sum()) == 0, (name, ticket["kind"])
+                try:
+                    ve, fe = marching_cubes_device(ev, 0.0)
+                except (ValueError, RuntimeError):
+                    continue                          # no surface on this lattice
+                vb, fb = marching_cubes_device(bv, 0.0)
+                assert torch.equal(fb, fe), (name, ticket["kind"])
+                if ticket["kind"] == "band":
+                    assert torch.equal(vb, ve)        # the fp32 chain's vertices exactly
+    print(name, "box", hip.box_stats, "band", hip.band_stats, "allowance", hip._box_tau, "modes", hip.coarse_mode, hip.fine_mode, hip.math)
+    hip.close()
