@@ -55,6 +55,10 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
 
+    The pipeline exists to produce meshes: it runs the coarse pass through `coarse_begin` / `coarse_finish` and the fine pass
+    through `fine_begin(..., mc_only=True)`, so a decoder set to the opt-in one-plane sweeps (ASDF_COARSE=box, ASDF_FINE=band)
+    uses them here - the yielded `vol_*` are then exact only where marching cubes reads values.
+
     Per sample the GPU work is  pass 1 -> [64-byte bbox readback, zoom cube on the host] -> pass 2 -> marching cubes,
     and only the bracketed step and the MC size readbacks synchronise with the host.  Pass 1 of sample k+1 is queued
     right behind pass 2 of sample k, i.e. before sample k's marching cubes and before the consumer's host work
