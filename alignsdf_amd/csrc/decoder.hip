@@ -333,8 +333,18 @@ struct asdf_decoder {
   size_t band_mark_bytes;
   int* band_idx;    // [2][kBandCap]
   int* band_count;  // [2] device words
+  // the exact re-evaluation of a short voxel list is latency-bound (one 128-point tile of one MLP on the fp32 chain takes
+  // 0.24 ms whatever the list holds): the two MLPs of a SeparateDecoder run side by side, the second on this stream
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
 };
 static constexpr int kNearCap = 1 << 16;
+
+namespace asdf {
+// K1 in its subset mode over one voxel list: both MLPs of a SeparateDecoder concurrently (one launch each, the second on the
+// decoder's side stream, joined back into `st`), everything else as one launch
+static int launch_subset(asdf_decoder* d, const DecodeParams& q, bool two_out, int grid, hipStream_t st);
+}
 static constexpr int kBandCap = 1 << 21;     // voxels per head the narrow-band sweep re-evaluates at most (12 % of 256^3)
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
@@ -385,6 +395,9 @@ int asdf_device_count(void) {
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
   float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi};
+  if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
+  if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+  if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   if (d->band_mark) (void)hipFree(d->band_mark);
   if (d->band_idx) (void)hipFree(d->band_idx);
   if (d->band_count) (void)hipFree(d->band_count);
@@ -462,6 +475,9 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) e = hipMemset(d->status, 0, 16 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kNearCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_count, sizeof(int));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
   d->refine_tau = 4e-6f;
 
   if (e != hipSuccess) {
@@ -529,6 +545,25 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
   return ASDF_OK;
 }
 
+namespace asdf {
+static int launch_subset(asdf_decoder* d, const DecodeParams& q, bool two_out, int grid, hipStream_t st) {
+  if (two_out || q.num_mlps != 2 || !q.sdf0 || !q.sdf1 || !d->side) {
+    k1_launch(d->kp, two_out, q, grid, st);
+    return ASDF_OK;
+  }
+  DecodeParams q0 = q, q1 = q;
+  q0.num_mlps = 1; q0.first_mlp = 0; q0.sdf1 = nullptr;
+  q1.num_mlps = 1; q1.first_mlp = 1; q1.sdf0 = nullptr;
+  ASDF_HIP(hipEventRecord(d->ev_fork, st));
+  ASDF_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+  k1_launch(d->kp, false, q0, grid, st);
+  k1_launch(d->kp, false, q1, grid, d->side);
+  ASDF_HIP(hipEventRecord(d->ev_join, d->side));
+  ASDF_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
+  return ASDF_OK;
+}
+}  // namespace asdf
+
 static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   if (!d->sample_bound) return ASDF_EINVAL;
   p.stream = d->stream;
@@ -589,7 +624,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
       q.stream = d->stream; q.cst = d->cst; q.bbox = p.bbox; q.fixup_flag = p.bbox ? d->status + 2 : nullptr;
       q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
       const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
-      k1_launch(d->kp, two_out, q, rgrid, st);
+      { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
       if (p.bbox) {
         // the fused box saw the unrefined values.  The refinement pass patches it in place - a voxel that became negative
         // extends the box and the count exactly - and raises a flag when one became non-negative (the box may have to
@@ -662,7 +697,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   q.stream = d->stream; q.cst = d->cst; q.fixup_flag = d->status + 2;
   q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
   const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
-  k1_launch(d->kp, two_out, q, rgrid, st);
+  { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
   ASDF_HIP(hipGetLastError());
   // the status record of this call travels with the boxes: one read-back for the caller
   ASDF_HIP(hipMemcpyAsync(bbox_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -175,7 +175,7 @@ int asdf_decoder_get_math(const asdf_decoder_t* dec);
  * (well inside the 1e-5 bar), but the SIGN of a voxel that close to the level is all that the zoom cube
  * (utils/mesh.py:208-237) and marching cubes (utils/mesh.py:354) look at: with the refinement, boxes and surfaces are
  * those of the fp32 chain, voxel for voxel.  Costs one compaction pass over the volumes and one fp32 launch over a few
- * hundred points (about 0.5 ms per N = 256 sweep).  At most 65536 voxels are refined per sweep; asdf_decoder_status
+ * hundred points (about 0.25 ms per sweep, whatever N).  At most 65536 voxels are refined per sweep; asdf_decoder_status
  * word [1] counts any beyond that. */
 int asdf_decoder_set_refine(asdf_decoder_t* dec, float tau);
 
