@@ -280,6 +280,21 @@ __global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* 
   }
 }
 
+// near-level voxels among the LISTED ones of one volume (the narrow-band sweep refines only where it re-evaluated)
+__global__ __launch_bounds__(256) void collect_near_level_list_kernel(const float* __restrict__ vol, const int* __restrict__ list,
+                                                                      const int* __restrict__ list_count, int list_cap, float tau, int* idx,
+                                                                      int* count, int cap, int* status) {
+  const int n = *list_count < list_cap ? *list_count : list_cap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int v = list[i];
+    if (fabsf(vol[v]) < tau) {
+      const int k = atomicAdd(count, 1);
+      if (k < cap) idx[k] = v;
+      else if (status) atomicAdd(status + 1, 1);
+    }
+  }
+}
+
 __global__ void bbox_reinit_keep_flags_kernel(int* bbox, const int* flag) {   // words 7 / 15 (the fp16 range report) survive
   if (flag && *flag == 0) return;
   const int i = threadIdx.x;
@@ -363,7 +378,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 116; }
+int asdf_version(void) { return 117; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -752,13 +767,28 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, d->band_idx + (size_t)h * kBandCap,
                        d->band_count + h, kBandCap);
-    DecodeParams q = p;                 // exact values (fp32 MFMA chain) of this head at its marked voxels
-    q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr; q.neg_thr = 0.0f;
+    // the values of the ordinary sweep at the marked voxels of this head: the split-half kernel over the list ...
+    DecodeParams q = p;
+    q.stream = d->stream16; q.cst = d->cst16; q.bbox = nullptr; q.neg_thr = 0.0f;
     q.sdf0 = h == 0 ? vols[0] : nullptr; q.sdf1 = h == 1 ? vols[1] : nullptr;
     q.first_mlp = h; q.num_mlps = 1;
     q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->band_idx + (size_t)h * kBandCap; q.count_dev = d->band_count + h; q.P = kBandCap;
     const int rgrid = kBandCap / kWgPts < d->num_cus ? kBandCap / kWgPts : d->num_cus;
-    k1_launch(d->kp, false, q, rgrid, st);
+    k1h_subset_launch(q, rgrid, st);
+  }
+  if (d->refine_tau > 0.0f) {
+    // ... and, as behind every split-half sweep, the fp32 chain where those values lie within refine_tau of the level (both
+    // MLPs over the union of the two near-level lists: an extra exact value is harmless)
+    ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
+    for (int h = 0; h < 2; ++h)
+      if (vols[h])
+        hipLaunchKernelGGL(collect_near_level_list_kernel, dim3(256), dim3(256), 0, st, vols[h], d->band_idx + (size_t)h * kBandCap,
+                           d->band_count + h, kBandCap, d->refine_tau, d->near_idx, d->near_count, kNearCap, d->status);
+    DecodeParams q = p;
+    q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr; q.neg_thr = 0.0f; q.status = nullptr;
+    q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
+    const int ngrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
+    { const int rc = launch_subset(d, q, false, ngrid, st); if (rc != ASDF_OK) return rc; }
   }
   ASDF_HIP(hipGetLastError());
   ASDF_HIP(hipMemcpyAsync(rec_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -281,7 +281,9 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
 // MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
 // constants block is 40 / 75 KiB).
-template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1>
+// SUB: the kGridSubset form of sdf_mlp_kernel.h - the points are the lattice voxels listed in p.idx (p.count_dev of them, a
+// device word; p.P is the list's capacity), coordinates from the voxel index, outputs scattered in place, no box.
+template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1, bool SUB = false>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
   using SG = S16<PL, G>;
@@ -297,7 +299,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
 
-  const long long ntiles = (p.P + kTilePts - 1) / kTilePts;
+  static_assert(!SUB || G == 1, "subset mode: one point group");
+  long long npts = p.P;
+  if (SUB) { const long long c = *p.count_dev; npts = c < npts ? c : npts; }
+  const long long ntiles = (npts + kTilePts - 1) / kTilePts;
   if ((long long)blockIdx.x >= ntiles) return;
 
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
@@ -346,16 +351,19 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #endif
       ASDF16_MARK(0);
       const long long pi = tile * kTilePts + wave * (kWavePts * G) + (lane & 31);
-      const bool valid = pi < p.P;
+      const bool valid = pi < npts;
+      const long long po = SUB ? (valid ? (long long)p.idx[pi] : 0) : pi;      // where the point lives in the lattice / the outputs
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      if (p.mode == kPointList) {
+      if (SUB) {
+        grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+      } else if (p.mode == kPointList) {
         if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
       } else {
         grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
       }
       // second point group (G == 2): the next 32 points
       const long long pib = pi + kWavePts;
-      const bool validb = G == 2 && pib < p.P;
+      const bool validb = G == 2 && pib < npts;
       float bpb[2] = {0.0f, 0.0f};
       if (G == 2) {
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
@@ -656,8 +664,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const bool is_hand = head == 0;
       if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
-        if (out) out[pi] = sdf;
-        if (TWO_OUT && p.sdf1) p.sdf1[pi] = sdfb;
+        // (subset mode replaces values: the largest change is the measured error of the arithmetic it corrects)
+        if (SUB && p.status && out) atomicMax(p.status + 3, __float_as_int(fabsf(sdf - out[po])));
+        if (out) out[po] = sdf;
+        if (TWO_OUT && p.sdf1) p.sdf1[po] = sdfb;
       }
       if (G == 2 && validb && half == 1) {       // lanes 32..63 store the second group: 64 consecutive floats per wave
         float* out = is_hand ? p.sdf0 : p.sdf1;
@@ -675,7 +685,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         atomicMax(wrec + 17, __float_as_int(amax1));
         atomicMax(wrec + 18, __float_as_int(amax2));
       }
-      if (p.bbox && p.mode != kPointList) {
+      if (!SUB && p.bbox && p.mode != kPointList) {
         // with two point groups every lane folds ITS point: lanes 0..31 the first group's, lanes 32..63 the second's
         const long long pf_ = (G == 2 && half == 1) ? pib : pi;
         const int i2 = (int)(pf_ % p.N), i1 = (int)((pf_ / p.N) % p.N), i0 = (int)((pf_ / p.N) / p.N);

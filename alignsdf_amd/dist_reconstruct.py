@@ -99,7 +99,7 @@ def main(argv=None):
                         "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
     p.add_argument("--fine", choices=["exact", "band"], default=None,
                    help="fine pass: an ordinary sweep (default) or the narrow-band sweep (one fp16 plane, the corners of every cell "
-                        "that can be active re-evaluated on the fp32 chain: the meshes of the fp32 chain, ~2x faster with --coarse box)")
+                        "that can be active re-evaluated as an ordinary sweep would: identical meshes, ~2.4x faster with --coarse box)")
     args = p.parse_args(argv)
     if args.coarse:
         os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed

@@ -176,8 +176,8 @@ class HipSdfDecoder:
         self.coarse_mode = os.environ.get("ASDF_COARSE", DEFAULT_COARSE)
         if self.coarse_mode not in ("exact", "box"):
             raise ValueError("ASDF_COARSE must be 'exact' or 'box', not %r" % self.coarse_mode)
-        # fine pass: "exact" = an ordinary sweep, "band" = one-plane sweep + exact re-evaluation of the corners of every cell
-        # that can be active (asdf_decode_grid_band) - for volumes that go to marching cubes and nowhere else
+        # fine pass: "exact" = an ordinary sweep, "band" = one-plane sweep + re-evaluation (as the ordinary sweep would) of the
+        # corners of every cell that can be active (asdf_decode_grid_band) - for volumes that go to marching cubes and nowhere else
         self.fine_mode = os.environ.get("ASDF_FINE", DEFAULT_FINE)
         if self.fine_mode not in ("exact", "band"):
             raise ValueError("ASDF_FINE must be 'exact' or 'band', not %r" % self.fine_mode)

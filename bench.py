@@ -431,18 +431,18 @@ def main():
                                "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
                                "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
                                "band_stats": dict(dec.band_stats), "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
-                # the meshes of the band volumes against those of the fp32 MFMA chain (the arithmetic the band re-evaluates
-                # on), vertex for vertex, on the parity sample
-                if "f32" in vols and dec._band_usable():
+                # the meshes of the band volumes against those of the ordinary sweeps (whose values the band re-evaluates to),
+                # vertex for vertex, on the parity sample
+                if "f16x3" in vols and dec._band_usable():
                     rb = decode_two_pass(True, True, dec, lat, mano, obj, specs, N, mc_only=True)
                     eq = []
                     for part in ("hand", "obj"):
                         vb, fb = marching_cubes_device(rb["vol_" + part], 0.0)
-                        ve, fe = marching_cubes_device(vols["f32"]["vol_" + part], 0.0)
+                        ve, fe = marching_cubes_device(vols["f16x3"]["vol_" + part], 0.0)
                         eq.append(bool(torch.equal(vb, ve) and torch.equal(fb, fe)))
-                    narrow_band["meshes_bit_identical_to_fp32_chain"] = eq
-                    narrow_band["sign_differences_to_fp32_chain"] = int(((rb["vol_hand"] < 0) != (vols["f32"]["vol_hand"] < 0)).sum() +
-                                                                        ((rb["vol_obj"] < 0) != (vols["f32"]["vol_obj"] < 0)).sum())
+                    narrow_band["meshes_bit_identical_to_ordinary_sweeps"] = eq
+                    narrow_band["sign_differences_to_ordinary_sweeps"] = int(((rb["vol_hand"] < 0) != (vols["f16x3"]["vol_hand"] < 0)).sum() +
+                                                                             ((rb["vol_obj"] < 0) != (vols["f16x3"]["vol_obj"] < 0)).sum())
                 dec.coarse_mode, dec.fine_mode = main_coarse, main_fine
         # ---- marching cubes chain (K3-K6) on the last sample's volumes: HBM roofline of the second kernel family
         from alignsdf_amd import marching_cubes as mcmod

@@ -130,11 +130,13 @@ int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], 
  *   1. sweeps the lattice with ONE fp16 plane per operand (as asdf_decode_grid_box);
  *   2. per head, marks the corners of every cell that can be active given |one-plane - exact| < tau - the cells whose corners
  *      are not all >= tau or all < -tau - (a few percent of the lattice next to the surface) and
- *   3. re-evaluates exactly those voxels of that head on the fp32 MFMA chain, in place.
- * Afterwards every voxel a marching-cubes pass at level 0 reads the VALUE of holds what asdf_decode_grid (ASDF_MATH_F32 at the
- * re-evaluated voxels) delivers, and every other voxel has the right SIGN: the meshes are identical, vertex for vertex;
+ *   3. re-evaluates exactly those voxels of that head the way asdf_decode_grid evaluates every voxel - the decoder's split-half
+ *      arithmetic over the list, then the fp32 MFMA chain where the result lies within the refinement threshold of the level -
+ *      in place.
+ * Afterwards every voxel a marching-cubes pass at level 0 reads the VALUE of holds exactly what asdf_decode_grid delivers
+ * there, and every other voxel has the right SIGN: the meshes are identical, vertex for vertex and face for face;
  * the volume away from the surface holds fp16-class values and must not be used for anything else.
- * rec_dev (int32[32], required): [7] / [15] fp16 range report, [16 + 3] largest |exact - one-plane| over the re-evaluated
+ * rec_dev (int32[32], required): [7] / [15] fp16 range report, [16 + 3] largest |re-evaluated - one-plane| over the re-evaluated
  * voxels (float bits), [28] / [29] voxels marked for the hand / object head (more than 2^21: not all were re-evaluated).
  * A caller must repeat with asdf_decode_grid when [7] / [15] != 0, [28] or [29] > 2^21, or [19] > tau / 2
  * (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  SeparateDecoder with affine point features only. */

@@ -167,9 +167,8 @@ def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
 @pytest.mark.parametrize("tag,N", [("nerf3", 64), ("nerf3", 128), ("both9", 96), ("nerf3", 256)])
 def test_band_volumes_give_the_identical_meshes(tag, N):
     """Exact values at every corner of every cell that can be active, the right sign everywhere else: marching cubes must
-    return the very same vertices and faces as on the volumes of the fp32 MFMA chain (ASDF_MATH_F32), whose values the
-    re-evaluated voxels hold - and the faces of the default split-half volumes, with vertices moved by the 1e-7-class
-    difference of the two arithmetics."""
+    return the very same vertices and faces as on the volumes of the ordinary sweep, whose values (split-half arithmetic, fp32
+    chain next to the level) the re-evaluated voxels hold."""
     from alignsdf_amd.marching_cubes import marching_cubes_device
     hip, specs = _decoder(tag)
     hip.coarse_mode, hip.fine_mode = "box", "band"
@@ -183,17 +182,12 @@ def test_band_volumes_give_the_identical_meshes(tag, N):
         if sample == 0:
             assert ticket["kind"] == "exact" or not repeat
         assert not repeat, hip.band_stats
-        sh, so, _ = hip.decode_grid(N, lattice[0], lattice[1])                   # the default (split-half) volumes
-        hip.set_math("f32")
-        eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1])                   # the fp32 MFMA chain: what the band re-evaluates on
-        hip.set_math("f16x3")
-        for b, e, s16 in ((bh, eh, sh), (bo, eo, so)):
-            assert int(((b < 0) != (e < 0)).sum()) == 0 and int(((b < 0) != (s16 < 0)).sum()) == 0       # every sign
+        sh, so, _ = hip.decode_grid(N, lattice[0], lattice[1])                   # the ordinary (default) volumes
+        for b, e in ((bh, sh), (bo, so)):
+            assert int(((b < 0) != (e < 0)).sum()) == 0                          # every sign
             vb, fb = marching_cubes_device(b, 0.0)
             ve, fe = marching_cubes_device(e, 0.0)
-            assert torch.equal(fb, fe) and torch.equal(vb, ve)                    # the fp32 chain's mesh, bit for bit
-            vs16, fs16 = marching_cubes_device(s16, 0.0)
-            assert torch.equal(fb, fs16) and (vb - vs16).abs().max().item() <= 2e-2   # the default mesh: same faces, vertices within 0.02 voxel
+            assert torch.equal(fb, fe) and torch.equal(vb, ve)                    # the ordinary sweep's mesh, bit for bit
     assert hip.band_stats["band"] >= 3
     assert hip.band_stats["fallback"] == 0 and hip.band_stats["max_err"] <= 0.5 * hip._box_tau
     assert 0 < hip.band_stats["max_marked"] < (1 << 21)
@@ -265,20 +259,18 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
         bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], hand=hand, obj=obj, mc_only=True)
         assert ticket["kind"] == "band" and not hip.fine_needs_repeat(ticket)
         assert (bh is None) == (not hand) and (bo is None) == (not obj)
-        hip.set_math("f32")
         eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1], hand=hand, obj=obj)
-        hip.set_math("f16x3")
         b, e = (bh, eh) if hand else (bo, eo)
         vb, fb = marching_cubes_device(b, 0.0)
         ve, fe = marching_cubes_device(e, 0.0)
         assert torch.equal(vb, ve) and torch.equal(fb, fe)
     hip.close()
-    # the product's pipeline with both one-plane sweeps against the ordinary run under the fp32 arithmetic
+    # the product's pipeline with both one-plane sweeps against the ordinary run (named "fp32" below for history's sake)
     specs = syn.specs_for("nerf3")
     src = synthetic_code_source("nerf3", "cuda")
     samples = [(i,) + src("s%d" % i, i) for i in (0, 4, 8, 15, 16)]
     out = {}
-    for name, env in (("fp32", {"ASDF_MATH": "f32"}), ("one_plane", {"ASDF_COARSE": "box", "ASDF_FINE": "band"})):
+    for name, env in (("fp32", {}), ("one_plane", {"ASDF_COARSE": "box", "ASDF_FINE": "band"})):
         for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -297,7 +289,7 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
 
 def test_one_plane_sweeps_over_all_64_synthetic_samples():
     """Every synthetic sample (the 64 the bench cycles through): box-only coarse sweep = the ordinary boxes, narrow-band
-    fine sweep = the fp32 chain's meshes, no sweep refused."""
+    fine sweep = the ordinary sweep's meshes, no sweep refused."""
     from alignsdf_amd.marching_cubes import marching_cubes_device
     from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
     hip, specs = _decoder("nerf3")
@@ -313,9 +305,7 @@ def test_one_plane_sweeps_over_all_64_synthetic_samples():
         nvs, norg = zoom_cube_from_bboxes([(b[0:3], b[3:6], int(b[6])), (b[8:11], b[11:14], int(b[14]))], N, vs)
         bh, bo, ticket = hip.fine_begin(N, norg.tolist(), nvs.item(), mc_only=True)
         assert not hip.fine_needs_repeat(ticket), (sample, hip.band_stats)
-        hip.set_math("f32")
         eh, eo, _ = hip.decode_grid(N, norg.tolist(), nvs.item())
-        hip.set_math("f16x3")
         for bv, ev in ((bh, eh), (bo, eo)):
             vb, fb = marching_cubes_device(bv, 0.0)
             ve, fe = marching_cubes_device(ev, 0.0)
@@ -330,7 +320,7 @@ def test_one_plane_sweeps_over_all_64_synthetic_samples():
 def test_one_plane_sweeps_on_adversarial_decoders(name):
     """The decoders that attack the split-half arithmetic (tests/test_gpu_split_half_adversarial.py), through the one-plane
     sweeps: whatever the one-plane error is on them, the outcome is either accepted AND right (boxes of the ordinary sweep,
-    meshes of the fp32 chain) or refused and repeated as an ordinary sweep - never a silently different cube or mesh."""
+    meshes of the ordinary sweep) or refused and repeated as an ordinary sweep - never a silently different cube or mesh."""
     from alignsdf_amd.hip_decoder import HipSdfDecoder
     from alignsdf_amd.marching_cubes import marching_cubes_device
     from tests.test_gpu_split_half_adversarial import variant
@@ -349,10 +339,7 @@ def test_one_plane_sweeps_on_adversarial_decoders(name):
                 bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], mc_only=True)
                 if not hip.fine_needs_repeat(ticket):
                     break
-            keep = hip.math
-            hip.set_math("f32")
             eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1])
-            hip.set_math(keep)
             for bv, ev in ((bh, eh), (bo, eo)):
                 assert int(((bv < 0) != (ev < 0)).sum()) == 0, (name, ticket["kind"])
                 try:
@@ -362,6 +349,6 @@ def test_one_plane_sweeps_on_adversarial_decoders(name):
                 vb, fb = marching_cubes_device(bv, 0.0)
                 assert torch.equal(fb, fe), (name, ticket["kind"])
                 if ticket["kind"] == "band":
-                    assert torch.equal(vb, ve)        # the fp32 chain's vertices exactly
+                    assert torch.equal(vb, ve)        # the ordinary sweep's vertices exactly
     print(name, "box", hip.box_stats, "band", hip.band_stats, "allowance", hip._box_tau, "modes", hip.coarse_mode, hip.fine_mode, hip.math)
     hip.close()
