@@ -7,10 +7,19 @@
 //       acc += W_hi . x_lo + W_lo . x_hi + W_hi . x_hi          (the lo.lo term is < 2^-22 of the product)
 //   fp16 x fp16 products are exact in fp32 and the accumulation is fp32, so the result is fp32-class (measured on the
 //   synthetic decoders: max |error| vs fp64 2.8e-7, the same as the fp32 MFMA chain) at 3/16 of the MFMA time of the
-//   fp32 instruction.  Scales: weights S_w per layer (max |w| S_w in [512, 1024)), activations S_x = 8; biases and the
-//   fp32 point-feature products enter the accumulator pre-multiplied by S_w S_x (pack.h, K0), and the accumulator is
-//   rescaled by the exact power of two 1 / S_w when it is split into the next layer's planes.  fp16 subnormal inputs
-//   are honoured by the MFMA (tools/mfma_f16_probe.hip), so small low planes degrade gracefully.
+//   fp32 instruction.  Scales: weights S_w per layer (max |w| S_w in [512, 1024)), activations S_x per MLP and layer,
+//   calibrated by the host from the peak plane values a sweep leaves in the decoder's status record (default 8); biases and
+//   the fp32 point-feature products enter the accumulator pre-multiplied by S_w S_x (pack.h, K0), and the accumulator is
+//   rescaled by an exact power of two when it is split into the next layer's planes (the multipliers travel in the
+//   constants block).  fp16 subnormal inputs are honoured by the MFMA (tools/mfma_f16_probe.hip), so small low planes
+//   degrade gracefully.
+//
+// One body, four forms (template parameters of sdf_mlp_f16_body):
+//   PL = 2            the split-half kernel above - the default arithmetic of every grid sweep;
+//   PL = 2, SUB       the same over a list of lattice voxels (the values of the narrow-band fine sweep);
+//   PL = 1, G = 1 | 2 one fp16 plane per operand, one MFMA per product sum, one or two 32-point groups per wave: the sweeps whose
+//                     values are consumed through signs only (asdf_decode_grid_box / _band);
+//   KP = 5 | 8        NeRF-encoded point features (k1h_nerf_kernels.hip).
 //
 // Operand maps (tools/mfma_f16_probe.hip): A lane l holds A[i = l & 31][k = 8 (l >> 5) + e], B lane l holds
 // B[k = 8 (l >> 5) + e][j = l & 31], e = 0..7 packed in 4 VGPRs; D as the fp32 form.  Registers 8 s .. 8 s + 7 of an
