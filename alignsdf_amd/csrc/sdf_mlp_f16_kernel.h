@@ -34,7 +34,29 @@ namespace asdf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 #define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
+// v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
+// v_pack per register on top)
+__device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
+  f32x2 t;
+  t[0] = __int_as_float(max(__float_as_int(a0), 0));
+  t[1] = __int_as_float(max(__float_as_int(a1), 0));
+  t = t * mul;
+#ifndef ASDF16_NO_RANGE_CHECK
+  amax = fmaxf(amax, fmaxf(t[0], t[1]));
+  asm volatile("" : "+v"(amax));
+#endif
+  const h2 r = __builtin_convertvector(t, h2);
+  u32x4 d = __builtin_bit_cast(u32x4, dst);
+  d[w] = __builtin_bit_cast(unsigned, r);
+  dst = __builtin_bit_cast(h8, d);
+}
 
 constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 
@@ -62,6 +84,9 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #endif
 #ifndef ASDF16_PIN_ACC
 #define ASDF16_PIN_ACC 1         // deferred epilogues read the finished accumulator part by part (no up-front copy)
+#endif
+#ifndef ASDF16_L0_PIPE
+#define ASDF16_L0_PIPE 1         // one-plane kernel: layer 0 software-pipelined over all 16 tiles in front of layer 1
 #endif
 #ifndef ASDF16_PRE_KB
 #define ASDF16_PRE_KB (ASDF16_STAGE_KB / 2 + 2)      // K-block of a tile's last stage whose region carries the next tile's preloads
@@ -113,30 +138,13 @@ static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 template <int PL = 2, int G = 1>
 __device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
                                            int e, int g = -1) {
-  if (PL == 1 && G == 2 && g != 0) {       // the second point group: its planes live where the low planes of the split-half kernel do
-    const float t0 = __int_as_float(max(__float_as_int(accb[2 * e]), 0)) * mul;
-    const float t1 = __int_as_float(max(__float_as_int(accb[2 * e + 1]), 0)) * mul;
-#ifndef ASDF16_NO_RANGE_CHECK
-    amax = fmaxf(amax, fmaxf(t0, t1));
-    asm volatile("" : "+v"(amax));
-#endif
-    h8& d = e < 4 ? lo0 : lo1;
-    d[(2 * e) & 7] = (_Float16)t0;
-    d[((2 * e) & 7) + 1] = (_Float16)t1;
-  }
+  if (PL == 1 && G == 2 && g != 0)         // the second point group: its planes live where the low planes of the split-half kernel do
+    relu_mul_pack(accb[2 * e], accb[2 * e + 1], mul, e < 4 ? lo0 : lo1, e & 3, amax);
   if (PL == 1 && G == 2 && g == 1) return;
   if (PL == 1) {
     // one plane: part e converts the NEIGHBOURING accumulator registers 2 e, 2 e + 1 (both land in one packed fp16 register,
     // one v_cvt_pk), about 5 VALU instructions - a part has to fit the shadow of the ONE MFMA of its K-block here
-    const float t0 = __int_as_float(max(__float_as_int(acc[2 * e]), 0)) * mul;
-    const float t1 = __int_as_float(max(__float_as_int(acc[2 * e + 1]), 0)) * mul;
-#ifndef ASDF16_NO_RANGE_CHECK
-    amax = fmaxf(amax, fmaxf(t0, t1));
-    asm volatile("" : "+v"(amax));
-#endif
-    h8& d = e < 4 ? hi0 : hi1;
-    d[(2 * e) & 7] = (_Float16)t0;
-    d[((2 * e) & 7) + 1] = (_Float16)t1;
+    relu_mul_pack(acc[2 * e], acc[2 * e + 1], mul, e < 4 ? hi0 : hi1, e & 3, amax);
     return;
   }
   const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
@@ -451,7 +459,43 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
       // the others ride in the epilogue slots of that stage, under its fp16 MFMAs.
-      constexpr int kL0Front = kS16Kb / 2 < kEpiChunks ? kTilesHidden : kS16Kb / 2;
+      constexpr int kL0Front = (PL == 1 && ASDF16_L0_PIPE) ? kTilesHidden : (kS16Kb / 2 < kEpiChunks ? kTilesHidden : kS16Kb / 2);
+      if (PL == 1 && ASDF16_L0_PIPE) {
+        // One-plane kernel: all 16 tiles up front, software-pipelined over three accumulator sets - the bias / fragment reads
+        // of tile t + 2, then the fp32 MFMAs of tile t + 1, then the fp16 conversions of tile t.  (Tile by tile, and with the
+        // second half squeezed into the 64-cycle K-blocks of layer 1's first stage, layer 0 took 21.6 k of this kernel's
+        // 124 k cycles per 256-point tile where its VALU work is 8 k: every tile waited for its LDS reads, then for its
+        // MFMAs, then converted.)
+        f32x16 la[3], lb[3];
+        float lf[3][KP];
+        auto l0p_load = [&](int t) {
+          la[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+          if (G == 2) lb[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+#pragma unroll
+          for (int s = 0; s < KP; ++s) lf[t % 3][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
+        };
+        auto l0p_mfma = [&](int t) {
+#pragma unroll
+          for (int s = 0; s < KP; ++s) {
+            la[t % 3] = ASDF_MFMA(lf[t % 3][s], bp[s], la[t % 3]);
+            if (G == 2) lb[t % 3] = ASDF_MFMA(lf[t % 3][s], bpb[s < 2 ? s : 0], lb[t % 3]);
+          }
+        };
+        l0p_load(0);
+        l0p_load(1);
+        acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+        if (G == 2) acc1b[0] = acc1[0];
+        __builtin_amdgcn_sched_barrier(0);
+        l0p_mfma(0);
+#pragma unroll
+        for (int t = 0; t < kTilesHidden; ++t) {
+          if (t + 2 < kTilesHidden) l0p_load(t + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < kTilesHidden) l0p_mfma(t + 1);
+          split_tile<PL, G>(la[t % 3], lb[t % 3], mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       l0_load(0);
       acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
       if (G == 2) acc1b[0] = acc1[0];
@@ -461,6 +505,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         l0_compute(t);
         if (!ASDF16_PRELOAD && t + 1 < kTilesHidden) l0_load(t + 1);
         if (ASDF16_PRELOAD) __builtin_amdgcn_sched_barrier(0);
+      }
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
