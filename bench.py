@@ -327,8 +327,8 @@ def main():
         return out
 
     def timed(first, count, warmup):
-        """(elapsed seconds over `count` steps, per-launch ms of the decoder kernel, records) with the barrier + synchronize
-        bracket of the bench contract on both sides."""
+        """(elapsed seconds over `count` steps, per-launch ms of the decoder kernel, records, per-launch ms of the one-plane
+        kernel if any ran) with the barrier + synchronize bracket of the bench contract on both sides."""
         run(0, warmup)
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -342,11 +342,9 @@ def main():
         elapsed = time.perf_counter() - t0
         events, dec.event_log = dec.event_log, None
         box_events, dec.box_event_log = dec.box_event_log, None
-        timed.box_ms = [e[0].elapsed_time(e[1]) for e in box_events]      # launches of the one-plane kernel, if any ran
-        return elapsed, [e[0].elapsed_time(e[1]) for e in events], done
+        return elapsed, [e[0].elapsed_time(e[1]) for e in events], done, [e[0].elapsed_time(e[1]) for e in box_events]
 
-    elapsed, k1_ms, done = timed(args.warmup, args.steps, args.warmup)
-    main_box_ms = list(timed.box_ms)
+    elapsed, k1_ms, done, main_box_ms = timed(args.warmup, args.steps, args.warmup)
     main_coarse = dec.coarse_mode if dec._box_usable() else "exact"
     main_fine = dec.fine_mode if dec._band_usable() else "exact"
     records = [dict(index=rank * args.steps + k, V_hand=d[1], F_hand=d[2], V_obj=d[3], F_obj=d[4], milliseconds=0.0)
@@ -401,20 +399,20 @@ def main():
         # ---- the other arithmetic as a full record: same steps, same bracket
         if not args.no_other_math and len(vols) == 2:
             dec.set_math("f32" if split else "f16x3")
-            e2, k2_ms, _ = timed(1, args.steps, 1)
+            e2, k2_ms, _, _ = timed(1, args.steps, 1)
             other = {"math": dec.math, "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * e2 / args.steps, "value": 2 * args.steps / e2,
                      "unit": "meshes/s", "launch_ms": float(np.mean(k2_ms)), "dtype": "f32" if split else "f32 as 2 x f16 planes"}
             dec.set_math(math0)
         # ---- the other coarse pass as a full record over the SAME samples: zoom cubes and surfaces must come out identical
         if not args.no_other_coarse and split and not dec.nerf_features:
             dec.coarse_mode = "exact" if main_coarse == "box" else "box"
-            e3, k3_ms, done3 = timed(args.warmup, args.steps, max(args.warmup, 2))
+            e3, k3_ms, done3, box3_ms = timed(args.warmup, args.steps, max(args.warmup, 2))
             same_cubes = sum(1 for a, b in zip(done, done3) if a[5] == b[5] and a[6] == b[6])
             same_vf = sum(1 for a, b in zip(done, done3) if a[1:5] == b[1:5])
             other_coarse = {"coarse": dec.coarse_mode if dec._box_usable() or dec.coarse_mode == "exact" else "exact (box switched itself off)",
                             "steps": args.steps, "ms_per_step": 1e3 * e3 / args.steps, "value": 2 * args.steps / e3, "unit": "meshes/s",
                             "launch_ms_pass2_kernel": float(np.mean(k3_ms)) if k3_ms else None,
-                            "launch_ms_one_plane_kernel": float(np.mean(timed.box_ms)) if timed.box_ms else None,
+                            "launch_ms_one_plane_kernel": float(np.mean(box3_ms)) if box3_ms else None,
                             "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
                             "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
                             "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
@@ -422,12 +420,12 @@ def main():
             # ---- both passes on the one-plane kernel (box-only coarse + narrow-band fine sweep), same samples
             if main_fine == "exact" and not dec.combined:
                 dec.coarse_mode, dec.fine_mode = "box", "band"
-                e4, k4_ms, done4 = timed(args.warmup, args.steps, max(args.warmup, 2))
+                e4, k4_ms, done4, box4_ms = timed(args.warmup, args.steps, max(args.warmup, 2))
                 same_cubes = sum(1 for a, b in zip(done, done4) if a[5] == b[5] and a[6] == b[6])
                 same_vf = sum(1 for a, b in zip(done, done4) if a[1:5] == b[1:5])
                 narrow_band = {"coarse": "box", "fine": "band" if dec._band_usable() else "exact (band switched itself off)",
                                "steps": args.steps, "ms_per_step": 1e3 * e4 / args.steps, "value": 2 * args.steps / e4, "unit": "meshes/s",
-                               "launch_ms_one_plane_kernel": float(np.mean(timed.box_ms)) if timed.box_ms else None,
+                               "launch_ms_one_plane_kernel": float(np.mean(box4_ms)) if box4_ms else None,
                                "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
                                "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
                                "band_stats": dict(dec.band_stats), "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}

@@ -1,4 +1,6 @@
-"""Count-phase time of experimental builds of mc33.hip (tools/bin/mcx_<n>.so, -DMC_EXP=<n>) on three volumes."""
+"""Count-phase time (classify + finalize) of stand-alone builds of mc33.hip side by side - how the round-2 variants of
+mc_classify were compared:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared [-D...] mc33.hip glue.cpp
+-o tools/bin/mcx_<name>.so  (glue.cpp defines asdf::g_last_hip_error), then this script on the GPU box."""
 import ctypes, glob, sys, torch
 n = 256
 ax = torch.linspace(-1, 1, n, device="cuda")
