@@ -352,3 +352,27 @@ def test_one_plane_sweeps_on_adversarial_decoders(name):
                     assert torch.equal(vb, ve)        # the ordinary sweep's vertices exactly
     print(name, "box", hip.box_stats, "band", hip.band_stats, "allowance", hip._box_tau, "modes", hip.coarse_mode, hip.fine_mode, hip.math)
     hip.close()
+
+
+@pytest.mark.parametrize("N", [17, 31, 50, 66])
+def test_one_plane_sweeps_on_lattices_that_are_not_multiples_of_four(N):
+    """Row lengths that are not a multiple of 4 (scalar paths of the candidate / mark / compact kernels, ragged last tiles)."""
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    hip, specs = _decoder("nerf3")
+    hip.coarse_mode, hip.fine_mode = "box", "band"
+    lattice = ([-0.62, -0.36, -0.37], 1.21 / (N - 1))
+    for sample in range(3):
+        _bind(hip, specs, sample)
+        b = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))
+        w = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))[2].cpu().numpy()
+        assert _boxes(b) == _boxes(w)
+        bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], mc_only=True)
+        assert not hip.fine_needs_repeat(ticket)
+        eh, eo, _ = hip.decode_grid(N, lattice[0], lattice[1])
+        for bv, ev in ((bh, eh), (bo, eo)):
+            assert int(((bv < 0) != (ev < 0)).sum()) == 0
+            vb, fb = marching_cubes_device(bv, 0.0)
+            ve, fe = marching_cubes_device(ev, 0.0)
+            assert torch.equal(vb, ve) and torch.equal(fb, fe)
+    assert hip.box_stats["box"] == 2 and hip.band_stats["band"] == 3 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+    hip.close()
