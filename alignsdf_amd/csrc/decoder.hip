@@ -295,6 +295,47 @@ __global__ __launch_bounds__(256) void collect_near_level_list_kernel(const floa
   }
 }
 
+// The audit of a one-plane sweep: n voxels drawn uniformly at random (splitmix64 of seed + k, with replacement) from those the
+// sweep DECIDED BY SIGN ALONE - not marked for re-evaluation (band sweep: mark[v] == 0, which implies |value| >= tau), or
+// outside [-tau, tau) for every evaluated head (box sweep) - are appended to a voxel list; the caller re-evaluates them with
+// the split-half kernel, which reports the largest |exact - one-plane| over them and the number whose sign was wrong.
+// One reservation per wave.
+__device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const unsigned char* __restrict__ mark, long long P, float tau,
+                                                         unsigned long long seed, int n, int* list, int* count, int cap) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = k < n;
+  long long v = 0;
+  if (ok) {
+    v = (long long)(splitmix64_dev(seed + (unsigned long long)k * 0xD1342543DE82EF95ull) % (unsigned long long)P);
+    if (mark) ok = mark[v] == 0;
+    else {
+      if (a) { const float t = a[v]; ok = ok && !(t >= -tau && t < tau); }
+      if (b) { const float t = b[v]; ok = ok && !(t >= -tau && t < tau); }
+    }
+  }
+  const unsigned long long m = __ballot(ok);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, 0);
+  const int at = base + __popcll(m & ((1ull << lane) - 1));
+  if (ok && at < cap) list[at] = (int)v;
+}
+
+// more voxels lay within the refinement threshold of the level than the list holds (status[1] != 0): bit 30 of the range word of
+// the bbox record tells the caller, who reads that record anyway
+__global__ void near_overflow_to_bbox_kernel(const int* status, int* bbox) {
+  if (threadIdx.x == 0 && status[1] != 0) atomicOr(bbox + 7, 0x40000000);
+}
+
 __global__ void bbox_reinit_keep_flags_kernel(int* bbox, const int* flag) {   // words 7 / 15 (the fp16 range report) survive
   if (flag && *flag == 0) return;
   const int i = threadIdx.x;
@@ -352,15 +393,26 @@ struct asdf_decoder {
   // 0.24 ms whatever the list holds): the two MLPs of a SeparateDecoder run side by side, the second on this stream
   hipStream_t side;
   hipEvent_t ev_fork, ev_join;
+  // audit of the one-plane sweeps (asdf_decoder_set_audit): voxels per sweep and head, the seed of the next draw, the record
+  // ([0] largest |exact - one-plane| bits, [1] sign contradictions, [2] evaluations, [4] / [5] first audit position of the band
+  // lists), and the voxel list of the box sweep's audit
+  int audit_n;
+  unsigned long long audit_seed;
+  int* audit_rec;   // [8]
+  int* audit_idx;   // [kAuditCap]
+  int* audit_count;
 };
-static constexpr int kNearCap = 1 << 16;
+static constexpr int kNearCap = 1 << 16;      // near-level refinement list of a split-half sweep
+static constexpr int kCandCap = 1 << 19;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
+                                              // or tiny shape - lists its whole surface shell); shares near_idx
+static constexpr int kAuditCap = 1 << 18;
 
 namespace asdf {
 // K1 in its subset mode over one voxel list: both MLPs of a SeparateDecoder concurrently (one launch each, the second on the
 // decoder's side stream, joined back into `st`), everything else as one launch
 static int launch_subset(asdf_decoder* d, const DecodeParams& q, bool two_out, int grid, hipStream_t st);
 }
-static constexpr int kBandCap = 1 << 21;     // voxels per head the narrow-band sweep re-evaluates at most (12 % of 256^3)
+static constexpr int kBandCap = 1 << 22;     // voxels per head the narrow-band sweep re-evaluates at most (25 % of 256^3)
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
 static bool spec_supported(const asdf_decoder_spec_t* s) {
@@ -378,7 +430,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 117; }
+int asdf_version(void) { return 118; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -420,6 +472,9 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   (void)hipFree(d->status);
   (void)hipFree(d->near_idx);
   (void)hipFree(d->near_count);
+  (void)hipFree(d->audit_rec);
+  (void)hipFree(d->audit_idx);
+  (void)hipFree(d->audit_count);
   std::free(d->cst_host);
   std::free(d->cst16_host);
   delete d;
@@ -488,8 +543,13 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) e = k1_cls_prepare();
   if (e == hipSuccess) e = hipMalloc((void**)&d->status, 16 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(d->status, 0, 16 * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kNearCap * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kCandCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_count, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->audit_rec, 8 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->audit_idx, kAuditCap * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->audit_count, sizeof(int));
+  d->audit_n = 1 << 16;
+  d->audit_seed = 0x5DF5A11D00000000ull;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
@@ -630,11 +690,11 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
       // the fp32 MFMA chain (the same kernel as ASDF_MATH_F32, coordinates from the same device function) and written
       // back in place: surfaces and boxes are those of the fp32 chain.
       ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
+      ASDF_HIP(hipMemsetAsync(d->status + 1, 0, 2 * sizeof(int), st));  // this sweep's list-overflow count and "box may shrink" flag
       const long long n4 = (p.P + 3) / 4;
       const int cgrid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
       hipLaunchKernelGGL(collect_near_level_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, p.P, d->refine_tau, d->near_idx,
                          d->near_count, kNearCap, d->status);
-      ASDF_HIP(hipMemsetAsync(d->status + 2, 0, sizeof(int), st));      // the "box may shrink" flag of this sweep
       DecodeParams q = p;
       q.stream = d->stream; q.cst = d->cst; q.bbox = p.bbox; q.fixup_flag = p.bbox ? d->status + 2 : nullptr;
       q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
@@ -650,6 +710,7 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
         const int bgrid = (int)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
         if (p.sdf0) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf0, p.N, p.N, p.N, p.bbox, flag);
         if (p.sdf1) hipLaunchKernelGGL(neg_bbox_kernel, dim3(bgrid), dim3(256), 0, st, p.sdf1, p.N, p.N, p.N, p.bbox + 8, flag);
+        hipLaunchKernelGGL(near_overflow_to_bbox_kernel, dim3(1), dim3(64), 0, st, d->status, p.bbox);
       }
     }
   } else {
@@ -672,6 +733,33 @@ int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float 
   p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
   return launch_decode(d, p, (hipStream_t)stream);
+}
+
+// the audit of a one-plane sweep (see audit_pick_kernel): draws d->audit_n decided voxels into list[*count ..] and advances the seed
+static int enqueue_audit_picks(asdf_decoder* d, const float* a, const float* b, const unsigned char* mark, long long P, float tau,
+                               int* list, int* count, int cap, hipStream_t st) {
+  if (d->audit_n <= 0) return ASDF_OK;
+  const int n = (long long)d->audit_n < P / 2 ? d->audit_n : (int)(P / 2 > 0 ? P / 2 : 1);      // (a lattice smaller than the sample: half of it)
+  hipLaunchKernelGGL(audit_pick_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed, n,
+                     list, count, cap);
+  ASDF_HIP(hipGetLastError());
+  d->audit_seed = d->audit_seed * 6364136223846793005ull + 1442695040888963407ull;
+  return ASDF_OK;
+}
+
+// words 32..39 of the record of a one-plane sweep, gathered on the device behind the call
+__global__ void sweep_record_kernel(int* rec, const int* status, const int* near_count, const int* audit_rec) {
+  const int i = threadIdx.x;
+  if (i < 16) rec[16 + i] = status[i];
+  if (i == 0) {
+    rec[32] = near_count ? *near_count : 0;
+    rec[33] = audit_rec[4];          // band sweep: voxels marked for the hand / object head (0 for the box sweep)
+    rec[34] = audit_rec[5];
+    rec[35] = audit_rec[0]; rec[36] = audit_rec[1]; rec[37] = audit_rec[2];
+    rec[38] = status[1];
+    rec[39] = 0;
+    for (int k = 40; k < 48; ++k) rec[k] = 0;
+  }
 }
 
 int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
@@ -701,22 +789,34 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   k1h_box_launch(two_out, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
-  // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
   ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
-  ASDF_HIP(hipMemsetAsync(d->status + 2, 0, 2 * sizeof(int), st));    // [2] contradiction flag, [3] largest |exact - one-plane|
+  ASDF_HIP(hipMemsetAsync(d->status + 1, 0, 3 * sizeof(int), st));    // [1] candidates beyond the list, [2] contradiction flag, [3] largest |exact - one-plane|
+  ASDF_HIP(hipMemsetAsync(d->audit_rec, 0, 8 * sizeof(int), st));
+  ASDF_HIP(hipMemsetAsync(d->audit_count, 0, sizeof(int), st));
+  // audit: voxels both heads decided by sign alone, drawn at random, through the split-half kernel (the arithmetic of the
+  // ordinary sweep) - they report the error of the one-plane values where nothing else looks
+  if (d->audit_n > 0) {
+    { const int rc = enqueue_audit_picks(d, p.sdf0, p.sdf1, nullptr, p.P, tau, d->audit_idx, d->audit_count, kAuditCap, st); if (rc != ASDF_OK) return rc; }
+    DecodeParams a = p;
+    a.stream = d->stream16; a.cst = d->cst16; a.bbox = nullptr; a.neg_thr = 0.0f;
+    a.mode = kGridSubset; a.grid_mode = p.mode; a.idx = d->audit_idx; a.count_dev = d->audit_count; a.P = kAuditCap;
+    a.audit = d->audit_rec; a.audit_from = nullptr;
+    const int agrid = kAuditCap / kWgPts < d->num_cus ? kAuditCap / kWgPts : d->num_cus;
+    k1h_subset_launch(two_out, a, agrid, st);
+  }
+  // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
   const long long items = (N & 3) == 0 ? p.P / 4 : p.P;
   const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
   hipLaunchKernelGGL(collect_box_candidates_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, N, tau, p.bbox, d->near_idx,
-                     d->near_count, kNearCap, d->status);
+                     d->near_count, kCandCap, d->status);
   DecodeParams q = p;
   q.stream = d->stream; q.cst = d->cst; q.fixup_flag = d->status + 2;
-  q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
-  const int rgrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
+  q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kCandCap;
+  const int rgrid = kCandCap / kWgPts < d->num_cus ? kCandCap / kWgPts : d->num_cus;
   { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
+  // the record of this call travels with the boxes: one read-back for the caller
+  hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, bbox_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
-  // the status record of this call travels with the boxes: one read-back for the caller
-  ASDF_HIP(hipMemcpyAsync(bbox_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));
-  ASDF_HIP(hipMemcpyAsync(bbox_dev + 17, d->near_count, sizeof(int), hipMemcpyDeviceToDevice, st));
   return ASDF_OK;
 }
 
@@ -755,7 +855,8 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
   ASDF_HIP(hipMemsetAsync(d->band_count, 0, 2 * sizeof(int), st));
-  ASDF_HIP(hipMemsetAsync(d->status + 2, 0, 2 * sizeof(int), st));    // [3]: largest |exact - one-plane| of this call
+  ASDF_HIP(hipMemsetAsync(d->status + 1, 0, 3 * sizeof(int), st));    // [1] near-level voxels beyond the list, [3] largest |exact - one-plane| of this call
+  ASDF_HIP(hipMemsetAsync(d->audit_rec, 0, 8 * sizeof(int), st));
   float* vols[2] = {sdf_hand_dev, sdf_obj_dev};
   for (int h = 0; h < 2; ++h) {
     if (!vols[h]) continue;
@@ -765,16 +866,21 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[h], N, tau, d->band_mark);
     const long long items = (P + 15) / 16;
     const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, d->band_idx + (size_t)h * kBandCap,
-                       d->band_count + h, kBandCap);
-    // the values of the ordinary sweep at the marked voxels of this head: the split-half kernel over the list ...
+    int* list = d->band_idx + (size_t)h * kBandCap;
+    hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, list, d->band_count + h, kBandCap);
+    // the audit picks of this head - unmarked voxels, i.e. voxels marching cubes will read the SIGN of and nothing else - ride
+    // behind the marked ones in the same list (positions >= audit_rec[4 + h])
+    ASDF_HIP(hipMemcpyAsync(d->audit_rec + 4 + h, d->band_count + h, sizeof(int), hipMemcpyDeviceToDevice, st));
+    { const int rc = enqueue_audit_picks(d, nullptr, nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
+    // the values of the ordinary sweep at the listed voxels of this head: the split-half kernel over the list ...
     DecodeParams q = p;
     q.stream = d->stream16; q.cst = d->cst16; q.bbox = nullptr; q.neg_thr = 0.0f;
     q.sdf0 = h == 0 ? vols[0] : nullptr; q.sdf1 = h == 1 ? vols[1] : nullptr;
     q.first_mlp = h; q.num_mlps = 1;
-    q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->band_idx + (size_t)h * kBandCap; q.count_dev = d->band_count + h; q.P = kBandCap;
+    q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = list; q.count_dev = d->band_count + h; q.P = kBandCap;
+    q.audit = d->audit_n > 0 ? d->audit_rec : nullptr; q.audit_from = d->audit_rec + 4 + h;
     const int rgrid = kBandCap / kWgPts < d->num_cus ? kBandCap / kWgPts : d->num_cus;
-    k1h_subset_launch(q, rgrid, st);
+    k1h_subset_launch(false, q, rgrid, st);
   }
   if (d->refine_tau > 0.0f) {
     // ... and, as behind every split-half sweep, the fp32 chain where those values lie within refine_tau of the level (both
@@ -790,9 +896,15 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     const int ngrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
     { const int rc = launch_subset(d, q, false, ngrid, st); if (rc != ASDF_OK) return rc; }
   }
+  hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, rec_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
-  ASDF_HIP(hipMemcpyAsync(rec_dev + 16, d->status, 16 * sizeof(int), hipMemcpyDeviceToDevice, st));
-  ASDF_HIP(hipMemcpyAsync(rec_dev + 28, d->band_count, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_audit(asdf_decoder_t* d, int32_t voxels, uint64_t seed) {
+  if (!d || voxels < 0 || voxels > kAuditCap) return ASDF_EINVAL;
+  d->audit_n = voxels;
+  d->audit_seed = seed;
   return ASDF_OK;
 }
 

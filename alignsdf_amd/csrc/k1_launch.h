@@ -18,7 +18,7 @@ void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_
 void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel, kp == 2 only; p.stream = high planes
-void k1h_subset_launch(const DecodeParams& p, int grid, hipStream_t st);   // split-half kernel over a voxel list (SeparateDecoder, kp == 2)
+void k1h_subset_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // split-half kernel over a voxel list (kp == 2)
 void k1h_nerf_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // kp 5 / 8 (k1h_nerf_kernels.hip)
 
 }  // namespace asdf

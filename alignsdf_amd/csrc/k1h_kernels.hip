@@ -13,18 +13,21 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_combined_kernel(const De
 
 // the split-half arithmetic on a voxel list (the exact values of the narrow-band fine sweep)
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_subset_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 2, 1, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16_subset_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true, 0, 2, 2, 1, true>(p); }
 
 hipError_t k1h_prepare() {
   hipError_t e = k1h_nerf_prepare();
-  for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel, (const void*)sdf_mlp_f16_subset_kernel})
+  for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel, (const void*)sdf_mlp_f16_subset_kernel,
+                        (const void*)sdf_mlp_f16_subset_combined_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16);
   for (const void* k : {(const void*)sdf_mlp_f16p1_kernel, (const void*)sdf_mlp_f16p1_combined_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16P1);
   return e;
 }
 
-void k1h_subset_launch(const DecodeParams& p, int grid, hipStream_t st) {
-  hipLaunchKernelGGL(sdf_mlp_f16_subset_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
+void k1h_subset_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_subset_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
+  else hipLaunchKernelGGL(sdf_mlp_f16_subset_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
 }
 
 void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {

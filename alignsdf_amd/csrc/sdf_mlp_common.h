@@ -62,6 +62,12 @@ struct DecodeParams {
   int* fixup_flag;          // kGridSubset with bbox: the outputs REPLACE earlier values - the box is patched in place (a voxel
                             // that turns negative extends it) and *fixup_flag is raised when one turns non-negative
   int* status;              // decoder-owned status record: [0] += lanes whose activations left the fp16 range (K1h only)
+  int* audit;               // split-half kGridSubset only: the audit record of a one-plane sweep (or null).  List positions
+                            // >= *audit_from (all of them when audit_from is null) are AUDIT picks - voxels the one-plane sweep
+                            // decided by sign alone, drawn at random and re-evaluated to check that decision: [0] = largest
+                            // |new - old| over them (float bits), [1] += picks whose sign changed, [2] += picks evaluated;
+                            // the other positions report to status[3] as usual
+  const int* audit_from;
   float neg_thr;            // a voxel counts as negative for the fused box when sdf < neg_thr: 0 for the ordinary sweeps, -tau
                             // for the one-plane sweep of asdf_decode_grid_box (certainly negative); kGridSubset patches
                             // compare the value they replace against it

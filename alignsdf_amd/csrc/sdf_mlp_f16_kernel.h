@@ -360,6 +360,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     }
     // accumulator -> next layer's planes: S_x of the produced activations / (S_w S_x) of the accumulator (powers of two)
     const float mul1 = hc[CL::kB4 + 2], mul2 = hc[CL::kB4 + 3], mul0 = hc[CL::kB4 + 4];
+    // subset mode: list positions from here on are audit picks (see DecodeParams::audit)
+    int audit_from = 0x7fffffff;
+    if (SUB && p.audit) audit_from = p.audit_from ? *p.audit_from : 0;
 
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -716,10 +719,36 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         sdfg = tanhf(partg + hc[CL::kB4]);
       }
       const bool is_hand = head == 0;
-      if (valid && half == 0) {
+      if (SUB) {
+        // subset mode replaces values: the largest change is the measured error of the arithmetic it corrects.  Marked voxels
+        // report to status[3]; audit picks (voxels the one-plane sweep decided by sign alone) to the audit record, together
+        // with the number of picks whose sign the exact value contradicts.  Reduced over the wave on the float BITS (a NaN
+        // is a huge pattern and must survive the reduction), then one set of atomics per wave.
+        int dm = 0, da = 0, flips = 0, na = 0;
+        if (valid && half == 0) {
+          const bool aud = p.audit && pi >= (long long)audit_from;
+          auto replace = [&](float* vol, float now) {
+            const float before = vol[po];
+            const int d = __float_as_int(fabsf(now - before));
+            if (aud) { da = max(da, d); flips += ((before < 0.0f) != (now < 0.0f)) ? 1 : 0; ++na; }
+            else dm = max(dm, d);
+            vol[po] = now;
+          };
+          float* out = is_hand ? p.sdf0 : p.sdf1;
+          if (out) replace(out, sdf);
+          if (TWO_OUT && p.sdf1) replace(p.sdf1, sdfb);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          dm = max(dm, __shfl_xor(dm, m)); da = max(da, __shfl_xor(da, m));
+          flips += __shfl_xor(flips, m); na += __shfl_xor(na, m);
+        }
+        if (lane == 0) {
+          if (p.status && dm) atomicMax(p.status + 3, dm);
+          if (p.audit && na) { atomicMax(p.audit + 0, da); if (flips) atomicAdd(p.audit + 1, flips); atomicAdd(p.audit + 2, na); }
+        }
+      } else if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
-        // (subset mode replaces values: the largest change is the measured error of the arithmetic it corrects)
-        if (SUB && p.status && out) atomicMax(p.status + 3, __float_as_int(fabsf(sdf - out[po])));
         if (out) out[po] = sdf;
         if (TWO_OUT && p.sdf1) p.sdf1[po] = sdfb;
       }

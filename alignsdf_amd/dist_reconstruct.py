@@ -27,6 +27,43 @@ def shard_range(num_items, world_size, rank):
     return start, end
 
 
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo restricted to the CPUs this process may
+    run on; falls back to the logical count)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cpu, pkg = set(), None, 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key = key.strip()
+                if key == "processor":
+                    cpu, pkg = int(val), 0
+                elif key == "physical id":
+                    pkg = int(val)
+                elif key == "core id" and cpu in allowed:
+                    cores.add((pkg, int(val)))
+    except (OSError, ValueError):
+        pass
+    return len(cores) or len(allowed) or 1
+
+
+def limit_host_threads(world_size, reserve=0):
+    """One rank's share of the host: torch's intra-op pool (and OMP / MKL for anything started later) is capped at
+    physical_cores // world_size.  The host tail of a sample (surface sampling, OBJ parsing, PLY export) is numpy / torch CPU work
+    that defaults to one thread per LOGICAL CPU in every process - eight ranks with 256 threads each on a 128-core box fight over
+    the cores and each other's caches.  ASDF_HOST_THREADS overrides.  Returns the thread count set."""
+    n = os.environ.get("ASDF_HOST_THREADS")
+    n = int(n) if n else max(1, physical_cores() // max(1, int(world_size)) - reserve)
+    torch.set_num_threads(n)
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[var] = str(n)
+    return n
+
+
 def gather_records(local_records, group=None):
     """Gather per-sample records (dicts with RECORD_FIELDS) from every rank to rank 0, ordered by sample index.
     One size exchange + one padded gather; returns the merged list on rank 0 and None elsewhere."""
@@ -63,6 +100,7 @@ def run_sharded(num_items, process_range, backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         backend = os.environ.get("ASDF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    limit_host_threads(world)
     if torch.cuda.is_available():
         # explicit rank -> device binding (the reference's thread race on the GPU index, dist_reconstruct.py:21, cannot
         # happen); ASDF_SHARE_DEVICE=1 folds the ranks onto the available devices for single-GPU testing over gloo
@@ -95,11 +133,12 @@ def main(argv=None):
     p.add_argument("--cube_dim", type=int, default=128)
     p.add_argument("--split", dest="split_filename", default=None, help="default: input/<task>.json like the reference")
     p.add_argument("--coarse", choices=["exact", "box"], default=None,
-                   help="coarse pass: an ordinary sweep (default) or the box-only one-plane sweep with exact re-evaluation of "
-                        "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
+                   help="coarse pass: the audited box-only one-plane sweep with exact re-evaluation of the voxels that can move the "
+                        "zoom cube (default; same cubes while its calibrated bound holds, checked on every sweep) or an ordinary sweep")
     p.add_argument("--fine", choices=["exact", "band"], default=None,
-                   help="fine pass: an ordinary sweep (default) or the narrow-band sweep (one fp16 plane, the corners of every cell "
-                        "that can be active re-evaluated as an ordinary sweep would: identical meshes, ~2.4x faster with --coarse box)")
+                   help="fine pass: the audited narrow-band sweep (default: one fp16 plane, the corners of every cell that can be "
+                        "active re-evaluated as an ordinary sweep would - identical meshes while the bound holds, checked on every "
+                        "sweep) or an ordinary sweep")
     args = p.parse_args(argv)
     if args.coarse:
         os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed

@@ -6,6 +6,7 @@ state-dict layout of networks/model.py:191-282) and attributes (`latent_size`, `
 `encode_style`).  PyTorch is used for device memory and streams only; all arithmetic runs in
 libalignsdf_hip.so.
 """
+import collections
 import ctypes
 import os
 
@@ -16,9 +17,17 @@ from . import _native
 
 
 DEFAULT_MATH = "f16x3"
-DEFAULT_COARSE = "exact"      # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
-DEFAULT_FINE = "exact"        # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
-BAND_CAP = 1 << 21
+# The one-plane sweeps are the default wherever a pass has ONE consumer that reads signs, or values next to the surface only:
+# the coarse pass of the two-pass flow (consumed through its negative-voxel boxes) and a fine pass whose caller declares
+# `mc_only` (consumed by marching cubes).  Every volume-returning call runs ordinary sweeps whatever these say.
+DEFAULT_COARSE = "box"        # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
+DEFAULT_FINE = "band"         # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
+BAND_CAP = 1 << 22           # voxels per head the narrow-band sweep can re-evaluate (csrc/decoder.hip: kBandCap)
+NEAR_CAP = 1 << 16           # near-level refinement list of a split-half sweep
+CAND_CAP = 1 << 19           # box candidates of one coarse sweep
+AUDIT_VOXELS = 1 << 16        # per one-plane sweep and head (asdf_decoder_set_audit)
+NEAR_OVERFLOW_BIT = 0x40000000
+REC_WORDS = 48                # record of a one-plane sweep (include/alignsdf_hip.h: asdf_decode_grid_box)
 
 
 def _effective(module_sd, name):
@@ -168,28 +177,49 @@ class HipSdfDecoder:
             raise ValueError("ASDF_MATH must be 'f32' or 'f16x3', not %r" % want)
         self._latent = None
         self._bound = None           # (latent, embed) of the sample the decoder is bound to
-        self._calibrated = False     # activation scales still at their default
-        self._recalibrations = 0
+        self._cal_done = np.zeros((2, 3), dtype=bool)     # activation scale of (MLP, layer) calibrated from a recorded peak
+        self._cal_attempts = 0
+        self._recalibrations = 0     # epoch of the activation scales: tickets and allowances carry the epoch they were made under
         self.refine_tau = 4e-6
-        # coarse pass of the two-pass flow: "exact" = an ordinary sweep, "box" = the one-plane box-only sweep
-        # (asdf_decode_grid_box) with exact re-evaluation of the voxels that can move the box; ASDF_COARSE overrides
+        # coarse pass of the two-pass flow: "box" = the one-plane box-only sweep (asdf_decode_grid_box) with exact re-evaluation of
+        # the voxels that can move the box and a random audit of the others, "exact" = an ordinary sweep; ASDF_COARSE overrides
         self.coarse_mode = os.environ.get("ASDF_COARSE", DEFAULT_COARSE)
         if self.coarse_mode not in ("exact", "box"):
             raise ValueError("ASDF_COARSE must be 'exact' or 'box', not %r" % self.coarse_mode)
-        # fine pass: "exact" = an ordinary sweep, "band" = one-plane sweep + re-evaluation (as the ordinary sweep would) of the
-        # corners of every cell that can be active (asdf_decode_grid_band) - for volumes that go to marching cubes and nowhere else
+        # fine pass: "band" = one-plane sweep + re-evaluation (as the ordinary sweep would) of the corners of every cell that can be
+        # active (asdf_decode_grid_band) + the audit - for volumes that go to marching cubes and nowhere else; "exact" = ordinary
         self.fine_mode = os.environ.get("ASDF_FINE", DEFAULT_FINE)
         if self.fine_mode not in ("exact", "band"):
             raise ValueError("ASDF_FINE must be 'exact' or 'band', not %r" % self.fine_mode)
         self._band_failures = 0
         self._band_skip = False      # the next fine_begin runs an ordinary sweep (a band sweep was just refused)
-        self.band_stats = {"band": 0, "exact": 0, "fallback": 0, "max_err": 0.0, "max_marked": 0}
-        self._box_tau = None         # error allowance of the one-plane values, calibrated per decoder (and per scale set)
+        self._force_f32_once = False # ... and on the fp32 chain (its near-level list overflowed)
+        self.band_stats = self._new_stats("band")
+        self.box_stats = self._new_stats("box")
+        # error allowance tau of the one-plane values: 4 x the estimated largest |one-plane - exact| over a lattice.  Calibrated
+        # per decoder and scale set from a whole-lattice comparison, then RE-ESTIMATED FROM EVERY SWEEP'S AUDIT: tau in use =
+        # 4 x the largest estimate of the last 16 sweeps (8 samples), where a sweep's estimate is its audit's largest error x
+        # the tail ratio (whole-lattice maximum / audit-sample maximum, measured in the calibration sweep)
+        self._box_tau = None
         self._box_epoch = -1
         self._box_failures = 0
-        self.box_stats = {"box": 0, "exact": 0, "fallback": 0, "max_err": 0.0, "max_candidates": 0}
+        self._tail = 1.0
+        self._err_window = collections.deque(maxlen=16)
+        self.audit_voxels = AUDIT_VOXELS
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
-        self.box_event_log = None  # the same for the one-plane kernel of the box-only coarse sweep
+        self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps
+
+    @staticmethod
+    def _new_stats(kind):
+        return {kind: 0, "exact": 0, "fallback": 0, "max_err": 0.0, "audit_max_err": 0.0, "audit_evals": 0, "audit_flips": 0,
+                "max_candidates" if kind == "box" else "max_marked": 0, "tau_min": None, "tau_max": None}
+
+    def set_audit(self, voxels, seed=None):
+        """Audit sample of the one-plane sweeps: `voxels` decided voxels per sweep and head are re-evaluated exactly (0 = off);
+        `seed` restarts the draw (asdf_decoder_set_audit)."""
+        seed = 0x5DF5A11D00000000 if seed is None else int(seed)
+        _native.check(self._L.asdf_decoder_set_audit(self._h, int(voxels), ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)), "asdf_decoder_set_audit")
+        self.audit_voxels = int(voxels)
 
     def set_math(self, math):
         """Select the arithmetic of the hidden GEMMs ("f32" / "f16x3"); raises for NeRF-encoded decoders and f16x3."""
@@ -203,22 +233,36 @@ class HipSdfDecoder:
         _native.check(self._L.asdf_decoder_set_refine(self._h, ctypes.c_float(float(tau))), "asdf_decoder_set_refine")
         self.refine_tau = float(tau)
 
-    def fall_back_if_overflowed(self, bbox_host):
+    @staticmethod
+    def _range_words(rec):
+        """(fp16 range violations, near-level list overflowed) of a bbox / sweep record: words 7 / 15, bit 30 = the flag."""
+        w = (int(rec[7]), int(rec[15]))
+        return sum(v & (NEAR_OVERFLOW_BIT - 1) for v in w), bool((w[0] | w[1]) & NEAR_OVERFLOW_BIT)
+
+    def fall_back_if_overflowed(self, bbox_host, epoch=None):
         """bbox words 7 / 15 count points whose activations left the fp16 range of the split-half planes; they are non-zero
         only for a sweep that ran under f16x3 (the fp32 kernel leaves them 0), so the decision rests on the record alone -
         whatever arithmetic the decoder has been switched to since that sweep was queued.  Returns True when the caller has
         to repeat the sweep the record belongs to: the activation scales were re-calibrated from the peaks that sweep left
         in the status record (first resort), or - when the scales cannot be lowered any further - the decoder was switched
-        to the fp32 MFMA chain for good."""
-        bad = int(bbox_host[7]) + int(bbox_host[15])
+        to the fp32 MFMA chain for good.  `epoch` = the scale epoch (`_recalibrations`) the sweep was LAUNCHED under: a
+        sweep queued before a re-calibration that has happened since is simply repeated under the current scales - its
+        overflow says nothing about them.  Bit 30 (the near-level refinement list overflowed: the signs next to the level are not
+        certified to be the fp32 chain's) makes the NEXT sweep of this decoder run on the fp32 chain, once."""
+        bad, near_over = self._range_words(bbox_host)
+        if near_over:
+            import logging
+            logging.warning("split-half sweep: more than %d voxels within %.1e of the level; repeated on the fp32 chain", NEAR_CAP, self.refine_tau)
+            self._force_f32_once = True
         if not bad:
-            return False
+            return near_over
+        if epoch is not None and epoch != self._recalibrations:
+            return True
         self._recover(bad)
         return True
 
     def _recover(self, bad, status=None):
-        if self.math == "f16x3" and self._recalibrations < 3:
-            self._recalibrations += 1
+        if self.math == "f16x3" and self._recalibrations < 4:
             if self.calibrate(status):
                 return
         self._to_f32(bad)
@@ -251,6 +295,7 @@ class HipSdfDecoder:
         arr = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(sx, np.float32).reshape(-1)])
         with torch.cuda.device(self.device):
             _native.check(self._L.asdf_decoder_set_act_scales(self._h, arr, self._stream()), "asdf_decoder_set_act_scales")
+        self._recalibrations += 1          # a new scale epoch: allowances and tickets made under the old scales are stale
         if self._bound is not None:
             self.set_sample(*self._bound)
 
@@ -258,7 +303,9 @@ class HipSdfDecoder:
         """Choose every S_x from the peak plane values of the sweeps since the last status clear (asdf_decoder_status words
         4..6 / 8..10): the power of two that puts the layer's peak in [1024, 2048) - a factor 32..64 of headroom under the fp16
         maximum for later samples, while every activation down to 2^-13 of the peak keeps two full planes.  A peak that overflowed (inf / NaN
-        pattern) moves that scale down by 2^6 instead.  Returns True when a scale changed (the caller repeats its sweep)."""
+        pattern) moves that scale down by 2^6 instead.  A (MLP, layer) whose peak is zero - the MLP did not run in those sweeps -
+        stays uncalibrated and is picked up by the first later sweep that evaluates it.  Returns True when a scale changed (the
+        caller repeats its sweep); every change starts a new scale epoch (set_act_scales)."""
         st = self._status(clear=True) if status is None else status
         cur = self.act_scales()
         new = cur.copy()
@@ -267,19 +314,34 @@ class HipSdfDecoder:
                 bits = int(st[4 + 4 * h + l])
                 if bits == 0:
                     continue                                  # this MLP did not run (or produced only zeros)
+                self._cal_done[h, l] = True
                 peak = float(np.int32(bits).view(np.float32))
                 if not np.isfinite(peak) or peak >= 65504.0:
-                    new[h, l] = cur[h, l] / 64.0
+                    new[h, l] = max(cur[h, l] / 64.0, 2.0 ** -24)      # (at the floor already: nothing changes, the caller goes to fp32)
                 else:
                     want = cur[h, l] * 2.0 ** np.floor(np.log2(2048.0 / peak))      # peak / cur = the activation itself
                     new[h, l] = float(np.clip(want, 2.0 ** -24, 2.0 ** 24))
-        self._calibrated = True
         if np.array_equal(new, cur):
             return False
         import logging
         logging.info("split-half decoder: activation scales %s -> %s", cur.tolist(), new.tolist())
         self.set_act_scales(new)
         return True
+
+    @property
+    def _calibrated(self):
+        return bool(self._cal_done.all())
+
+    @_calibrated.setter
+    def _calibrated(self, value):
+        """True = treat every activation scale as calibrated (tests of the range guard keep the default S_x = 8 this way)."""
+        self._cal_done[:] = bool(value)
+
+    def _needs_calibration(self, hand, obj):
+        if self.math != "f16x3" or self._cal_attempts >= 4 or self._recalibrations >= 4:
+            return False
+        heads = [0] if self.combined else [h for h, on in ((0, hand), (1, obj)) if on]
+        return any(not self._cal_done[h].all() for h in heads)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -338,13 +400,20 @@ class HipSdfDecoder:
         fp32 kernel and the sweep is repeated.  check_range=False skips that for callers that know the range is safe."""
         if self.combined:
             hand = obj = True
+        want_hand, want_obj = hand, obj
         hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
         obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
         bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
         guard = self.math == "f16x3" and not want_bbox and (check_range is None or check_range)
+        once_f32 = self._force_f32_once and self.math == "f16x3"
+        self._force_f32_once = False
+        if once_f32:
+            self.set_math("f32")          # one sweep on the fp32 chain (the previous one's near-level list overflowed)
+            guard = False
 
         def launch():
+            ev = None
             with torch.cuda.device(self.device):
                 if self.event_log is not None:
                     # the events bracket the decoder kernel itself (asdf_decoder_time_next_sweep), not the bbox / refinement
@@ -359,41 +428,50 @@ class HipSdfDecoder:
                                                        obj.data_ptr() if obj is not None else None,
                                                        bbox.data_ptr() if want_bbox else None, self._stream()),
                               "asdf_decode_grid")
-                if self.event_log is not None:
-                    self.event_log.append(ev)
+            return ev
 
-        # The first split-half sweep of a decoder calibrates the activation scales from the peaks it leaves in the status
-        # record (one stream synchronisation, once per decoder); a bbox-less sweep is additionally guarded.
-        first = self.math == "f16x3" and not self._calibrated and check_range is not False
+        # A split-half sweep that evaluates an MLP whose activation scales are still at their default calibrates them from
+        # the peaks it leaves in the status record (one stream synchronisation, once per decoder and MLP); a bbox-less
+        # sweep is additionally guarded.  Only the events of the launch whose volumes are returned are logged.
+        first = check_range is not False and self._needs_calibration(want_hand, want_obj)
         if guard or first:
             self._status(clear=True)                # earlier sweeps answer for themselves
-        launch()
+        ev = launch()
         if first:
+            self._cal_attempts += 1
             st = self._status(clear=False)
             if self.calibrate(st):
                 self._status(clear=True)
-                launch()                            # the calibrated image; its own report is read below / by the caller
+                ev = launch()                       # the calibrated image; its own report is read below / by the caller
         if guard:
             for _ in range(5):
                 st = self._status(clear=True)
+                if int(st[1]) and self.math == "f16x3":
+                    # more near-level voxels than the refinement list holds: this sweep on the fp32 chain
+                    self.set_math("f32")
+                    ev = launch()
+                    self.set_math("f16x3")
+                    break
                 if not int(st[0]):
                     break
                 self._recover(int(st[0]), st)
-                launch()
+                ev = launch()
+        if once_f32:
+            self.set_math("f16x3")
+        if ev is not None:
+            self.event_log.append(ev)
         return hand, obj, bbox
 
-    # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
-    # per-head boxes of its negative voxels.  begin() enqueues, finish() reads the record back (the one host
-    # synchronisation the zoom cube needs anyway) and repeats the sweep where a guard asks for it.
-    def _box_usable(self):
-        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features
+    # ---- the one-plane sweeps (asdf_decode_grid_box / asdf_decode_grid_band): allowance, record, acceptance -------------------
+    def _tau_current(self):
+        return float(np.clip(4.0 * max(self._err_window), 1e-6, 0.05)) if self._err_window else None
 
-    def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
+    def _one_plane_launch(self, fn, name, N, origin3, voxel_size, grid_mode, hand, obj, tau):
         if self.combined:
             hand = obj = True
         sh = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
         so = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
-        rec = torch.empty(32, dtype=torch.int32, device=self.device)
+        rec = torch.empty(REC_WORDS, dtype=torch.int32, device=self.device)
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
         with torch.cuda.device(self.device):
             ev = None
@@ -403,65 +481,118 @@ class HipSdfDecoder:
                 ev[1].record()
                 _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
                                                                    ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
-            _native.check(self._L.asdf_decode_grid_box(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
-                                                       ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
-                                                       so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()),
-                          "asdf_decode_grid_box")
+            _native.check(fn(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
+                             ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
+                             so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()), name)
             if ev is not None:
                 self.box_event_log.append(ev)
         return rec, sh, so
 
+    def _judge(self, r, tau, stats, cap_word, cap):
+        """Verdict on the record of one one-plane sweep launched with allowance tau: (accepted, range violations, reason).
+        Accepted = no fp16 range violation, every list within its capacity, no contradiction, the largest |exact - one-plane| over
+        the re-evaluated voxels AND the audit's estimate of the lattice maximum within tau / 2, and no audit voxel whose sign the
+        exact value contradicts.  The audit's estimate enters the allowance of the sweeps that follow."""
+        bad, near_over = self._range_words(r)
+        f = lambda w: float(np.int32(r[w]).view(np.float32))
+        err, audit = f(19), f(35)
+        flips, evals = int(r[36]), int(r[37])
+        listed = max(int(r[w]) for w in cap_word)
+        est = audit * self._tail
+        stats["max_err"] = max(stats["max_err"], err)
+        stats["audit_max_err"] = max(stats["audit_max_err"], audit)
+        stats["audit_evals"] += evals
+        stats["audit_flips"] += flips
+        key = "max_candidates" if "max_candidates" in stats else "max_marked"
+        stats[key] = max(stats[key], listed)
+        stats["tau_min"] = tau if stats["tau_min"] is None else min(stats["tau_min"], tau)
+        stats["tau_max"] = tau if stats["tau_max"] is None else max(stats["tau_max"], tau)
+        reason = None
+        if bad:
+            reason = "%d activations left the fp16 range" % bad
+        elif listed > cap:
+            reason = "%d voxels listed, capacity %d" % (listed, cap)
+        elif near_over or int(r[38]):
+            reason = "near-level list overflowed"
+        elif int(r[18]):
+            reason = "a voxel taken as certainly negative was not"
+        elif flips:
+            reason = "%d of %d audit voxels have the other sign" % (flips, evals)
+        elif not (err <= 0.5 * tau):
+            reason = "error %.3g on the re-evaluated voxels against allowance %.3g" % (err, tau)
+        elif not (est <= 0.5 * tau):
+            reason = "audit error %.3g (x tail %.2f) against allowance %.3g" % (audit, self._tail, tau)
+        elif self.audit_voxels and evals == 0:
+            reason = "the audit evaluated nothing"
+        if not bad and np.isfinite(est) and np.isfinite(err):
+            # per-sweep re-estimate of the lattice maximum: the next sweeps' allowance follows the samples
+            self._err_window.append(max(est, err, 2.5e-7))
+            self._box_tau = self._tau_current()
+        return reason is None, bad, near_over, reason
+
+    # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
+    # per-head boxes of its negative voxels.  begin() enqueues, finish() reads the record back (the one host
+    # synchronisation the zoom cube needs anyway) and repeats the sweep where a guard asks for it.
+    def _box_usable(self):
+        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features
+
+    def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
+        return self._one_plane_launch(self._L.asdf_decode_grid_box, "asdf_decode_grid_box", N, origin3, voxel_size, grid_mode, hand, obj, tau)
+
+    def _allowance_valid(self):
+        return self._box_tau is not None and self._box_epoch == self._recalibrations
+
     def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
         """Enqueue the coarse pass of one sample; returns a ticket for coarse_finish."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
-        if self._box_usable() and self._box_tau is not None and self._box_epoch == self._recalibrations:
+        if self._box_usable() and self._allowance_valid() and not self._force_f32_once:
             rec, sh, so = self._box_launch(*args, self._box_tau)
-            return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so)}
+            return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": self._box_tau, "epoch": self._recalibrations}
         h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
-        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o)}
+        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
 
     def coarse_finish(self, ticket):
         """int32[16] host record of the coarse pass (words 0..5 / 8..13: boxes of the negative voxels; 6 / 14: non-zero
         iff there is one).  Synchronises with the sweep; a sweep whose guards fired is repeated here - the decoder must
         still be bound to the ticket's sample."""
+        import logging
         N, origin3, voxel_size, grid_mode, hand, obj = ticket["args"]
+        calibrate_allowance = True
         if ticket["kind"] == "box":
             r = ticket["rec"].cpu().numpy()
-            b = r[:16]
-            bad = int(b[7]) + int(b[15])
-            err = float(np.int32(r[19]).view(np.float32))
-            cand = int(r[17])
-            self.box_stats["max_err"] = max(self.box_stats["max_err"], err)
-            self.box_stats["max_candidates"] = max(self.box_stats["max_candidates"], cand)
-            if not bad and cand <= 65536 and not int(r[18]) and err <= 0.5 * self._box_tau:
+            if ticket["epoch"] != self._recalibrations:
+                ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
+            else:
+                ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP)
+            if ok:
                 self.box_stats["box"] += 1
-                return b
-            import logging
+                return r[:16].copy()
             self.box_stats["fallback"] += 1
             if bad:
                 self._recover(bad)                  # new activation scales: the allowance is re-calibrated with them
             else:
-                logging.warning("box-only coarse sweep not accepted (candidates %d, contradiction %d, error %.3g against "
-                                "allowance %.3g): repeated as an ordinary sweep", cand, int(r[18]), err, self._box_tau)
-                self._box_failures += 1
-                if err > 0.5 * self._box_tau:
-                    self._box_tau = min(4.0 * err, 0.25)
+                logging.warning("box-only coarse sweep not accepted (%s): repeated as an ordinary sweep", reason)
+                if ticket["epoch"] == self._recalibrations:
+                    self._box_failures += 1
+                    calibrate_allowance = False
                 if self._box_failures >= 3:
                     logging.warning("box-only coarse sweep switched off for this decoder")
                     self.coarse_mode = "exact"
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
-            ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "no_calibration": True}
+            ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
         b = ticket["rec"].cpu().numpy()
-        keep = ticket["keep"]
-        while self.fall_back_if_overflowed(b):      # split-half planes out of fp16 range: re-calibrated, or at last fp32
+        keep, epoch = ticket["keep"], ticket["epoch"]
+        while self.fall_back_if_overflowed(b, epoch):      # split-half planes out of fp16 range: re-calibrated, or at last fp32
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
-            b, keep = bbox.cpu().numpy(), (h, o)
+            b, keep, epoch = bbox.cpu().numpy(), (h, o), self._recalibrations
         self.box_stats["exact"] += 1
         # the error allowance of the one-plane kernel (shared by the box-only coarse sweep and the narrow-band fine sweep) is
         # calibrated here, on the coarse lattice, while the decoder is bound to this sample
-        if (self._box_usable() or self._band_usable()) and not ticket.get("no_calibration") and (
-                self._box_tau is None or self._box_epoch != self._recalibrations):
+        if (self._box_usable() or self._band_usable()) and calibrate_allowance and not self._allowance_valid():
             self._calibrate_box(ticket["args"], keep)
+        b = b.copy()
+        b[7] &= NEAR_OVERFLOW_BIT - 1
+        b[15] &= NEAR_OVERFLOW_BIT - 1
         return b
 
     # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else
@@ -474,30 +605,13 @@ class HipSdfDecoder:
         mc_only=True declares that the volumes go to marching cubes at level 0 and nowhere else: only then may a decoder
         set to fine_mode "band" deliver them exact next to the surface and sign-correct elsewhere."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
-        if (mc_only and self._band_usable() and not self._band_skip and self._box_tau is not None
-                and self._box_epoch == self._recalibrations):
-            vh = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
-            vo = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
-            rec = torch.empty(32, dtype=torch.int32, device=self.device)
-            org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
-            with torch.cuda.device(self.device):
-                ev = None
-                if self.box_event_log is not None:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    ev[0].record()
-                    ev[1].record()
-                    _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
-                                                                       ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
-                _native.check(self._L.asdf_decode_grid_band(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
-                                                            ctypes.c_float(float(self._box_tau)), vh.data_ptr() if vh is not None else None,
-                                                            vo.data_ptr() if vo is not None else None, rec.data_ptr(), self._stream()),
-                              "asdf_decode_grid_band")
-                if ev is not None:
-                    self.box_event_log.append(ev)
-            return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau}
+        if mc_only and self._band_usable() and not self._band_skip and self._allowance_valid() and not self._force_f32_once:
+            rec, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band, "asdf_decode_grid_band", N, origin3, voxel_size,
+                                                 grid_mode, hand, obj, self._box_tau)
+            return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau, "epoch": self._recalibrations}
         self._band_skip = False
         vh, vo, bbox2 = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj)
-        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2}
+        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations}
 
     def fine_needs_repeat(self, ticket):
         """True when the fine pass has to be repeated (the decoder must be bound to its sample again first): its range or
@@ -505,53 +619,68 @@ class HipSdfDecoder:
         if ticket is None:
             return False
         if ticket["kind"] == "band":
+            import logging
             r = ticket["rec"].cpu().numpy()
-            bad = int(r[7]) + int(r[15])
-            err = float(np.int32(r[19]).view(np.float32))
-            marked = max(int(r[28]), int(r[29]))
-            self.band_stats["max_err"] = max(self.band_stats["max_err"], err)
-            self.band_stats["max_marked"] = max(self.band_stats["max_marked"], marked)
-            if not bad and marked <= BAND_CAP and err <= 0.5 * ticket["tau"]:
+            if ticket["epoch"] != self._recalibrations:
+                ok, bad, near_over, reason = False, 0, False, "launched under activation scales that have been re-calibrated since"
+            else:
+                ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP)
+            if ok:
                 self.band_stats["band"] += 1
                 return False
-            import logging
             self.band_stats["fallback"] += 1
             if bad:
                 self._recover(bad)
             else:
-                logging.warning("narrow-band fine sweep not accepted (marked %d, error %.3g against allowance %.3g): repeated as an "
-                                "ordinary sweep", marked, err, ticket["tau"])
-                self._band_failures += 1
-                if err > 0.5 * ticket["tau"] and self._box_tau is not None:
-                    self._box_tau = min(max(self._box_tau, 4.0 * err), 0.25)
+                logging.warning("narrow-band fine sweep not accepted (%s): repeated as an ordinary sweep", reason)
+                if near_over or int(r[38]):
+                    self._force_f32_once = True
+                elif ticket["epoch"] == self._recalibrations:
+                    self._band_failures += 1
                 if self._band_failures >= 3:
                     logging.warning("narrow-band fine sweep switched off for this decoder")
                     self.fine_mode = "exact"
             self._band_skip = True
             return True
         rec = ticket["rec"]
-        if rec is not None and self.fall_back_if_overflowed(rec.cpu().numpy()):
+        if rec is not None and self.fall_back_if_overflowed(rec.cpu().numpy(), ticket.get("epoch")):
             return True
         self.band_stats["exact"] += 1
         return False
 
     def _calibrate_box(self, args, exact_vols):
-        """Error allowance of the one-plane sweep for this decoder and scale set: 4 x the largest |one-plane - split-half|
-        over every voxel of one whole coarse sweep (2 x N^3 values).  Later sweeps are accepted only while the error seen
-        on their re-evaluated voxels stays under half of it."""
+        """Error allowance of the one-plane sweep for this decoder and scale set, from one whole coarse sweep run both ways:
+        4 x the largest |one-plane - split-half| over every voxel (2 x N^3 values).  A random sample of the audit's size from the
+        same differences gives the tail ratio (lattice maximum / sample maximum) with which the audits of later sweeps estimate
+        THEIR lattice maximum."""
         import logging
+        audit = self.audit_voxels
+        self.set_audit(0)                                      # (the audit would overwrite its picks with exact values)
         rec, sh, so = self._box_launch(*args, 1e-7)            # (a tiny allowance: next to no candidates, plain one-plane values)
-        err = 0.0
+        self._audit_restarts = getattr(self, "_audit_restarts", 0) + 1
+        self.set_audit(audit, seed=0x5DF5A11D00000000 + 0x9E3779B9 * self._audit_restarts)
+        err, sample = 0.0, 0.0
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(12345)
         for fast, exact in zip((sh, so), exact_vols):
             if fast is not None and exact is not None:
-                err = max(err, float((fast - exact).abs().max().item()))
+                diff = (fast - exact).abs().reshape(-1)
+                err = max(err, float(diff.max().item()))
+                n = min(max(audit, 1), max(diff.numel() // 2, 1))
+                pick = torch.randint(0, diff.numel(), (n,), device=self.device, generator=gen)
+                sample = max(sample, float(diff[pick].max().item()))
         self._box_epoch = self._recalibrations
+        self._err_window.clear()
         if not np.isfinite(err) or 4.0 * err > 0.05:
             logging.warning("one-plane sweeps: error %.3g too large, switched off for this decoder", err)
             self.coarse_mode = self.fine_mode = "exact"
+            self._box_tau = None
             return
-        self._box_tau = max(4.0 * err, 1e-6)
-        logging.info("box-only coarse sweep: one-plane error %.3g, allowance %.3g", err, self._box_tau)
+        self._tail = float(np.clip(err / sample, 1.0, 4.0)) if sample > 0 and np.isfinite(sample) else 2.0
+        self._err_window.append(max(err, 2.5e-7))
+        self._box_tau = self._tau_current()
+        logging.info("one-plane sweeps: lattice error %.3g, sample of %d per head %.3g (tail ratio %.2f), allowance %.3g", err, audit,
+                     sample, self._tail, self._box_tau)
 
     def decode_points(self, xyz):
         """Both heads on explicit normalised points [M,3]. Returns (hand [M], obj [M]) device tensors."""

@@ -56,8 +56,9 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
 
     The pipeline exists to produce meshes: it runs the coarse pass through `coarse_begin` / `coarse_finish` and the fine pass
-    through `fine_begin(..., mc_only=True)`, so a decoder set to the opt-in one-plane sweeps (ASDF_COARSE=box, ASDF_FINE=band)
-    uses them here - the yielded `vol_*` are then exact only where marching cubes reads values.
+    through `fine_begin(..., mc_only=True)`, i.e. on the audited one-plane sweeps wherever the decoder supports them (the default;
+    ASDF_COARSE=exact / ASDF_FINE=exact for ordinary sweeps) - the yielded `vol_*` are then exact only where marching cubes reads
+    values and must not be used as SDF volumes.
 
     Per sample the GPU work is  pass 1 -> [64-byte bbox readback, zoom cube on the host] -> pass 2 -> marching cubes,
     and only the bracketed step and the MC size readbacks synchronise with the host.  Pass 1 of sample k+1 is queued
@@ -344,11 +345,12 @@ def main(argv=None):
     p.add_argument("--allow_missing_gt", action="store_true", help="eval mode: write unaligned meshes when a ground-truth mesh is missing instead of aborting")
     p.add_argument("--cube_dim", type=int, default=128, help="grid resolution (reference CLI hard-codes 128, reconstruct.py:178)")
     p.add_argument("--coarse", choices=["exact", "box"], default=None,
-                   help="coarse pass: an ordinary sweep (default) or the box-only one-plane sweep with exact re-evaluation of "
-                        "the voxels that can move the zoom cube (same cubes and meshes, ~1.4x faster per sample)")
+                   help="coarse pass: the audited box-only one-plane sweep with exact re-evaluation of the voxels that can move the "
+                        "zoom cube (default; same cubes while its calibrated bound holds, checked on every sweep) or an ordinary sweep")
     p.add_argument("--fine", choices=["exact", "band"], default=None,
-                   help="fine pass: an ordinary sweep (default) or the narrow-band sweep (one fp16 plane, the corners of every cell "
-                        "that can be active re-evaluated as an ordinary sweep would: identical meshes, ~2.4x faster with --coarse box)")
+                   help="fine pass: the audited narrow-band sweep (default: one fp16 plane, the corners of every cell that can be "
+                        "active re-evaluated as an ordinary sweep would - identical meshes while the bound holds, checked on every "
+                        "sweep) or an ordinary sweep")
     args = p.parse_args(argv)
     if args.coarse:
         os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed

@@ -216,6 +216,22 @@ def cpu_baseline(tag, N, gpu, golden_dir=os.path.join(ROOT, "tests", "golden")):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def golden_counts(tag, N, hand_only=False, golden_dir=os.path.join(ROOT, "tests", "golden")):
+    """[[V, F] hand, [V, F] obj] of synthetic sample 0 as the REFERENCE (decoder + skimage) produced them, from the committed
+    fixtures (tests/golden/ref_fullsize*.npz), or None when there is no fixture for this configuration."""
+    name = "ref_fullsize_hand64.npz" if hand_only else ("ref_fullsize.npz" if tag == "nerf3" else "ref_fullsize_%s.npz" % tag)
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if "mc_hand_%d" % N not in g.files:
+        return None
+    out = [g["mc_hand_%d" % N].tolist()]
+    if not hand_only:
+        out.append(g["mc_obj_%d" % N].tolist())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,17 +239,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=256, help="grid resolution N (BASELINE metric is quoted at 256)")
     ap.add_argument("--tag", default="nerf3", choices=["nerf3", "both9"], help="nerf3 = ObMan config, both9 = DexYCB MANO-aligned")
+    ap.add_argument("--branches", default="both", choices=["both", "hand"],
+                    help="both = hand + object (2 meshes per sample); hand = HandBranch only (BASELINE configs[0]: 1 mesh per sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-math", action="store_true", help="skip the second full record under the other arithmetic")
+    ap.add_argument("--no-other-math", action="store_true", help="skip the full record on the fp32 MFMA chain (and its share of parity_in_run)")
     ap.add_argument("--math", default=None, choices=["f32", "f16x3"],
                     help="arithmetic of the hidden GEMMs (default: the product's default, split-half fp16 MFMA)")
     ap.add_argument("--coarse", default=None, choices=["exact", "box"],
-                    help="coarse pass of the two-pass flow in the timed region: an ordinary sweep, or the box-only one-plane "
-                         "sweep with exact re-evaluation of the box candidates (default: the product's default)")
+                    help="coarse pass of the two-pass flow in the timed region (default: the product's default, the audited box-only "
+                         "one-plane sweep); exact = an ordinary sweep")
     ap.add_argument("--fine", default=None, choices=["exact", "band"],
-                    help="fine pass in the timed region: an ordinary sweep, or the narrow-band sweep (one-plane values, exact "
-                         "re-evaluation of the corners of every cell that can be active; for marching cubes only)")
-    ap.add_argument("--no-other-coarse", action="store_true", help="skip the full records under the other coarse / fine passes")
+                    help="fine pass in the timed region (default: the product's default, the audited narrow-band sweep - one-plane "
+                         "values, every value marching cubes reads re-evaluated as the ordinary sweep computes it); exact = ordinary")
+    ap.add_argument("--no-other-sweeps", "--no-other-coarse", dest="no_other_sweeps", action="store_true",
+                    help="skip the full record with ordinary sweeps in both passes (and its share of parity_in_run)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short records of the other single-GPU configurations")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -273,6 +293,8 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    from alignsdf_amd.dist_reconstruct import limit_host_threads
+    host_threads = limit_host_threads(world)      # each rank's host tail on its share of the cores (no 8 x 256 thread pools)
     n_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -291,64 +313,91 @@ def main():
     from alignsdf_amd.utils.utils import sample_embedding
 
     N = args.grid
-    specs = syn.specs_for(args.tag)
-    dec = HipSdfDecoder(syn.full_state_dict(args.tag), 256, specs["PointFeatSize"], specs["EncodeStyle"], device=dev)
+    hand_only = args.branches == "hand"
+    parts = ("hand",) if hand_only else ("hand", "obj")
+    meshes_per_sample = len(parts)
+
+    class Config:
+        """One decoder + its 64 resident synthetic samples + the product's sample pipeline over them."""
+
+        def __init__(self, tag, hand_only=False):
+            self.tag = tag
+            self.specs = dict(syn.specs_for(tag), ObjectBranch=not hand_only)
+            self.parts = ("hand",) if hand_only else ("hand", "obj")
+            self.dec = HipSdfDecoder(syn.full_state_dict(tag), 256, self.specs["PointFeatSize"], self.specs["EncodeStyle"], device=dev)
+            self.codes = []
+            for s in range(64):
+                lat = torch.from_numpy(syn.latent_code(s)).to(dev)
+                mano = obj = None
+                if tag == "both9":
+                    m, o = syn.pose_inputs(s)
+                    mano = {k: torch.from_numpy(v).to(dev) for k, v in m.items()}
+                    obj = {k: torch.from_numpy(v).to(dev) for k, v in o.items()}
+                self.codes.append((lat, mano, obj))
+
+        @staticmethod
+        def sample_id(i):
+            return (rank * 7919 + i) % 64
+
+        def stream(self, first, count):
+            for i in range(first, first + count):
+                lat, mano, obj = self.codes[self.sample_id(i)]
+                yield i, lat, mano, obj
+
+        def run(self, first, count, n, keep_meshes=False):
+            """`count` whole samples through alignsdf_amd.reconstruct.pipelined_two_pass (pass 1 of sample k+1 is queued before the
+            host-synchronous marching cubes of sample k).  One record per sample; the meshes stay on the device."""
+            out = []
+            for i, r in pipelined_two_pass(self.dec, self.specs, self.stream(first, count), n):
+                rec = {"i": i, "sample": self.sample_id(i), "origin": tuple(r["origin"]), "voxel_size": float(r["voxel_size"])}
+                for part in self.parts:
+                    rec["V_" + part], rec["F_" + part] = r["V_" + part], r["F_" + part]
+                    if keep_meshes:
+                        rec["verts_" + part], rec["faces_" + part] = r.get("verts_" + part), r.get("faces_" + part)
+                out.append(rec)
+            return out
+
+        def timed(self, first, count, warmup, n, keep_meshes=False):
+            """(elapsed seconds over `count` steps, per-launch ms of the ordinary decoder kernel, records, per-launch ms of the
+            one-plane kernel) with the barrier + synchronize bracket of the bench contract on both sides."""
+            dec = self.dec
+            self.run(0, warmup, n)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            dec.event_log, dec.box_event_log = [], []
+            t0 = time.perf_counter()
+            done = self.run(first, count, n, keep_meshes)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            events, dec.event_log = dec.event_log, None
+            box_events, dec.box_event_log = dec.box_event_log, None
+            return elapsed, [e[0].elapsed_time(e[1]) for e in events], done, [e[0].elapsed_time(e[1]) for e in box_events]
+
+        def sweep_summary(self):
+            d = self.dec
+            return {"coarse": d.coarse_mode if d._box_usable() else "exact", "fine": d.fine_mode if d._band_usable() else "exact",
+                    "coarse_sweeps": dict(d.box_stats), "fine_sweeps": dict(d.band_stats),
+                    "refused_sweeps": d.box_stats["fallback"] + d.band_stats["fallback"],
+                    "audit_voxels_per_sweep_and_head": d.audit_voxels, "allowance_now": d._box_tau, "tail_ratio": d._tail}
+
+    cfg = Config(args.tag, hand_only)
+    dec, specs = cfg.dec, cfg.specs
     if args.math is not None:
         dec.set_math(args.math)
     if args.coarse is not None:
         dec.coarse_mode = args.coarse
     if args.fine is not None:
         dec.fine_mode = args.fine
-    # 64 distinct synthetic samples, resident on the device before timing
-    codes = []
-    for s in range(64):
-        lat = torch.from_numpy(syn.latent_code(s)).to(dev)
-        mano = obj = None
-        if args.tag == "both9":
-            m, o = syn.pose_inputs(s)
-            mano = {k: torch.from_numpy(v).to(dev) for k, v in m.items()}
-            obj = {k: torch.from_numpy(v).to(dev) for k, v in o.items()}
-        codes.append((lat, mano, obj))
 
-    def sample_id(i):
-        return (rank * 7919 + i) % 64
-
-    def sample_stream(first, count):
-        for i in range(first, first + count):
-            lat, mano, obj = codes[sample_id(i)]
-            yield i, lat, mano, obj
-
-    # the product's sample pipeline (alignsdf_amd.reconstruct.pipelined_two_pass): pass 1 of sample k+1 is queued
-    # before the host-synchronous marching cubes of sample k; each call below runs `count` whole samples to completion
-    def run(first, count):
-        out = []
-        for i, r in pipelined_two_pass(dec, specs, sample_stream(first, count), N):
-            out.append((i, r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"], tuple(r["origin"]), float(r["voxel_size"])))
-        return out
-
-    def timed(first, count, warmup):
-        """(elapsed seconds over `count` steps, per-launch ms of the decoder kernel, records, per-launch ms of the one-plane
-        kernel if any ran) with the barrier + synchronize bracket of the bench contract on both sides."""
-        run(0, warmup)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        dec.event_log, dec.box_event_log = [], []
-        t0 = time.perf_counter()
-        done = run(first, count)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        events, dec.event_log = dec.event_log, None
-        box_events, dec.box_event_log = dec.box_event_log, None
-        return elapsed, [e[0].elapsed_time(e[1]) for e in events], done, [e[0].elapsed_time(e[1]) for e in box_events]
-
-    elapsed, k1_ms, done, main_box_ms = timed(args.warmup, args.steps, args.warmup)
-    main_coarse = dec.coarse_mode if dec._box_usable() else "exact"
-    main_fine = dec.fine_mode if dec._band_usable() else "exact"
-    records = [dict(index=rank * args.steps + k, V_hand=d[1], F_hand=d[2], V_obj=d[3], F_obj=d[4], milliseconds=0.0)
-               for k, d in enumerate(done)]
+    # ---- the timed region: K whole samples under the product's defaults
+    elapsed, k1_ms, done, p1_ms = cfg.timed(args.warmup, args.steps, args.warmup, N, keep_meshes=(world == 1))
+    main_sweeps = cfg.sweep_summary()
+    main_coarse, main_fine, main_math = main_sweeps["coarse"], main_sweeps["fine"], dec.math
+    records = [dict(index=rank * args.steps + k, V_hand=d["V_hand"], F_hand=d["F_hand"], V_obj=d.get("V_obj", 0), F_obj=d.get("F_obj", 0),
+                    milliseconds=0.0) for k, d in enumerate(done)]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -358,95 +407,119 @@ def main():
     else:
         merged = records
 
-    # dominant kernel: the fused decoder (2 launches per step), timed with HIP events on the launch stream
-    k1_avg_s = float(np.mean(k1_ms)) * 1e-3
-    alg_flop = N ** 3 * 2 * FLOP_PER_POINT_HEAD
+    # ---- dominant kernel of the timed region: timed with HIP events recorded by the library around that kernel on the launch
+    # stream.  Under the default sweeps it is the one-plane kernel (2 launches per sample); with --coarse exact --fine exact the
+    # split-half kernel (or the fp32 one with --math f32).
+    one_plane_main = bool(p1_ms) and len(p1_ms) >= len(k1_ms)
+    alg_flop = N ** 3 * meshes_per_sample * FLOP_PER_POINT_HEAD
     split = dec.math == "f16x3"
-    kernel_name = "sdf_mlp_f16_kernel" if split else "sdf_mlp_kernel"
-    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-    exec_flop = N ** 3 * 2 * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
+    if one_plane_main:
+        kernel_name, peak, launch_ms_all = "sdf_mlp_f16p1_kernel", PEAK_F16_MFMA_TFLOPS, p1_ms
+        exec_flop = N ** 3 * meshes_per_sample * EXEC_F16_FLOP_PER_POINT_HEAD // 3
+    else:
+        kernel_name = "sdf_mlp_f16_kernel" if split else "sdf_mlp_kernel"
+        peak, launch_ms_all = (PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS), k1_ms
+        exec_flop = N ** 3 * meshes_per_sample * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
+    k_avg_s = float(np.mean(launch_ms_all)) * 1e-3
 
-    other = parity = mc_line = other_coarse = narrow_band = None
+    def compare_meshes(ref_done, exact_bits):
+        """Per timed sample: the meshes of `ref_done` (same samples, another arithmetic / other sweeps) against the timed run's."""
+        out = {"samples": len(done), "zoom_cubes_equal": 0, "V_F_equal": 0, "faces_identical": 0, "vertices_identical": 0,
+               "max_vertex_difference_voxels": 0.0}
+        for a, b in zip(done, ref_done):
+            out["zoom_cubes_equal"] += int(a["origin"] == b["origin"] and a["voxel_size"] == b["voxel_size"])
+            vf = all(a["V_" + p] == b["V_" + p] and a["F_" + p] == b["F_" + p] for p in cfg.parts)
+            out["V_F_equal"] += int(vf)
+            if not vf:
+                continue
+            fe = ve = True
+            for p in cfg.parts:
+                if a.get("verts_" + p) is None or b.get("verts_" + p) is None:
+                    continue
+                fe = fe and bool(torch.equal(a["faces_" + p], b["faces_" + p]))
+                ve = ve and bool(torch.equal(a["verts_" + p], b["verts_" + p]))
+                out["max_vertex_difference_voxels"] = max(out["max_vertex_difference_voxels"],
+                                                          float((a["verts_" + p] - b["verts_" + p]).abs().max()))
+            out["faces_identical"] += int(fe)
+            out["vertices_identical"] += int(ve)
+        if not exact_bits:
+            out.pop("vertices_identical")
+        return out
+
+    other_math = other_sweeps = parity = mc_line = other_configs = None
     if world == 1:
-        last_sample = sample_id(args.warmup + args.steps - 1)
-        lat, mano, obj = codes[last_sample]
-        # ---- parity in the run: the last timed sample under both arithmetics, every voxel of both pass-2 volumes
-        math0 = dec.math
-        vols, counts = {}, {}
-        for m in ("f16x3", "f32"):
-            dec.set_math(m)
-            r = decode_two_pass(True, True, dec, lat, mano, obj, specs, N)
-            vols[m] = r
-            counts[m] = []
-            for part in ("hand", "obj"):
-                try:
-                    v, f = marching_cubes_device(r["vol_" + part], 0.0)
-                    counts[m].append([int(v.shape[0]), int(f.shape[0])])
-                except (ValueError, RuntimeError):
-                    counts[m].append([0, 0])
-        dec.set_math(math0)
-        if len(vols) == 2:
+        # ---- the SAME samples with ordinary sweeps in both passes (the split-half kernel on every voxel): a full record, and the
+        # meshes of the timed run must be those meshes bit for bit
+        parity = {"samples": [d["sample"] for d in done], "bar": "SDF 1e-5 (north_star); identical triangle counts"}
+        if not args.no_other_sweeps and split and (main_coarse, main_fine) != ("exact", "exact"):
+            dec.coarse_mode, dec.fine_mode = "exact", "exact"
+            e2, k2_ms, done2, _ = cfg.timed(args.warmup, args.steps, 1, N, keep_meshes=True)
+            other_sweeps = {"coarse": "exact", "fine": "exact", "math": dec.math, "steps": args.steps, "warmup": 1,
+                            "ms_per_step": 1e3 * e2 / args.steps, "value": meshes_per_sample * args.steps / e2, "unit": "meshes/s",
+                            "kernel": "sdf_mlp_f16_kernel", "launch_ms": float(np.mean(k2_ms)) if k2_ms else None,
+                            "dtype": "f32 as 2 x f16 planes (3 x v_mfma_f32_32x32x16_f16 per product sum, fp32 accumulate) on every voxel"}
+            parity["against_ordinary_sweeps_f16x3"] = compare_meshes(done2, exact_bits=True)
+            del done2
+            dec.coarse_mode, dec.fine_mode = main_coarse, main_fine
+        # ---- the SAME samples on the fp32 MFMA chain with ordinary sweeps: the strict-reading record, and the timed run's
+        # surfaces must have its faces (the vertices differ by the two arithmetics' 1e-7-class difference in the SDF values)
+        if not args.no_other_math and split:
+            dec.coarse_mode, dec.fine_mode = "exact", "exact"
+            dec.set_math("f32")
+            e3, k3_ms, done3, _ = cfg.timed(args.warmup, args.steps, 1, N, keep_meshes=True)
+            other_math = {"math": "f32", "coarse": "exact", "fine": "exact", "steps": args.steps, "warmup": 1,
+                          "ms_per_step": 1e3 * e3 / args.steps, "value": meshes_per_sample * args.steps / e3, "unit": "meshes/s",
+                          "kernel": "sdf_mlp_kernel", "launch_ms": float(np.mean(k3_ms)) if k3_ms else None, "dtype": "f32"}
+            parity["against_fp32_chain"] = compare_meshes(done3, exact_bits=False)
+            del done3
+            dec.set_math(main_math)
+            dec.coarse_mode, dec.fine_mode = main_coarse, main_fine
+        # every voxel of one sample under both arithmetics (ordinary sweeps; volume-returning calls always are)
+        if split:
+            lat, mano, obj = cfg.codes[done[-1]["sample"]]
+            vols = {}
+            for m in ("f16x3", "f32"):
+                dec.set_math(m)
+                vols[m] = decode_two_pass(True, not hand_only, dec, lat, mano, obj, specs, N)
+            dec.set_math(main_math)
             a, b = vols["f16x3"], vols["f32"]
             same_cube = bool(float(a["voxel_size"]) == float(b["voxel_size"]) and a["origin"] == b["origin"])
-            parity = {
-                "sample": last_sample, "zoom_cube_equal": same_cube,
-                "max_abs_f16x3_minus_f32": max(float((a["vol_hand"] - b["vol_hand"]).abs().max()),
-                                               float((a["vol_obj"] - b["vol_obj"]).abs().max())) if same_cube else None,
-                "sign_differences": int(((a["vol_hand"] < 0) != (b["vol_hand"] < 0)).sum() + ((a["vol_obj"] < 0) != (b["vol_obj"] < 0)).sum()) if same_cube else None,
-                "V_F_f16x3": counts["f16x3"], "V_F_f32": counts["f32"], "V_F_equal": counts["f16x3"] == counts["f32"],
-                "voxels_compared": 2 * N ** 3, "bar": 1e-5,
-            }
-        # ---- the other arithmetic as a full record: same steps, same bracket
-        if not args.no_other_math and len(vols) == 2:
-            dec.set_math("f32" if split else "f16x3")
-            e2, k2_ms, _, _ = timed(1, args.steps, 1)
-            other = {"math": dec.math, "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * e2 / args.steps, "value": 2 * args.steps / e2,
-                     "unit": "meshes/s", "launch_ms": float(np.mean(k2_ms)), "dtype": "f32" if split else "f32 as 2 x f16 planes"}
-            dec.set_math(math0)
-        # ---- the other coarse pass as a full record over the SAME samples: zoom cubes and surfaces must come out identical
-        if not args.no_other_coarse and split and not dec.nerf_features:
-            dec.coarse_mode = "exact" if main_coarse == "box" else "box"
-            e3, k3_ms, done3, box3_ms = timed(args.warmup, args.steps, max(args.warmup, 2))
-            same_cubes = sum(1 for a, b in zip(done, done3) if a[5] == b[5] and a[6] == b[6])
-            same_vf = sum(1 for a, b in zip(done, done3) if a[1:5] == b[1:5])
-            other_coarse = {"coarse": dec.coarse_mode if dec._box_usable() or dec.coarse_mode == "exact" else "exact (box switched itself off)",
-                            "steps": args.steps, "ms_per_step": 1e3 * e3 / args.steps, "value": 2 * args.steps / e3, "unit": "meshes/s",
-                            "launch_ms_pass2_kernel": float(np.mean(k3_ms)) if k3_ms else None,
-                            "launch_ms_one_plane_kernel": float(np.mean(box3_ms)) if box3_ms else None,
-                            "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
-                            "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
-                            "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
-            dec.coarse_mode = main_coarse
-            # ---- both passes on the one-plane kernel (box-only coarse + narrow-band fine sweep), same samples
-            if main_fine == "exact" and not dec.combined:
-                dec.coarse_mode, dec.fine_mode = "box", "band"
-                e4, k4_ms, done4, box4_ms = timed(args.warmup, args.steps, max(args.warmup, 2))
-                same_cubes = sum(1 for a, b in zip(done, done4) if a[5] == b[5] and a[6] == b[6])
-                same_vf = sum(1 for a, b in zip(done, done4) if a[1:5] == b[1:5])
-                narrow_band = {"coarse": "box", "fine": "band" if dec._band_usable() else "exact (band switched itself off)",
-                               "steps": args.steps, "ms_per_step": 1e3 * e4 / args.steps, "value": 2 * args.steps / e4, "unit": "meshes/s",
-                               "launch_ms_one_plane_kernel": float(np.mean(box4_ms)) if box4_ms else None,
-                               "zoom_cubes_equal_to_main_run": "%d of %d" % (same_cubes, len(done)),
-                               "V_F_equal_to_main_run": "%d of %d" % (same_vf, len(done)),
-                               "band_stats": dict(dec.band_stats), "box_stats": dict(dec.box_stats), "allowance": dec._box_tau}
-                # the meshes of the band volumes against those of the ordinary sweeps (whose values the band re-evaluates to),
-                # vertex for vertex, on the parity sample
-                if "f16x3" in vols and dec._band_usable():
-                    rb = decode_two_pass(True, True, dec, lat, mano, obj, specs, N, mc_only=True)
-                    eq = []
-                    for part in ("hand", "obj"):
-                        vb, fb = marching_cubes_device(rb["vol_" + part], 0.0)
-                        ve, fe = marching_cubes_device(vols["f16x3"]["vol_" + part], 0.0)
-                        eq.append(bool(torch.equal(vb, ve) and torch.equal(fb, fe)))
-                    narrow_band["meshes_bit_identical_to_ordinary_sweeps"] = eq
-                    narrow_band["sign_differences_to_ordinary_sweeps"] = int(((rb["vol_hand"] < 0) != (vols["f16x3"]["vol_hand"] < 0)).sum() +
-                                                                             ((rb["vol_obj"] < 0) != (vols["f16x3"]["vol_obj"] < 0)).sum())
-                dec.coarse_mode, dec.fine_mode = main_coarse, main_fine
-        # ---- marching cubes chain (K3-K6) on the last sample's volumes: HBM roofline of the second kernel family
+            if same_cube:
+                parity["volumes_f16x3_vs_f32"] = {
+                    "sample": done[-1]["sample"], "voxels_compared": meshes_per_sample * N ** 3,
+                    "max_abs_difference": max(float((a["vol_" + p] - b["vol_" + p]).abs().max()) for p in cfg.parts),
+                    "sign_differences": int(sum(((a["vol_" + p] < 0) != (b["vol_" + p] < 0)).sum() for p in cfg.parts))}
+            parity["zoom_cube_equal_f16x3_vs_f32"] = same_cube
+            r_mc = vols[main_math]
+        else:
+            lat, mano, obj = cfg.codes[done[-1]["sample"]]
+            r_mc = decode_two_pass(True, not hand_only, dec, lat, mano, obj, specs, N)
+        # ---- marching cubes chain (K3-K6) on that sample's volumes: HBM roofline of the second kernel family
         from alignsdf_amd import marching_cubes as mcmod
-        r = vols.get(math0) or decode_two_pass(True, True, dec, lat, mano, obj, specs, N)
-        if hasattr(mcmod, "time_chain"):
-            mc_line = mcmod.time_chain(r["vol_hand"], r["vol_obj"], PEAK_HBM_GBS)
+        if not hand_only:
+            mc_line = mcmod.time_chain(r_mc["vol_hand"], r_mc["vol_obj"], PEAK_HBM_GBS)
+        del r_mc
+        # ---- the other single-GPU configurations of BASELINE.json, a few steps each, V / F of sample 0 against the reference's
+        if not args.no_other_configs:
+            other_configs = []
+            for name, tag, n, ho in (("configs[0]: hand-only, N=64", "nerf3", 64, True), ("configs[1]: hand+object, N=128", "nerf3", 128, False),
+                                     ("configs[2]: hand+object, N=256", "nerf3", 256, False),
+                                     ("configs[4] decoder (DexYCB MANO-aligned, PointFeatSize 9), N=256, one GPU", "both9", 256, False)):
+                if (tag, n, ho) == (args.tag, N, hand_only):
+                    continue
+                c = Config(tag, ho)
+                steps = 4 if n >= 256 else 8
+                e, km, dn, pm = c.timed(2, steps, 2, n)
+                first = c.run(0, 1, n)[0] if c.sample_id(0) == 0 else None
+                got = [[first["V_" + p], first["F_" + p]] for p in c.parts] if first else None
+                want = golden_counts(tag, n, ho)
+                other_configs.append({"config": name, "tag": tag, "grid": n, "branches": "hand" if ho else "both", "steps": steps,
+                                      "ms_per_step": 1e3 * e / steps, "value": len(c.parts) * steps / e, "unit": "meshes/s",
+                                      "launch_ms_one_plane_kernel": float(np.mean(pm)) if pm else None,
+                                      "launch_ms_ordinary_kernel": float(np.mean(km)) if km else None,
+                                      "sweeps": c.sweep_summary(), "V_F_sample0": got, "V_F_sample0_reference_golden": want,
+                                      "V_F_equal_reference": (got == want) if want is not None and got is not None else None})
+                c.dec.close()
 
     # HBM traffic of the dominant kernel comes from PMC passes (rocprofv3 cannot run inside the timed region); the
     # committed summary of the last collection is reported only while it still describes this kernel: same grid, same
@@ -455,23 +528,41 @@ def main():
     try:
         import hashlib
         digest = hashlib.sha256()
-        for name in ("sdf_mlp_f16_kernel.h" if split else "sdf_mlp_kernel.h", "sdf_mlp_common.h", "sdf_layout.h"):
+        for name in ("sdf_mlp_kernel.h" if kernel_name == "sdf_mlp_kernel" else "sdf_mlp_f16_kernel.h", "sdf_mlp_common.h", "sdf_layout.h"):
             with open(os.path.join(ROOT, "alignsdf_amd", "csrc", name), "rb") as f:
                 digest.update(f.read())
         for cand in sorted([p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith(".json") and "hbm_traffic" in p], reverse=True):
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 t = json.load(f)
-            if t.get("grid") == N and t.get("kernel") == kernel_name and t.get("source_sha256", digest.hexdigest()) == digest.hexdigest():
-                if "source_sha256" in t:
-                    traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/" + cand
-                    break
+            if t.get("grid") == N and t.get("kernel") == kernel_name and t.get("source_sha256") == digest.hexdigest():
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/" + cand
+                break
     except (OSError, ValueError, KeyError):
         pass
 
     if rank == 0:
-        total_meshes = 2 * args.steps * world
+        total_meshes = meshes_per_sample * args.steps * world
+        if one_plane_main:
+            dtype = ("f32-class results from f16 planes: lattice sweeps on ONE fp16 plane per operand (1 x v_mfma_f32_32x32x16_f16 per "
+                     "product sum, fp32 accumulate) for signs only; every value the zoom cube or marching cubes reads re-evaluated on "
+                     "TWO planes (3 MFMAs, f32-class) and on the fp32 MFMA chain within 4e-6 of the level; audited per sweep")
+        else:
+            dtype = "f32 as 2 x f16 planes (3 x v_mfma_f32_32x32x16_f16 per product sum, fp32 accumulate)" if split else "f32"
+        note_common = ("achieved counts the reference's dense fp32 FLOPs (1,573,888 per point per head) of the N^3 points one launch "
+                       "decides, against the peak of the MFMA instruction that is issued; ")
+        if one_plane_main:
+            note = note_common + ("the one-plane kernel issues ONE v_mfma_f32_32x32x16_f16 per product sum (%d MFMA FLOPs per point per "
+                                  "head, plus %d on the fp32 MFMA for the point features): frac_executed is the matrix-pipe utilisation "
+                                  "against the 2.5 PFLOP/s spec" % (EXEC_F16_FLOP_PER_POINT_HEAD // 3, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD))
+        elif split:
+            note = note_common + ("each fp32 product sum is carried as two fp16 planes per operand and costs three v_mfma_f32_32x32x16_f16 "
+                                  "(%d MFMA FLOPs per point per head, plus %d on the fp32 MFMA); the part is power-limited under this kernel "
+                                  "(profiles/r02_k1h_power_limit.txt)" % (EXEC_F16_FLOP_PER_POINT_HEAD, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD))
+        else:
+            note = note_common + ("the kernel folds the per-sample-constant latent columns into a bias and issues %d, so frac can exceed 1; "
+                                  "frac_executed is the MFMA pipe utilisation" % EXEC_FLOP_PER_POINT_HEAD)
         result = {
-            "metric": "meshes_per_sec_hand_plus_obj_N%d" % N,
+            "metric": "meshes_per_sec_hand_plus_obj_N%d" % N if not hand_only else "meshes_per_sec_hand_only_N%d" % N,
             "value": total_meshes / elapsed,
             "unit": "meshes/s",
             "n_gpus": n_seen,
@@ -481,62 +572,54 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 as 2 x f16 planes (3 x v_mfma_f32_32x32x16_f16 per product sum, fp32 accumulate)" if split else "f32",
+            "dtype": dtype,
             "data": "synthetic",
             "config": {
-                "workload": "single sample, hand+object dual SDF decoder, N=%d grid, 2 passes (coarse + zoom cube) + HIP "
-                            "marching cubes; %s decoder (PointFeatSize %d, EncodeStyle %s)" % (
-                                N, "ObMan" if args.tag == "nerf3" else "DexYCB MANO-aligned", specs["PointFeatSize"],
-                                specs["EncodeStyle"]),
-                "grid": N, "samples_per_gpu": args.steps, "meshes_per_sample": 2,
+                "workload": "single sample, %s SDF decoder, N=%d grid, 2 passes (coarse -> zoom cube -> fine) + HIP marching cubes; %s "
+                            "decoder (PointFeatSize %d, EncodeStyle %s); coarse pass: %s, fine pass: %s" % (
+                                "hand-only" if hand_only else "hand+object dual", N, "ObMan" if args.tag == "nerf3" else "DexYCB MANO-aligned",
+                                specs["PointFeatSize"], specs["EncodeStyle"],
+                                "audited box-only one-plane sweep + exact re-evaluation of the voxels that can move the boxes" if main_coarse == "box" else "ordinary sweep",
+                                "audited narrow-band sweep (one-plane signs, ordinary values at every corner of every cell that can be active)" if main_fine == "band" else "ordinary sweep"),
+                "grid": N, "samples_per_gpu": args.steps, "meshes_per_sample": meshes_per_sample,
                 "parallelism": "sample-sharded x%d (one process per GPU, %s)" % (world, backend if world > 1 else "no collective"),
-                "ranks_requested": args.gpus, "world_size_env": world,
+                "ranks_requested": args.gpus, "world_size_env": world, "host_threads_per_rank": host_threads,
                 "samples_per_sec": args.steps * world / elapsed,
                 "mesh_sizes_last_sample": merged[-1] if merged else None,
+                "coarse_pass": main_coarse, "fine_pass": main_fine, "math": main_math,
             },
+            "sweeps": main_sweeps,
             "roofline": {
                 "bound": "mfma", "kernel": kernel_name,
-                "achieved": alg_flop / k1_avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": alg_flop / k1_avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "launch_ms": 1e3 * k1_avg_s, "launches_timed": len(k1_ms),
+                "achieved": alg_flop / k_avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg_flop / k_avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "launch_ms": 1e3 * k_avg_s, "launches_timed": len(launch_ms_all),
                 "algorithmic_flop_per_launch": alg_flop,
                 "executed_flop_per_launch": exec_flop,
-                "achieved_executed": exec_flop / k1_avg_s / 1e12,
-                "frac_executed": exec_flop / k1_avg_s / 1e12 / peak,
-                "note": ("achieved counts the reference's dense fp32 FLOPs (1,573,888 per point per head) against the fp16 MFMA "
-                         "peak, because that is the instruction issued: each fp32 product sum is carried as two fp16 planes per "
-                         "operand and costs three v_mfma_f32_32x32x16_f16 (%d MFMA FLOPs per point per head, plus %d on the fp32 "
-                         "MFMA for the point features); frac_executed is the matrix-pipe utilisation against the 2.5 PFLOP/s "
-                         "spec.  On these operands the part is power-limited (it holds ~1.85-1.95 GHz under this kernel; the same "
-                         "binary on all-zero operands runs at 2.36 GHz and 21 %% faster: profiles/r02_k1h_power_limit.txt)" % (
-                             EXEC_F16_FLOP_PER_POINT_HEAD, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD)) if split else (
-                    "achieved counts the reference's dense FLOPs (1,573,888 per point per head); the kernel folds the "
-                    "per-sample-constant latent columns into a bias and issues %d, so frac can exceed 1; "
-                    "frac_executed is the MFMA pipe utilisation" % EXEC_FLOP_PER_POINT_HEAD),
+                "achieved_executed": exec_flop / k_avg_s / 1e12,
+                "frac_executed": exec_flop / k_avg_s / 1e12 / peak,
+                "ordinary_sweeps_in_timed_region": len(k1_ms),
+                "note": note,
             },
         }
         if split:
             result["roofline"]["fp32_mfma_equivalent"] = {
                 "note": "the same algorithmic FLOPs against the fp32 MFMA peak the reference arithmetic would be priced at",
-                "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg_flop / k1_avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg_flop / k_avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if mc_line is not None:
             result["roofline_marching_cubes"] = mc_line
         if parity is not None:
             result["parity_in_run"] = parity
-        if other is not None:
-            result["other_math"] = other
-        result["config"]["coarse_pass"] = main_coarse
-        result["config"]["fine_pass"] = main_fine
-        if main_box_ms:
-            result["roofline"]["launch_ms_one_plane_kernel"] = float(np.mean(main_box_ms))
-        if other_coarse is not None:
-            result["other_coarse_pass"] = other_coarse
-        if narrow_band is not None:
-            result["one_plane_sweeps"] = narrow_band
-        if world == 1 and not args.no_cpu_baseline:
+        if other_sweeps is not None:
+            result["other_sweeps"] = other_sweeps
+        if other_math is not None:
+            result["other_math"] = other_math
+        if other_configs:
+            result["other_configs"] = other_configs
+        if world == 1 and not args.no_cpu_baseline and not hand_only:
             # one extra GPU sample (outside every timed region) with its pass-1 volumes kept for the CPU zoom-cube leg
             sid = 0
-            lat, mano, obj = codes[sid]
+            lat, mano, obj = cfg.codes[sid]
             dec.set_sample(lat, sample_embedding(specs, mano, obj, dec.combined))
             v1h, v1o, _ = dec.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
             r = decode_two_pass(True, True, dec, lat, mano, obj, specs, N)

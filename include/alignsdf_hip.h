@@ -96,6 +96,8 @@ int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const 
  *   [h*8 + 0..2] = min index per axis, [h*8 + 3..5] = max index per axis, [h*8 + 6] = #negative voxels,
  *   [h*8 + 7] = #points whose hidden activations left the fp16 range of the split-half planes (|x| >= 8188) - always
  *   0 under ASDF_MATH_F32; if non-zero under ASDF_MATH_F16X3 the caller should switch to ASDF_MATH_F32 and repeat.
+ *   Bit 30 of word [7] is set when more voxels lay within the refinement threshold of the level than the refinement list
+ *   holds (asdf_decoder_set_refine): the signs next to the level are then the split-half arithmetic's, not the fp32 chain's.
  *   With bbox_dev == NULL the same count is available from asdf_decoder_status.
  * Replaces one pass of utils/mesh.py:27-63 (or :82-115) plus the nonzero/min/max of
  * get_higher_res_cube (utils/mesh.py:208-237); deep_sdf/mesh.py:24-54 for the legacy entry point. */
@@ -110,15 +112,19 @@ int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], floa
  *   2. lists the voxels a head leaves undecided (-tau <= value < tau) that lie outside that head's box - only those can
  *      move it - and re-evaluates them on the fp32 MFMA chain (the arithmetic of ASDF_MATH_F32); every one that is
  *      negative extends the box.
- * bbox_dev (int32[32], required): words 0..15 then hold exactly the min / max words asdf_decode_grid would have produced,
+ * bbox_dev (int32[48], required): words 0..15 then hold exactly the min / max words asdf_decode_grid would have produced,
  * PROVIDED the one-plane values are within tau of the exact ones; word [6] / [14] is non-zero iff the head has a negative
- * voxel (it is not the count), [7] / [15] the fp16 range report as usual.  The proviso is checked on every call where it
- * matters - on the re-evaluated voxels - and the outcome travels in words 16..31, a copy of the decoder's status record
- * taken behind the call: [16 + 3] = largest |exact - one-plane| seen (float bits), [16 + 2] != 0 = a voxel taken as
- * certainly negative was not, [16 + 1] = number of candidates (more than 65536: not all were re-evaluated).  A caller must
- * treat [7] / [15] / [18] != 0, [17] > 65536 or [19] > tau / 2 as "repeat with asdf_decode_grid"
- * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also calibrate tau per decoder from a whole-volume
- * comparison with the split-half sweep).
+ * voxel (it is not the count), [7] / [15] the fp16 range report as usual.  The proviso is checked on every call: on the
+ * re-evaluated candidates, and on an AUDIT sample - asdf_decoder_set_audit voxels (default 65536) drawn at random from those
+ * both heads decided by sign alone, re-evaluated with the split-half arithmetic of the ordinary sweep (at most half the lattice).  The outcome travels in
+ * words 16..31, a copy of the decoder's status record taken behind the call ([16 + 3] = largest |exact - one-plane| over the
+ * candidates (float bits), [16 + 2] != 0 = a voxel taken as certainly negative was not), and in words 32..39:
+ *   [32] number of candidates (more than 2^19: not all were re-evaluated),
+ *   [33] / [34] asdf_decode_grid_band only: voxels marked for the hand / object head (more than 2^22: not all re-evaluated),
+ *   [35] largest |exact - one-plane| over the audit sample (float bits), [36] audit voxels whose SIGN the exact value
+ *   contradicts, [37] audit evaluations (voxels x heads), [38] near-level voxels beyond the refinement list (band sweep).
+ * A caller must treat [7] / [15] / [18] / [36] != 0, [32] > 2^19, or [19] or [35] > tau / 2 as "repeat with asdf_decode_grid"
+ * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also re-estimate tau from the audit of every sample).
  * scratch_*_dev: N^3 floats per evaluated head (same NULL rules as asdf_decode_grid); contents afterwards: one-plane
  * values, exact ones at the re-evaluated voxels.  Affine point features only (ASDF_EINVAL otherwise). */
 int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
@@ -136,12 +142,19 @@ int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], 
  * Afterwards every voxel a marching-cubes pass at level 0 reads the VALUE of holds exactly what asdf_decode_grid delivers
  * there, and every other voxel has the right SIGN: the meshes are identical, vertex for vertex and face for face;
  * the volume away from the surface holds fp16-class values and must not be used for anything else.
- * rec_dev (int32[32], required): [7] / [15] fp16 range report, [16 + 3] largest |re-evaluated - one-plane| over the re-evaluated
- * voxels (float bits), [28] / [29] voxels marked for the hand / object head (more than 2^21: not all were re-evaluated).
- * A caller must repeat with asdf_decode_grid when [7] / [15] != 0, [28] or [29] > 2^21, or [19] > tau / 2
- * (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  SeparateDecoder with affine point features only. */
+ * rec_dev (int32[48], required; layout as asdf_decode_grid_box): [7] / [15] fp16 range report, [16 + 3] largest
+ * |re-evaluated - one-plane| over the marked voxels (float bits), [33] / [34] voxels marked for the hand / object head (more
+ * than 2^22: not all were re-evaluated), [35] .. [37] the audit: per head, asdf_decoder_set_audit UNMARKED voxels - voxels whose
+ * sign is all marching cubes will read - drawn at random and re-evaluated with the marked ones; [38] near-level voxels beyond
+ * the refinement list.  A caller must repeat with asdf_decode_grid when [7] / [15] / [36] / [38] != 0, [33] or [34] > 2^22, or
+ * [19] or [35] > tau / 2 (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  SeparateDecoder, affine features. */
 int asdf_decode_grid_band(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
+
+/* The audit sample of the one-plane sweeps above: `voxels` per sweep and head (0 switches it off, at most 262144; default
+ * 65536), drawn with a splitmix64 stream that starts at `seed` and advances with every sweep - so a run is reproducible and
+ * no two sweeps look at the same voxels. */
+int asdf_decoder_set_audit(asdf_decoder_t* dec, int32_t voxels, uint64_t seed);
 
 /* Bounding box of the voxels with value < 0 of one [n0][n1][n2] fp32 device volume, as int32[16] on the
  * device (record 0 only: [0..2] min index per axis, [3..5] max index per axis, [6] count; min = INT_MAX and

@@ -1,0 +1,86 @@
+"""Round-3 golden vectors: MORE SAMPLES at BASELINE.json's full sizes, produced by RUNNING THE REFERENCE (zerchen/AlignSDF at
+/root/reference) in the build container.
+
+Rounds 1 / 2 pinned one sample (latent 0) per configuration at N = 128 / 256; one sign flip at 256^3 changes the vertex and face
+counts, so one sample is thin evidence for "identical triangle counts".  This script runs the reference's
+create_mesh_combined_decoder (utils/mesh.py:17-195) on
+
+    nerf3 (ObMan decoder)              N = 128: synthetic samples 1..8,   N = 256: samples 1, 2
+    both9 (DexYCB MANO-aligned)        N = 128: samples 1..8 (each with its own pose_inputs(s)),   N = 256: samples 1, 2
+
+and records, per (tag, N, sample): the negative-voxel boxes and counts of pass 1, the zoom cube (new_voxel_size, new_origin),
+8192 probes per head and pass, the number of voxels within 1e-6 of the level, and - step 2, skimage 0.18.3 under
+/opt/conda/bin/python3.9 with the reference's call (utils/mesh.py:354) - V, F and coordinate / index checksums of both surfaces.
+-> tests/golden/ref_fullsize_r3_<tag>.npz, keys "<N>/s<sample>/<name>".
+
+Usage:  python tests/golden/make_r3_goldens.py nerf3 [both9]          (~20 min of CPU per tag with 4 threads)
+        /opt/conda/bin/python3.9 tests/golden/make_r3_goldens.py --mc nerf3 [both9]
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+TMP = "/tmp/asdf_r3_%s_%d_s%d_%s.npy"
+PLAN = ((128, tuple(range(1, 9))), (256, (1, 2)))
+
+
+def out_path(tag):
+    return os.path.join(HERE, "ref_fullsize_r3_%s.npz" % tag)
+
+
+def decode(tags):
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from alignsdf_amd import synthetic as syn
+    import make_r2_goldens as r2
+    import make_ref_goldens as mrg
+    arch, um, uu, _ = mrg.import_reference()
+    for tag in tags:
+        specs, sd = syn.specs_for(tag), syn.full_state_dict(tag)
+        dec = arch.SeparateDecoder(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
+        dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        gold = dict(np.load(out_path(tag))) if os.path.exists(out_path(tag)) else {}
+        for N, samples in PLAN:
+            for s in samples:
+                if "%d/s%d/bbox" % (N, s) in gold:
+                    continue
+                latent, mano, obj = r2._torch_inputs(tag, syn, torch, s)
+                g, vols2 = r2.two_pass(um, dec, latent, mano, obj, specs, N)
+                for k, v in g.items():
+                    name = k[:-len("_%d" % N)]
+                    if name == "probe_sel":
+                        gold["%d/probe_sel" % N] = v            # the same index set for every sample of a size
+                    else:
+                        gold["%d/s%d/%s" % (N, s, name)] = v
+                for part, (v, _, _) in vols2.items():
+                    np.save(TMP % (tag, N, s, part), v)
+                print(tag, N, "sample", s, "zoom", g["new_voxel_size_%d" % N], g["new_origin_%d" % N], "neg", g["neg_count_%d" % N], flush=True)
+                np.savez_compressed(out_path(tag), **gold)
+
+
+def mc(tags):
+    from skimage.measure import marching_cubes_lewiner
+    for tag in tags:
+        gold = dict(np.load(out_path(tag)))
+        for N, samples in PLAN:
+            for s in samples:
+                if "%d/s%d/bbox" % (N, s) not in gold or "%d/s%d/mc_hand" % (N, s) in gold:
+                    continue
+                vs = np.float32(gold["%d/s%d/new_voxel_size" % (N, s)][0])
+                for part in ("hand", "obj"):
+                    vol = np.load(TMP % (tag, N, s, part))
+                    v, f, _, _ = marching_cubes_lewiner(vol, level=0.0, spacing=[vs] * 3)
+                    gold["%d/s%d/mc_%s" % (N, s, part)] = np.array([len(v), len(f)])
+                    gold["%d/s%d/mc_%s_vsum" % (N, s, part)] = v.astype(np.float64).sum(0)
+                    gold["%d/s%d/mc_%s_fsum" % (N, s, part)] = f.astype(np.int64).sum(0)
+                    print(tag, N, "sample", s, part, "V", len(v), "F", len(f), flush=True)
+        np.savez_compressed(out_path(tag), **gold)
+
+
+if __name__ == "__main__":
+    tags = [a for a in sys.argv[1:] if not a.startswith("-")] or ["nerf3", "both9"]
+    mc(tags) if "--mc" in sys.argv else decode(tags)

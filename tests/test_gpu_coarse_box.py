@@ -112,7 +112,7 @@ def test_box_entry_point_argument_checks(native_lib):
     import ctypes
     hip, specs = _decoder("nerf9")          # NeRF-encoded features: no one-plane kernel
     _bind(hip, specs, 0)
-    rec = torch.zeros(32, dtype=torch.int32, device="cuda")
+    rec = torch.zeros(48, dtype=torch.int32, device="cuda")
     vol = torch.zeros(32 ** 3, dtype=torch.float32, device="cuda")
     org = (ctypes.c_float * 3)(-1.0, -1.0, -1.0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -143,6 +143,7 @@ def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
     N = 64
     samples = [(i,) + src("s%d" % i, i) for i in (0, 3, 7, 11, 20, 21)]
     out = {}
+    monkeypatch.setenv("ASDF_FINE", "exact")      # (ordinary fine sweeps: the volumes themselves are compared below)
     for mode in ("exact", "box"):
         monkeypatch.setenv("ASDF_COARSE", mode)
         dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()})
@@ -270,7 +271,7 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
     src = synthetic_code_source("nerf3", "cuda")
     samples = [(i,) + src("s%d" % i, i) for i in (0, 4, 8, 15, 16)]
     out = {}
-    for name, env in (("fp32", {}), ("one_plane", {"ASDF_COARSE": "box", "ASDF_FINE": "band"})):
+    for name, env in (("fp32", {"ASDF_COARSE": "exact", "ASDF_FINE": "exact"}), ("one_plane", {"ASDF_COARSE": "box", "ASDF_FINE": "band"})):
         for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

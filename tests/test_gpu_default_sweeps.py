@@ -1,0 +1,179 @@
+"""The product's DEFAULT sweeps for mesh-producing calls - the audited box-only coarse sweep and the audited narrow-band fine sweep
+(alignsdf_amd.hip_decoder: DEFAULT_COARSE / DEFAULT_FINE) - at the size the headline metric is quoted on.
+
+What `create_mesh_combined_decoder` (utils/mesh.py:17-195) delivers is meshes; under the defaults they must be the meshes of ordinary
+sweeps bit for bit (and have the faces of the fp32 chain's), for every one of the 64 synthetic samples the benchmark cycles through,
+with no sweep refused; and the audit - a random sample of the voxels whose SIGN is all that is trusted, re-evaluated exactly in every
+sweep - must actually run, find no contradiction, and be what refuses a sweep whose allowance is wrong."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(tag):
+    from alignsdf_amd.networks.model import build_decoder
+    specs = syn.specs_for(tag)
+    return build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()}), specs
+
+
+def _meshes(tag, N, samples, monkeypatch, coarse=None, fine=None, math=None):
+    """{sample: (origin, voxel_size, verts_hand, faces_hand, verts_obj, faces_obj)} through the product's sample pipeline."""
+    from alignsdf_amd.reconstruct import pipelined_two_pass, synthetic_code_source
+    from alignsdf_amd.utils.utils import decoder_for
+    for k, v in (("ASDF_COARSE", coarse), ("ASDF_FINE", fine), ("ASDF_MATH", math)):
+        monkeypatch.delenv(k, raising=False)
+        if v is not None:
+            monkeypatch.setenv(k, v)
+    dec, specs = _module(tag)
+    src = synthetic_code_source(tag, "cuda")
+    items = [(s,) + src("s%d" % s, s) for s in samples]
+    out = {}
+    for s, r in pipelined_two_pass(dec, specs, iter(items), N):
+        out[s] = (r["origin"], float(r["voxel_size"]), r["verts_hand"], r["faces_hand"], r["verts_obj"], r["faces_obj"])
+    hip = decoder_for(dec, specs, items[0][2])
+    return out, hip
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, monkeypatch):
+    """N = 256 (BASELINE configs[2] / configs[4]'s decoder), all 64 synthetic samples: torch.equal on vertices and faces."""
+    N = 256
+    samples = list(range(64))
+    want, _ = _meshes(tag, N, samples, monkeypatch, coarse="exact", fine="exact")
+    got, hip = _meshes(tag, N, samples, monkeypatch)                     # the defaults
+    assert (hip.coarse_mode, hip.fine_mode) == ("box", "band") and hip.math == "f16x3"
+    for s in samples:
+        a, b = want[s], got[s]
+        assert a[0] == b[0] and a[1] == b[1], (s, "zoom cube")
+        for k in (2, 3, 4, 5):
+            assert torch.equal(a[k], b[k]), (s, k)
+    # sample 0's coarse pass calibrated the allowance on an ordinary sweep; everything else ran on the one-plane kernel
+    assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 64, (hip.box_stats, hip.band_stats)
+    assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+    # the audit ran in every sweep (voxels x heads), found no sign contradiction, and its error stayed inside the allowance
+    assert hip.box_stats["audit_evals"] >= 63 * 2 * 60000 and hip.band_stats["audit_evals"] >= 64 * 2 * 60000
+    assert hip.box_stats["audit_flips"] == 0 and hip.band_stats["audit_flips"] == 0
+    assert 0.0 < hip.band_stats["audit_max_err"] * hip._tail <= 0.5 * hip.band_stats["tau_min"]
+    print(tag, "box", hip.box_stats, "band", hip.band_stats, "tail", hip._tail)
+
+
+def test_default_meshes_have_the_faces_of_the_fp32_chain(monkeypatch):
+    """Against the fp32 MFMA chain (the strict-reading arithmetic): identical faces and counts; vertices within the two arithmetics'
+    difference (a few 1e-7 in the SDF values moves an interpolated vertex by 1e-7 / |v0 - v1| of a voxel: up to a few 1e-2 on the
+    rare edges whose two corner values are both within 1e-5 of the level, 1e-4 typically)."""
+    N = 128
+    samples = list(range(12))
+    want, _ = _meshes("nerf3", N, samples, monkeypatch, coarse="exact", fine="exact", math="f32")
+    got, hip = _meshes("nerf3", N, samples, monkeypatch)
+    for s in samples:
+        a, b = want[s], got[s]
+        assert a[0] == b[0] and a[1] == b[1]
+        assert torch.equal(a[3], b[3]) and torch.equal(a[5], b[5]), s
+        assert float((a[2] - b[2]).abs().max()) <= 5e-2 and float((a[4] - b[4]).abs().max()) <= 5e-2
+        assert float((a[2] - b[2]).abs().mean()) <= 1e-4 and float((a[4] - b[4]).abs().mean()) <= 1e-4
+    assert hip.band_stats["fallback"] == 0 and hip.box_stats["fallback"] == 0
+
+
+def _raw_band(hip, N, origin, vs, tau, entry="asdf_decode_grid_band"):
+    from alignsdf_amd import _native
+    vh = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+    vo = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+    rec = torch.zeros(48, dtype=torch.int32, device="cuda")
+    org = (ctypes.c_float * 3)(*origin)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _native.check(getattr(hip._L, entry)(hip._h, N, org, ctypes.c_float(vs), 0, ctypes.c_float(tau), vh.data_ptr(), vo.data_ptr(),
+                                         rec.data_ptr(), st), entry)
+    return vh, vo, rec.cpu().numpy()
+
+
+def test_audit_record_of_the_c_abi():
+    """The audit through the C ABI: it evaluates the requested number of UNMARKED voxels per head, its error is a lower bound of the
+    lattice maximum of |one-plane - exact| and of the same order, it is reproducible under a seed, off when set to 0 - and with a
+    deliberately understated allowance it reports an error above tau / 2 (what makes the caller refuse the sweep)."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    hip = HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
+    hip.set_sample(torch.from_numpy(syn.latent_code(3)).cuda())
+    N = 96
+    origin, vs = [-0.62, -0.36, -0.37], 1.21 / (N - 1)
+    eh, eo, _ = hip.decode_grid(N, origin, vs)                      # ordinary volumes (this also calibrates the activation scales)
+    f = lambda w: float(np.int32(w).view(np.float32))
+    # one-plane values: the scratch volumes of a box sweep with a tiny allowance (next to no candidates) and no audit
+    hip.set_audit(0)
+    ph, po, r0 = _raw_band(hip, N, origin, vs, 1e-7, "asdf_decode_grid_box")
+    assert int(r0[37]) == 0 and int(r0[35]) == 0 and int(r0[32]) < 64
+    lattice_max = max(float((ph - eh).abs().max()), float((po - eo).abs().max()))
+    assert 1e-5 < lattice_max < 5e-3
+    # the audit of an honest sweep
+    tau = 4.0 * lattice_max
+    hip.set_audit(1 << 16, seed=1234)
+    _, _, r1 = _raw_band(hip, N, origin, vs, tau)
+    marked = (int(r1[33]), int(r1[34]))
+    assert all(0 < m < N ** 3 // 2 for m in marked)
+    assert int(r1[36]) == 0                                         # no audited voxel has the other sign
+    assert 2 * 65536 * 0.75 <= int(r1[37]) <= 2 * 65536             # picks that fell on marked voxels are dropped
+    assert 0.2 * lattice_max <= f(r1[35]) <= lattice_max + 1e-6
+    assert f(r1[19]) <= lattice_max + 1e-6
+    hip.set_audit(1 << 16, seed=1234)
+    _, _, r2 = _raw_band(hip, N, origin, vs, tau)
+    assert int(r2[35]) == int(r1[35]) and int(r2[37]) == int(r1[37])      # same seed, same draw
+    _, _, r3 = _raw_band(hip, N, origin, vs, tau)
+    assert int(r3[37]) > 0 and (int(r3[35]), int(r3[37])) != (int(r1[35]), int(r1[37]))      # the seed advances with every sweep
+    # an allowance 16 x too small: fewer voxels are marked, and the audit - looking where nothing else does - sees an error > tau / 2
+    small = lattice_max / 4.0
+    _, _, r4 = _raw_band(hip, N, origin, vs, small)
+    assert f(r4[35]) > 0.5 * small
+    hip.close()
+
+
+def test_python_layer_refuses_on_the_audit_alone():
+    """The re-evaluated (marked) voxels sit next to the surface; make THEIR check pass trivially and the allowance wrong: only the
+    audit can notice.  The sweep must be refused and repeated as an ordinary one."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    hip = HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
+    N = 96
+    lat = lambda s: torch.from_numpy(syn.latent_code(s)).cuda()
+    hip.set_sample(lat(0))
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))      # calibrates the allowance
+    honest = hip._box_tau
+    hip.set_sample(lat(1))
+    real_judge = hip._judge
+
+    def judge_without_marked_error(r, tau, stats, cap_word, cap):
+        r = r.copy()
+        r[19] = 0                              # pretend the re-evaluated voxels showed no error at all
+        return real_judge(r, tau, stats, cap_word, cap)
+
+    hip._judge = judge_without_marked_error
+    hip._box_tau = honest / 32.0
+    bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "band" and hip.fine_needs_repeat(ticket)
+    assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * hip._tail > 0.5 * honest / 32.0
+    bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "exact" and not hip.fine_needs_repeat(ticket)
+    assert hip._box_tau > honest / 32.0        # the refused sweep's audit went into the allowance
+    hip.close()
+
+
+def test_allowance_follows_the_samples():
+    """tau is re-estimated from every sweep's audit: after a run of samples it is 4 x the largest recent estimate, not the value the
+    first sample calibrated."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    hip = HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
+    N = 64
+    taus = []
+    for s in range(12):
+        hip.set_sample(torch.from_numpy(syn.latent_code(s)).cuda())
+        hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))
+        taus.append(hip._box_tau)
+        _, _, t = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+        assert not hip.fine_needs_repeat(t)
+    assert len(hip._err_window) == 16 and abs(hip._box_tau - 4.0 * max(hip._err_window)) <= 1e-12
+    assert len(set(taus)) > 1 and all(1e-5 < t < 0.05 for t in taus)
+    assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+    hip.close()

@@ -98,9 +98,11 @@ def test_resnet18_like_shapes_cpu():
 
 
 @pytest.mark.gpu
-def test_encoder_in_the_sample_pipeline():
+def test_encoder_in_the_sample_pipeline(monkeypatch):
     """Codes produced on the device by an encoder in the loop (no host synchronisation) give the same surfaces as the same
     codes fed as resident tensors."""
+    monkeypatch.setenv("ASDF_FINE", "exact")      # the pass-2 VOLUMES are compared below: ordinary sweeps (the pipeline's default
+                                                  # narrow-band volumes are only defined where marching cubes reads values)
     from alignsdf_amd.frontend import ResNet18Like, encoder_code_source
     from alignsdf_amd.hip_decoder import HipSdfDecoder
     from alignsdf_amd.reconstruct import pipelined_two_pass
