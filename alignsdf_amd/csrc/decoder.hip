@@ -403,7 +403,7 @@ struct asdf_decoder {
   int* audit_count;
 };
 static constexpr int kNearCap = 1 << 16;      // near-level refinement list of a split-half sweep
-static constexpr int kCandCap = 1 << 19;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
+static constexpr int kCandCap = 1 << 21;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
                                               // or tiny shape - lists its whole surface shell); shares near_idx
 static constexpr int kAuditCap = 1 << 18;
 

@@ -24,10 +24,16 @@ DEFAULT_COARSE = "box"        # coarse pass of the two-pass flow: "exact" | "box
 DEFAULT_FINE = "band"         # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
 BAND_CAP = 1 << 22           # voxels per head the narrow-band sweep can re-evaluate (csrc/decoder.hip: kBandCap)
 NEAR_CAP = 1 << 16           # near-level refinement list of a split-half sweep
-CAND_CAP = 1 << 19           # box candidates of one coarse sweep
+CAND_CAP = 1 << 21           # box candidates of one coarse sweep
 AUDIT_VOXELS = 1 << 16        # per one-plane sweep and head (asdf_decoder_set_audit)
 NEAR_OVERFLOW_BIT = 0x40000000
 REC_WORDS = 48                # record of a one-plane sweep (include/alignsdf_hip.h: asdf_decode_grid_box)
+# allowance tau = TAU_FACTOR x the estimated lattice maximum of |one-plane - exact| of recent sweeps; a sweep is accepted while ITS
+# estimate (and the error on its re-evaluated voxels) stays within TAU_ACCEPT x the tau it was launched with - a factor
+# TAU_FACTOR x TAU_ACCEPT = 3 of sample-to-sample head room (pose-aligned decoders vary by 2 x), 1 / TAU_ACCEPT = 1.67 of safety
+# between the tail-corrected estimate and the bound that must hold for every voxel
+TAU_FACTOR = 5.0
+TAU_ACCEPT = 0.6
 
 
 def _effective(module_sd, name):
@@ -196,9 +202,9 @@ class HipSdfDecoder:
         self._force_f32_once = False # ... and on the fp32 chain (its near-level list overflowed)
         self.band_stats = self._new_stats("band")
         self.box_stats = self._new_stats("box")
-        # error allowance tau of the one-plane values: 4 x the estimated largest |one-plane - exact| over a lattice.  Calibrated
+        # error allowance tau of the one-plane values: TAU_FACTOR x the estimated largest |one-plane - exact| over a lattice.  Calibrated
         # per decoder and scale set from a whole-lattice comparison, then RE-ESTIMATED FROM EVERY SWEEP'S AUDIT: tau in use =
-        # 4 x the largest estimate of the last 16 sweeps (8 samples), where a sweep's estimate is its audit's largest error x
+        # TAU_FACTOR x the largest estimate of the last 16 sweeps (8 samples), where a sweep's estimate is its audit's largest error x
         # the tail ratio (whole-lattice maximum / audit-sample maximum, measured in the calibration sweep)
         self._box_tau = None
         self._box_epoch = -1
@@ -464,7 +470,7 @@ class HipSdfDecoder:
 
     # ---- the one-plane sweeps (asdf_decode_grid_box / asdf_decode_grid_band): allowance, record, acceptance -------------------
     def _tau_current(self):
-        return float(np.clip(4.0 * max(self._err_window), 1e-6, 0.05)) if self._err_window else None
+        return float(np.clip(TAU_FACTOR * max(self._err_window), 1e-6, 0.05)) if self._err_window else None
 
     def _one_plane_launch(self, fn, name, N, origin3, voxel_size, grid_mode, hand, obj, tau):
         if self.combined:
@@ -491,7 +497,7 @@ class HipSdfDecoder:
     def _judge(self, r, tau, stats, cap_word, cap):
         """Verdict on the record of one one-plane sweep launched with allowance tau: (accepted, range violations, reason).
         Accepted = no fp16 range violation, every list within its capacity, no contradiction, the largest |exact - one-plane| over
-        the re-evaluated voxels AND the audit's estimate of the lattice maximum within tau / 2, and no audit voxel whose sign the
+        the re-evaluated voxels AND the audit's estimate of the lattice maximum within TAU_ACCEPT x tau, and no audit voxel whose sign the
         exact value contradicts.  The audit's estimate enters the allowance of the sweeps that follow."""
         bad, near_over = self._range_words(r)
         f = lambda w: float(np.int32(r[w]).view(np.float32))
@@ -518,9 +524,9 @@ class HipSdfDecoder:
             reason = "a voxel taken as certainly negative was not"
         elif flips:
             reason = "%d of %d audit voxels have the other sign" % (flips, evals)
-        elif not (err <= 0.5 * tau):
+        elif not (err <= TAU_ACCEPT * tau):
             reason = "error %.3g on the re-evaluated voxels against allowance %.3g" % (err, tau)
-        elif not (est <= 0.5 * tau):
+        elif not (est <= TAU_ACCEPT * tau):
             reason = "audit error %.3g (x tail %.2f) against allowance %.3g" % (audit, self._tail, tau)
         elif self.audit_voxels and evals == 0:
             reason = "the audit evaluated nothing"
@@ -566,6 +572,7 @@ class HipSdfDecoder:
                 ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP)
             if ok:
                 self.box_stats["box"] += 1
+                self._box_failures = 0              # (three refusals IN A ROW switch the mode off)
                 return r[:16].copy()
             self.box_stats["fallback"] += 1
             if bad:
@@ -627,6 +634,7 @@ class HipSdfDecoder:
                 ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP)
             if ok:
                 self.band_stats["band"] += 1
+                self._band_failures = 0
                 return False
             self.band_stats["fallback"] += 1
             if bad:
@@ -650,7 +658,7 @@ class HipSdfDecoder:
 
     def _calibrate_box(self, args, exact_vols):
         """Error allowance of the one-plane sweep for this decoder and scale set, from one whole coarse sweep run both ways:
-        4 x the largest |one-plane - split-half| over every voxel (2 x N^3 values).  A random sample of the audit's size from the
+        TAU_FACTOR x the largest |one-plane - split-half| over every voxel (2 x N^3 values).  A random sample of the audit's size from the
         same differences gives the tail ratio (lattice maximum / sample maximum) with which the audits of later sweeps estimate
         THEIR lattice maximum."""
         import logging
@@ -671,7 +679,7 @@ class HipSdfDecoder:
                 sample = max(sample, float(diff[pick].max().item()))
         self._box_epoch = self._recalibrations
         self._err_window.clear()
-        if not np.isfinite(err) or 4.0 * err > 0.05:
+        if not np.isfinite(err) or TAU_FACTOR * err > 0.05:
             logging.warning("one-plane sweeps: error %.3g too large, switched off for this decoder", err)
             self.coarse_mode = self.fine_mode = "exact"
             self._box_tau = None

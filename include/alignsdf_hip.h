@@ -119,11 +119,11 @@ int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], floa
  * both heads decided by sign alone, re-evaluated with the split-half arithmetic of the ordinary sweep (at most half the lattice).  The outcome travels in
  * words 16..31, a copy of the decoder's status record taken behind the call ([16 + 3] = largest |exact - one-plane| over the
  * candidates (float bits), [16 + 2] != 0 = a voxel taken as certainly negative was not), and in words 32..39:
- *   [32] number of candidates (more than 2^19: not all were re-evaluated),
+ *   [32] number of candidates (more than 2^21: not all were re-evaluated),
  *   [33] / [34] asdf_decode_grid_band only: voxels marked for the hand / object head (more than 2^22: not all re-evaluated),
  *   [35] largest |exact - one-plane| over the audit sample (float bits), [36] audit voxels whose SIGN the exact value
  *   contradicts, [37] audit evaluations (voxels x heads), [38] near-level voxels beyond the refinement list (band sweep).
- * A caller must treat [7] / [15] / [18] / [36] != 0, [32] > 2^19, or [19] or [35] > tau / 2 as "repeat with asdf_decode_grid"
+ * A caller must treat [7] / [15] / [18] / [36] != 0, [32] > 2^21, or [19] or [35] > tau / 2 as "repeat with asdf_decode_grid"
  * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also re-estimate tau from the audit of every sample).
  * scratch_*_dev: N^3 floats per evaluated head (same NULL rules as asdf_decode_grid); contents afterwards: one-plane
  * values, exact ones at the re-evaluated voxels.  Affine point features only (ASDF_EINVAL otherwise). */

@@ -44,7 +44,7 @@ def test_boxes_equal_the_ordinary_sweep(tag, N):
         assert _boxes(got) == _boxes(want), (sample, got, want)
     # the first sample calibrated the allowance on an ordinary sweep, the others ran the one-plane kernel and were accepted
     assert hip.box_stats["box"] == 4 and hip.box_stats["exact"] == 1 and hip.box_stats["fallback"] == 0, hip.box_stats
-    assert 0.0 < hip._box_tau < 0.05 and hip.box_stats["max_err"] <= 0.5 * hip._box_tau
+    assert 0.0 < hip._box_tau < 0.05 and hip.box_stats["max_err"] <= 0.6 * hip._box_tau
     assert hip.range_violations() == 0
     hip.close()
 
@@ -190,7 +190,7 @@ def test_band_volumes_give_the_identical_meshes(tag, N):
             ve, fe = marching_cubes_device(e, 0.0)
             assert torch.equal(fb, fe) and torch.equal(vb, ve)                    # the ordinary sweep's mesh, bit for bit
     assert hip.band_stats["band"] >= 3
-    assert hip.band_stats["fallback"] == 0 and hip.band_stats["max_err"] <= 0.5 * hip._box_tau
+    assert hip.band_stats["fallback"] == 0 and hip.band_stats["max_err"] <= 0.6 * hip._box_tau
     assert 0 < hip.band_stats["max_marked"] < (1 << 21)
     hip.close()
 

@@ -59,7 +59,7 @@ def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, 
     # the audit ran in every sweep (voxels x heads), found no sign contradiction, and its error stayed inside the allowance
     assert hip.box_stats["audit_evals"] >= 63 * 2 * 60000 and hip.band_stats["audit_evals"] >= 64 * 2 * 60000
     assert hip.box_stats["audit_flips"] == 0 and hip.band_stats["audit_flips"] == 0
-    assert 0.0 < hip.band_stats["audit_max_err"] * hip._tail <= 0.5 * hip.band_stats["tau_min"]
+    assert 0.0 < hip.band_stats["audit_max_err"] * hip._tail <= 0.6 * hip.band_stats["tau_max"]
     print(tag, "box", hip.box_stats, "band", hip.band_stats, "tail", hip._tail)
 
 
@@ -110,7 +110,7 @@ def test_audit_record_of_the_c_abi():
     lattice_max = max(float((ph - eh).abs().max()), float((po - eo).abs().max()))
     assert 1e-5 < lattice_max < 5e-3
     # the audit of an honest sweep
-    tau = 4.0 * lattice_max
+    tau = 5.0 * lattice_max
     hip.set_audit(1 << 16, seed=1234)
     _, _, r1 = _raw_band(hip, N, origin, vs, tau)
     marked = (int(r1[33]), int(r1[34]))
@@ -153,7 +153,7 @@ def test_python_layer_refuses_on_the_audit_alone():
     hip._box_tau = honest / 32.0
     bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
     assert ticket["kind"] == "band" and hip.fine_needs_repeat(ticket)
-    assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * hip._tail > 0.5 * honest / 32.0
+    assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * hip._tail > 0.6 * honest / 32.0
     bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
     assert ticket["kind"] == "exact" and not hip.fine_needs_repeat(ticket)
     assert hip._box_tau > honest / 32.0        # the refused sweep's audit went into the allowance
@@ -173,7 +173,7 @@ def test_allowance_follows_the_samples():
         taus.append(hip._box_tau)
         _, _, t = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
         assert not hip.fine_needs_repeat(t)
-    assert len(hip._err_window) == 16 and abs(hip._box_tau - 4.0 * max(hip._err_window)) <= 1e-12
+    assert len(hip._err_window) == 16 and abs(hip._box_tau - 5.0 * max(hip._err_window)) <= 1e-12
     assert len(set(taus)) > 1 and all(1e-5 < t < 0.05 for t in taus)
     assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     hip.close()
