@@ -43,7 +43,35 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
 // v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
 // v_pack per register on top)
+template <int PL>
+__device__ __forceinline__ float amax_value(float amax) {      // the running range maximum as a float (the one-plane kernel under PK_RELU keeps two packed halves)
+#if ASDF16_PK_RELU
+  if (PL == 1) {
+    const h2 m = __builtin_bit_cast(h2, amax);
+    return fmaxf((float)m[0], (float)m[1]);
+  }
+#endif
+  return amax;
+}
 __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
+#if ASDF16_PK_RELU
+  // mul, convert, then ReLU and the running maximum on the packed pair: negative values become +0 either way, positive ones
+  // are converted exactly as before (same rounding of the same product), an overflow is an infinity that the maximum keeps
+  f32x2 u;
+  u[0] = a0; u[1] = a1;
+  u = u * mul;
+  h2 q = __builtin_convertvector(u, h2);
+  const h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+  q = __builtin_elementwise_max(q, zero);
+  h2 m = __builtin_bit_cast(h2, amax);
+  m = __builtin_elementwise_max(m, q);
+  amax = __builtin_bit_cast(float, m);
+  asm volatile("" : "+v"(amax));
+  u32x4 dd = __builtin_bit_cast(u32x4, dst);
+  dd[w] = __builtin_bit_cast(unsigned, q);
+  dst = __builtin_bit_cast(h8, dd);
+  return;
+#endif
   f32x2 t;
   t[0] = __int_as_float(max(__float_as_int(a0), 0));
   t[1] = __int_as_float(max(__float_as_int(a1), 0));
@@ -73,6 +101,12 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #ifndef ASDF16_BARRIER_KB
 #define ASDF16_BARRIER_KB (ASDF16_STAGE_KB / 2)      // K-block in front of which the stage's wait + barrier sit
 #endif
+#ifndef ASDF16_BARRIER_KB_P1
+#define ASDF16_BARRIER_KB_P1 12      // ... of the one-plane kernel (16 KiB stages: the wait then covers pieces issued 2.75 stages ago)
+#endif
+#ifndef ASDF16_PRE_KB_P1
+#define ASDF16_PRE_KB_P1 (ASDF16_STAGE_KB / 2 + 2)      // ... and the K-block of its last stage that carries the next tile's preloads
+#endif
 #ifndef ASDF16_MFMA_ORDER
 #define ASDF16_MFMA_ORDER 0      // order of the three MFMAs of a K-block (an energy experiment: see the tuning log)
 #endif
@@ -90,6 +124,23 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #endif
 #ifndef ASDF16_PRE_KB
 #define ASDF16_PRE_KB (ASDF16_STAGE_KB / 2 + 2)      // K-block of a tile's last stage whose region carries the next tile's preloads
+#endif
+// one-plane kernel (PL = 1) only - its K-blocks are 32 / 64 matrix-pipe cycles, not 96, so what hides behind a K-block of the
+// split-half kernel does not hide here:
+#ifndef ASDF16_PK_RELU
+#define ASDF16_PK_RELU 0         // ReLU and the range maximum on the PACKED fp16 pair (v_pk_max_f16) behind the conversion: 4 VALU per pair, not 6
+#endif
+#ifndef ASDF16_W4_TILE
+#define ASDF16_W4_TILE 1         // the 16 last-layer weights of a tile's deferred epilogue read at once, half a tile ahead (not pair by pair one K-block ahead)
+#endif
+#ifndef ASDF16_PF_G2
+#define ASDF16_PF_G2 2           // A-fragment prefetch distance (K-blocks of 64 cycles) of the two-group kernel
+#endif
+#ifndef ASDF16_FOLD_BALLOT
+#define ASDF16_FOLD_BALLOT 1     // the negative-voxel fold of a tile is skipped when no lane of the wave has anything to fold
+#endif
+#ifndef ASDF16_FAST_TANH
+#define ASDF16_FAST_TANH 1       // tanh as 1 - 2 / (1 + exp(2 x)) on the hardware exp / rcp (absolute error ~1e-7; the values carry ~1e-4)
 #endif
 
 // The split-half stream of a head is a flat sequence of (tile, K-block) records of 2 KiB ([plane hi / lo][lane][8 halves]),
@@ -115,7 +166,7 @@ struct S16 {
   static constexpr int kMfmas = PL == 2 ? 3 : G;           // MFMAs per K-block
   // A fragments are read from LDS this many K-blocks ahead of their MFMAs: the read latency (~100 cycles) has to fit in the
   // MFMA time of that distance - one K-block of three MFMAs (96 cycles), or three K-blocks of one
-  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : (G == 2 ? 2 : 3) * ASDF16_PREFETCH;
+  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : (G == 2 ? ASDF16_PF_G2 : 3) * ASDF16_PREFETCH;
   static_assert(PL == 2 ? G == 1 : (G == 1 || G == 2), "point groups");
   static_assert(kPieces == 4 || kPieces == 8, "stage size");
 };
@@ -188,10 +239,14 @@ typedef NoOp16 NoEpilogue16;
 // make the compiler treat an accumulator as freshly defined here: element reads behind this statement cannot be hoisted
 // in front of it (instruction selection otherwise copies a whole finished accumulator out of the AGPRs right behind its
 // last MFMA - an s_nop 11 plus the wait for that MFMA at every tile boundary)
-__device__ __forceinline__ void pin_acc(f32x16& acc) {
-#if ASDF16_PIN_ACC
-  asm volatile("" : "+a"(acc));
+// (One-plane kernel with two point groups: the pin does the opposite there - with it the register allocator copies every finished
+// layer-3 accumulator out of the AGPRs and back in, 64 moves and two s_nop 11 per tile; ASDF16_PIN_ACC_P1 = 0.)
+#ifndef ASDF16_PIN_ACC_P1
+#define ASDF16_PIN_ACC_P1 0
 #endif
+template <int PL = 2>
+__device__ __forceinline__ void pin_acc(f32x16& acc) {
+  if (PL == 2 ? ASDF16_PIN_ACC : ASDF16_PIN_ACC_P1) asm volatile("" : "+a"(acc));
 }
 
 // One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
@@ -201,6 +256,26 @@ template <int P>
 __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
   lds_dma16_off<(P & 3) * 1024>(src + (P >> 2) * 1024, dst + (P >> 2) * 4096);
 }
+
+// All four pieces of a wave's share of a 16 KiB stage behind ONE M0 set-up (one asm statement: M0 is saved and restored inside it)
+__device__ __forceinline__ void dma_burst4(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+#ifndef ASDF16_DMA_BURST
+#define ASDF16_DMA_BURST 0       // one-plane kernel (4 pieces per stage): 1 = all four in one sequence behind the barrier
+#endif
 
 // One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
@@ -217,7 +292,7 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
                                         h8 (&ah)[S16<PL, G>::kPrefetch], h8 (&al)[S16<PL, G>::kPrefetch], Pre&& pre, Epi&& epi) {
   constexpr int PF = S16<PL, G>::kPrefetch;
-  constexpr int BKB = ASDF16_BARRIER_KB;
+  constexpr int BKB = PL == 2 ? ASDF16_BARRIER_KB : ASDF16_BARRIER_KB_P1;
   constexpr int nslot = (SLOT + kRing - 1) % kRing;   // slot of stage (this - 1), refilled with stage (this + 3)
   using SG = S16<PL, G>;
   const float* src = next_src + wave * SG::kWaveFloats + lane * 4;
@@ -258,7 +333,9 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
       acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
 #endif
       const int m = (kb - BKB) * SG::kMfmas + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
-      if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
+      if (ASDF16_DMA_BURST && SG::kPieces == 4 && !(ABL & 1) && !(ABL & 32)) {
+        if (m == 0) { dma_burst4(src, dst); __builtin_amdgcn_sched_barrier(0); }
+      } else if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
         else if (m == 2) dma_piece<2>(src, dst);
@@ -420,6 +497,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       f32x16 acc1b[2], acc2b[2], acc3b[2];      // G == 2: the accumulators of the second point group
       float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
       float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
+      // one-plane kernel: all 16 of a tile's, read half a tile ahead (a K-block of 64 cycles is shorter than the LDS latency)
+      constexpr bool kW4Tile = ASDF16_W4_TILE && PL == 1 && !TWO_OUT;
+      constexpr int kPreKb = PL == 2 ? ASDF16_PRE_KB : ASDF16_PRE_KB_P1;
+      // layer 2 has ONE stage per tile: the preload of the next tile's bias row lands in the accumulator the deferred epilogue of
+      // the previous tile is still reading until its last part (K-block kEpiShift + kEpiChunks - 1)
+      static_assert(kS16Kb == 8 || kPreKb >= kEpiShift + kEpiChunks, "preload K-block inside the epilogue slots");
+      f32x16 w4t;
       // (the 8 K-step form of PointFeatSize 15 has no registers to spare for these: it reads its fragments at the point of use)
       constexpr bool kPreloadPf = KP <= 5;
       auto load_pf2 = [&](int t) {
@@ -538,13 +622,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          if (g != 1) pin_acc(acc1[(t - 1) & 1]);
-          if (G == 2 && g != 0) pin_acc(acc1b[(t - 1) & 1]);
+          if (g != 1) pin_acc<PL>(acc1[(t - 1) & 1]);
+          if (G == 2 && g != 0) pin_acc<PL>(acc1b[(t - 1) & 1]);
           split_part<PL, G>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
                             h1l[2 * (t - 1) + 1], amax1, c, g);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
-          if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
+          if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
           else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
@@ -585,19 +669,19 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
-            if (g != 1) pin_acc(acc2[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc(acc2b[(t - 1) & 1]);
+            if (g != 1) pin_acc<PL>(acc2[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(t - 1) & 1]);
             split_part<PL, G>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
                               h2l[2 * (t - 1) + 1], amax2, c, g);
           } else {
-            if (g != 1) pin_acc(acc1[(kTilesL1 - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc(acc1b[(kTilesL1 - 1) & 1]);
+            if (g != 1) pin_acc<PL>(acc1[(kTilesL1 - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL>(acc1b[(kTilesL1 - 1) & 1]);
             split_part<PL, G>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
                               h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, g);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
         };
         auto pre_last = [&](int c) {
-          if (!ASDF16_PRELOAD || c != ASDF16_PRE_KB) return;
+          if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesHidden) {
             acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
             if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
@@ -637,12 +721,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       auto dot_w4_part = [&](const f32x16& a, const f32x16& ab, int c, int g = -1) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
+          const float w = kW4Tile ? w4t[2 * c + r] : w4c[r];
           if (g != 1) {
             const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
-            part = fmaf(v, w4c[r], part);
+            part = fmaf(v, w, part);
             if (TWO_OUT) partb = fmaf(v, w4bc[r], partb);
           }
-          if (G == 2 && g != 0) partg = fmaf(__int_as_float(max(__float_as_int(ab[2 * c + r]), 0)), w4c[r], partg);
+          if (G == 2 && g != 0) partg = fmaf(__int_as_float(max(__float_as_int(ab[2 * c + r]), 0)), w, partg);
         }
         if (TWO_OUT) asm volatile("" : "+v"(part), "+v"(partb));
         if (G == 2) asm volatile("" : "+v"(part), "+v"(partg));
@@ -654,30 +739,31 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         if (!ASDF16_PRELOAD) acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
         auto pre = [&](int kb) {       // first stage: w4 of the next epilogue part
           const int c = kb - kEpiShift;
-          if (t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
+          if (!kW4Tile && t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
         };
         auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) {
-            if (g != 1) pin_acc(acc3[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc(acc3b[(t - 1) & 1]);
+            if (g != 1) pin_acc<PL>(acc3[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL>(acc3b[(t - 1) & 1]);
             dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, g);
-            if (g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
+            if (!kW4Tile && g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
           } else {
-            if (g != 1) pin_acc(acc2[(kTilesHidden - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc(acc2b[(kTilesHidden - 1) & 1]);
+            if (g != 1) pin_acc<PL>(acc2[(kTilesHidden - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(kTilesHidden - 1) & 1]);
             split_part<PL, G>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
                               h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, g);  // K-blocks 30, 31: end of this tile
           }
         };
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
-          if (c != ASDF16_PRE_KB) return;
+          if (c != kPreKb) return;
           if (ASDF16_PRELOAD && t + 1 < kTilesHidden) {
             acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
             if (G == 2) acc3b[(t + 1) & 1] = acc3[(t + 1) & 1];
           }
+          if (kW4Tile) { w4t = load_bias16(hc + CL::kW4 + (t * 2 + half) * 16); return; }
           load_w4(t, 0);
           next_w4();
         };
@@ -701,22 +787,28 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // the last tile's epilogue has no MFMA stream to hide under
 #pragma unroll
       for (int c = 0; c < kEpiChunks; ++c) {
-        if (c + 1 < kEpiChunks) load_w4(kTilesHidden - 1, c + 1);
+        if (!kW4Tile && c + 1 < kEpiChunks) load_w4(kTilesHidden - 1, c + 1);
         dot_w4_part(acc3[(kTilesHidden - 1) & 1], acc3b[(kTilesHidden - 1) & 1], c);
-        next_w4();
+        if (!kW4Tile) next_w4();
       }
 #undef ASDF_STAGE16
+      auto tanh_out = [&](float x) -> float {
+#if ASDF16_FAST_TANH
+        if (PL == 1) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+#endif
+        return tanhf(x);
+      };
       part += __shfl_xor(part, 32);
-      const float sdf = tanhf(part + hc[CL::kB4]);
+      const float sdf = tanh_out(part + hc[CL::kB4]);
       float sdfb = 1.0f;
       if (TWO_OUT) {
         partb += __shfl_xor(partb, 32);
-        sdfb = tanhf(partb + hc[CL::kB4 + 1]);
+        sdfb = tanh_out(partb + hc[CL::kB4 + 1]);
       }
       float sdfg = 0.0f;           // the second point group's output (G == 2)
       if (G == 2) {
         partg += __shfl_xor(partg, 32);
-        sdfg = tanhf(partg + hc[CL::kB4]);
+        sdfg = tanh_out(partg + hc[CL::kB4]);
       }
       const bool is_hand = head == 0;
       if (SUB) {
@@ -760,6 +852,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
+      amax = amax_value<PL>(amax); amax1 = amax_value<PL>(amax1); amax2 = amax_value<PL>(amax2);
       const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
       const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)) ||
                                             (G == 2 && !(fabsf(sdfg) <= 1.0f)))) ? 1 : 0;
@@ -773,6 +866,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         const long long pf_ = (G == 2 && half == 1) ? pib : pi;
         const int i2 = (int)(pf_ % p.N), i1 = (int)((pf_ / p.N) % p.N), i0 = (int)((pf_ / p.N) / p.N);
         auto fold = [&](bool neg, int* rec, int extra) {
+#if ASDF16_FOLD_BALLOT
+          if (PL == 1 && !__any(neg || extra != 0)) return;      // (wave-uniform: most tiles of a sweep hold no negative voxel)
+#endif
           int a0 = neg ? i0 : 0x7fffffff, a1 = neg ? i1 : 0x7fffffff, a2 = neg ? i2 : 0x7fffffff;
           int b0 = neg ? i0 : -1, b1 = neg ? i1 : -1, b2 = neg ? i2 : -1, n = neg ? 1 : 0;
 #pragma unroll

@@ -13,8 +13,13 @@ and records, per (tag, N, sample): the negative-voxel boxes and counts of pass 1
 /opt/conda/bin/python3.9 with the reference's call (utils/mesh.py:354) - V, F and coordinate / index checksums of both surfaces.
 -> tests/golden/ref_fullsize_r3_<tag>.npz, keys "<N>/s<sample>/<name>".
 
+Step 3 (`--signs`, from the pass-2 volumes step 1 parked in /tmp): the SIGN of every voxel of both pass-2 volumes (packed bits) and
+the list of voxels within 2e-6 of the level with their values - so that a test can compare every voxel's sign with the reference's
+and attribute each disagreement to a voxel whose sign is undefined at the 1e-5 bar.
+
 Usage:  python tests/golden/make_r3_goldens.py nerf3 [both9]          (~20 min of CPU per tag with 4 threads)
         /opt/conda/bin/python3.9 tests/golden/make_r3_goldens.py --mc nerf3 [both9]
+        python tests/golden/make_r3_goldens.py --signs nerf3 [both9]
 """
 import os
 import sys
@@ -81,6 +86,28 @@ def mc(tags):
         np.savez_compressed(out_path(tag), **gold)
 
 
+def signs(tags):
+    for tag in tags:
+        gold = dict(np.load(out_path(tag)))
+        for N, samples in PLAN:
+            for s in samples:
+                if "%d/s%d/bbox" % (N, s) not in gold:
+                    continue
+                for part in ("hand", "obj"):
+                    vol = np.load(TMP % (tag, N, s, part)).reshape(-1)
+                    gold["%d/s%d/sign_bits_%s" % (N, s, part)] = np.packbits(vol < 0)
+                    near = np.flatnonzero(np.abs(vol) < 2e-6)
+                    gold["%d/s%d/near_idx_%s" % (N, s, part)] = near.astype(np.int32)
+                    gold["%d/s%d/near_val_%s" % (N, s, part)] = vol[near]
+                    print(tag, N, "sample", s, part, "negative", int((vol < 0).sum()), "within 2e-6 of the level", len(near), flush=True)
+        np.savez_compressed(out_path(tag), **gold)
+
+
 if __name__ == "__main__":
     tags = [a for a in sys.argv[1:] if not a.startswith("-")] or ["nerf3", "both9"]
-    mc(tags) if "--mc" in sys.argv else decode(tags)
+    if "--mc" in sys.argv:
+        mc(tags)
+    elif "--signs" in sys.argv:
+        signs(tags)
+    else:
+        decode(tags)
