@@ -1,5 +1,6 @@
-// Marching Cubes 33 (Lewiner et al., JGT 8(2) 2003) case selection, shared by the HIP kernels
-// (mc33.hip) and the sequential CPU restatement (oracle/mc33_oracle.c).  Plain C99 / HIP.
+// Marching Cubes 33 (Lewiner et al., JGT 8(2) 2003) case selection of the HIP kernels (mc33.hip).  Device code only: the
+// sequential CPU restatement the tests check it against (oracle/mc33_oracle.c) shares nothing with this header - it has its
+// own deciders and its own copy of the published tables.
 //
 // Behaviour being reproduced: skimage 0.18.3 `marching_cubes_lewiner` - the third-party routine the
 // reference calls at utils/mesh.py:354 and deep_sdf/mesh.py:81 (its Cython source is not shipped with
@@ -14,11 +15,7 @@
 #pragma once
 #include <stdint.h>
 
-#ifdef __HIPCC__
 #define MC33_HD __device__ __forceinline__
-#else
-#define MC33_HD static inline
-#endif
 
 #include "mc33_tables.h"
 

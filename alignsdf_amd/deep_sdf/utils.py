@@ -1,14 +1,43 @@
 """deep_sdf.utils.decode_sdf counterpart (deep_sdf/utils.py:64-75)."""
 import torch
 
-from ..utils.utils import hip_decoder_for
+from ..utils.utils import decoder_for, hip_decoder_for
+
+
+def legacy_evaluator(decoder, latent_vector, query_width=3):
+    """The evaluator behind the legacy single-output contract `decoder(cat(latent, xyz)) -> [M, 1]` (`decoder(xyz)` when
+    latent_vector is None): the fused HIP kernels for SeparateDecoder / CombinedDecoder modules of the shape they are built for
+    (their hand head is the single output), the module itself on PyTorch-ROCm for anything else - any nn.Module, any width, with
+    or without a latent (alignsdf_amd.torch_decoder.TorchModuleDecoder with specs None)."""
+    from ..hip_decoder import HipSdfDecoder
+    from ..torch_decoder import TorchModuleDecoder, needs_module_path
+    if isinstance(decoder, (HipSdfDecoder, TorchModuleDecoder)):
+        return decoder
+    why = needs_module_path(decoder, None, None) if latent_vector is not None else "latent-free decoder (deep_sdf/utils.py:67-68)"
+    if why is None and (query_width != 3 or (decoder.point_feat_size != 3 and decoder.encode_style != "nerf")):
+        # the legacy interface hands the queries to the module as they are: features the caller has embedded already (or a
+        # pose-aligned module, which the xyz-only HIP binding cannot serve without its poses) go to the module
+        why = "queries of width %d for a decoder with PointFeatSize %d / EncodeStyle %s" % (query_width, decoder.point_feat_size, decoder.encode_style)
+    if why is None:
+        return hip_decoder_for(decoder)
+    return decoder_for_module(decoder, why)
+
+
+def decoder_for_module(decoder, why):
+    """Cached TorchModuleDecoder (legacy contract: specs None) of a module."""
+    from ..torch_decoder import TorchModuleDecoder
+    from ..utils.utils import _cache
+    dev = torch.device("cuda:%d" % torch.cuda.current_device())
+    per_mod = _cache.setdefault(decoder, {})
+    key = "legacy:%s" % dev
+    if key not in per_mod:
+        per_mod[key] = (None, TorchModuleDecoder(decoder, None, why, dev))
+    return per_mod[key][1]
 
 
 def decode_sdf(decoder, latent_vector, queries):
-    """Hand-head SDF [M,1] of normalised xyz queries through the HIP decoder (the legacy single-output API)."""
-    if latent_vector is None:
-        raise NotImplementedError("latent-free decoders are not SeparateDecoder-shaped")
-    hip = hip_decoder_for(decoder)
-    hip.set_sample(latent_vector)
-    h, _ = hip.decode_points(queries)
+    """SDF [M,1] of normalised xyz queries: the decoder's single output (the hand head of a two-head module)."""
+    ev = legacy_evaluator(decoder, latent_vector, int(queries.shape[1]))
+    ev.set_sample(latent_vector)
+    h, _ = ev.decode_points(queries)
     return h.unsqueeze(1)

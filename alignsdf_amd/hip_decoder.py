@@ -103,6 +103,49 @@ def kinematic_affine(point_feat_size, encode_style, scale_factor, mano_results, 
     return hand, np.concatenate([rows_hand[0]] + rows_obj_tail, 0)   # networks/model.py:297-299
 
 
+def unsupported_reason(state_dict, latent_size, point_feat_size, encode_style):
+    """Why (a string) the fused kernels cannot evaluate a decoder with these parameters, or None when they can.  The kernels are
+    built for the shape every shipped AlignSDF config uses (experiments/*/*.json: LatentSize 256, dims [512] * 4, latent_in [2] -
+    networks/model.py:192-282): five layers per MLP, 512-wide, the skip concatenation in front of layer 2; any other legal
+    NetworkSpecs runs on the module path (alignsdf_amd.torch_decoder).  `state_dict` maps parameter names (module.decoder. prefix
+    already stripped) to tensors / arrays; only shapes are looked at."""
+    shape = lambda k: tuple(state_dict[k].shape)
+    keys = set(state_dict)
+    if any(k.startswith("bn") for k in keys):
+        return "LayerNorm form (weight_norm false)"
+    combined = "lin0.bias" in keys
+    prefixes = ("lin",) if combined else ("linh", "lino")
+    if not combined and "linh0.bias" not in keys:
+        return "not a SeparateDecoder / CombinedDecoder shaped module"
+    if int(latent_size) != 256:
+        return "LatentSize %d (the kernels fold a 256-wide latent)" % int(latent_size)
+    if encode_style not in ("nerf", "hand", "obj", "both"):
+        return "EncodeStyle %r" % (encode_style,)
+    pf = (int(point_feat_size),) if combined else head_point_feats(int(point_feat_size), encode_style)
+    if encode_style == "nerf" and int(point_feat_size) > 3 and int(point_feat_size) not in (9, 15):
+        return "NeRF positional encoding with PointFeatSize %d (9 and 15 are built)" % int(point_feat_size)
+    n_out = 2 if combined else 1
+    for prefix, f in zip(prefixes, pf):
+        if not 1 <= f <= _native.MAX_POINT_FEATS or 512 - 256 - f < 1:
+            return "%d point features per head" % f
+        if (prefix + "5.bias") in keys or (prefix + "4.bias") not in keys:
+            return "not five layers per MLP (dims other than [512, 512, 512, 512])"
+        n_in = 256 + f
+        want = [(512, n_in), (512 - n_in, 512), (512, 512), (512, 512), (n_out, 512)]
+        for layer in range(5):
+            name = "%s%d" % (prefix, layer)
+            wkey = name + (".weight_v" if name + ".weight_v" in keys else ".weight")
+            if wkey not in keys or name + ".bias" not in keys:
+                return "layer %s missing" % name
+            if shape(wkey) != want[layer]:
+                return "layer %s is %s, the kernels need %s (dims [512] * 4, latent_in [2])" % (name, shape(wkey), want[layer])
+    if "classifier_head.weight" in keys:
+        cw = shape("classifier_head.weight")
+        if len(cw) != 2 or cw[1] != 512 or not 1 <= cw[0] <= _native.MAX_CLASSES:
+            return "classifier_head of shape %s" % (cw,)
+    return None
+
+
 class HipSdfDecoder:
     """Device-resident packed decoder.  One instance per (module, device)."""
 
@@ -118,11 +161,11 @@ class HipSdfDecoder:
         else:
             sd = {k: torch.as_tensor(v) for k, v in module_or_state_dict.items()}
         sd = {k[len("module.decoder."):] if k.startswith("module.decoder.") else k: v for k, v in sd.items()}
+        why = unsupported_reason(sd, latent_size if latent_size is not None else 256, point_feat_size, encode_style)
+        if why is not None:
+            raise NotImplementedError("the fused kernels do not cover this decoder: %s - utils.utils.decoder_for routes it to the "
+                                      "module path (alignsdf_amd.torch_decoder)" % why)
         self.combined = "lin0.bias" in sd and "lin4.bias" in sd
-        if not self.combined and ("linh0.bias" not in sd or "lino4.bias" not in sd):
-            raise NotImplementedError("HIP path supports SeparateDecoder (linh*/lino*) and CombinedDecoder (lin*) modules")
-        if any(k.startswith("bn") for k in sd):
-            raise NotImplementedError("the LayerNorm variant is outside the HIP path")
         self.latent_size = int(latent_size)
         self.point_feat_size = int(point_feat_size)
         self.encode_style = encode_style
@@ -177,6 +220,10 @@ class HipSdfDecoder:
         # ASDF_MATH overrides the default
         self.math = "f32"
         want = os.environ.get("ASDF_MATH", DEFAULT_MATH)
+        if want == "f16x3" and self.nerf_features and self.point_feat_size == 15 and not self.combined and "ASDF_MATH" not in os.environ:
+            # the 8-K-step split-half instantiation of PointFeatSize 15 (two MLPs) keeps 400 B per lane in scratch; the fp32 chain
+            # has room for it.  No shipped config uses this shape; ASDF_MATH=f16x3 still selects the split-half kernel.
+            want = "f32"
         if want == "f16x3":
             self.set_math("f16x3")
         elif want not in ("f32", "f16x3"):

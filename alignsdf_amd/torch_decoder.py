@@ -9,8 +9,10 @@ Variants served here: `use_tanh`, the LayerNorm form (`weight_norm` false), `xyz
 `PixelAlign` (utils/utils.py:536-566), and any module whose parameters are not SeparateDecoder / CombinedDecoder shaped.
 It is a GPU path like the rest of the package: CPU tensors raise.
 """
+import copy
 import ctypes
 import logging
+import weakref
 
 import numpy as np
 import torch
@@ -83,23 +85,36 @@ def needs_module_path(decoder, specs=None, mano_results=None):
             return "use_tanh"
         if getattr(decoder, "xyz_in_all", False):
             return "xyz_in_all"
-        keys = list(decoder.state_dict().keys())
-        if any(k.startswith("bn") for k in keys):
-            return "LayerNorm form (weight_norm false)"
-        if not any(k.startswith(("linh0.", "lin0.")) for k in keys):
+        # shapes: NetworkSpecs other than the shipped dims [512] * 4 / latent_in [2] / LatentSize 256 are legal
+        # (networks/model.py:192-282) and run on the module
+        from .hip_decoder import unsupported_reason
+        sd = decoder.state_dict()
+        if not hasattr(decoder, "point_feat_size") or not hasattr(decoder, "encode_style"):
             return "not a SeparateDecoder / CombinedDecoder shaped module"
+        why = unsupported_reason(sd, getattr(decoder, "latent_size", (specs or {}).get("LatentSize", 256)), decoder.point_feat_size,
+                                 decoder.encode_style)
+        if why is not None:
+            return why
     if specs is not None and specs["PointFeatSize"] > 3 and specs["EncodeStyle"] != "nerf" and mano_results is None:
         return "pose-aligned model without mano_results: NeRF branch of utils/mesh.py:53-55"
     return None
 
 
 class TorchModuleDecoder:
-    """The interface of HipSdfDecoder (set_sample / decode_grid / decode_points / classify_points) on a plain module call."""
+    """The interface of HipSdfDecoder (set_sample / decode_grid / decode_points / classify_points) on a plain module call.
+
+    The caller's module is neither moved nor switched: it is held through a weak reference, called in eval mode with its
+    training flag restored afterwards, and - when its parameters live on another device (the reference keeps checkpoints on the
+    CPU until `.cuda()`) - evaluated through a device COPY that is refreshed whenever a parameter tensor is replaced or written
+    (the reference reconstructs from inside its training loop, train.py:668).  `specs` None = the legacy single-output
+    contract of deep_sdf.utils.decode_sdf (deep_sdf/utils.py:64-75): `module(cat(latent, xyz))` or `module(xyz)` when there is
+    no latent, returning [M, 1] (the first element if the module returns a tuple)."""
 
     math = "torch"
     combined = False
     nerf_features = False
     event_log = None
+    coarse_mode = fine_mode = "exact"
 
     def __init__(self, module, specs, reason, device=None):
         if not isinstance(module, torch.nn.Module):
@@ -107,19 +122,40 @@ class TorchModuleDecoder:
         if not torch.cuda.is_available() or _native.lib().asdf_device_count() < 1:
             raise _native.NativeError(-4, "no gfx950 (MI355X) device visible - there is no CPU path")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        self.module = module.to(self.device).eval()
+        self._module_ref = weakref.ref(module)
+        self._copy = None            # (fingerprint, device copy) when the caller's parameters are not on self.device
         self.specs = specs
         self.reason = reason
         self.num_class = int(getattr(module, "num_class", 0)) if getattr(module, "use_classifier", False) else 0
         self._sample = None
         logging.warning("decoder runs on the PyTorch-ROCm module path (%s); the HIP kernels do not cover this variant", reason)
 
+    @property
+    def module(self):
+        """The module to call: the caller's own when it lives on this device, otherwise an up-to-date device copy."""
+        m = self._module_ref()
+        if m is None:
+            raise ReferenceError("the decoder module has been garbage-collected")
+        params = list(m.parameters())
+        if not params or all(p.device == self.device for p in params):
+            return m
+        fp = tuple((p.data_ptr(), p._version) for p in params)
+        if self._copy is None or self._copy[0] != fp:
+            # old-style weight_norm leaves the effective weight of its last forward on the module as a NON-leaf tensor, which
+            # deepcopy refuses; the forward pre-hook recomputes it on every call, so a detached stand-in loses nothing
+            for sub in m.modules():
+                for name, val in list(vars(sub).items()):
+                    if torch.is_tensor(val) and not val.is_leaf:
+                        vars(sub)[name] = val.detach()
+            self._copy = (fp, copy.deepcopy(m).to(self.device).eval())
+        return self._copy[1]
+
     def set_sample(self, latent_vec, mano_results=None, obj_results=None, cam_intr=None):
         dev = lambda d: None if d is None else {k: v.to(self.device) for k, v in d.items()}
-        self._sample = (latent_vec.detach().to(self.device, torch.float32), dev(mano_results), dev(obj_results),
-                        None if cam_intr is None else cam_intr.to(self.device))
+        self._sample = (None if latent_vec is None else latent_vec.detach().to(self.device, torch.float32), dev(mano_results),
+                        dev(obj_results), None if cam_intr is None else cam_intr.to(self.device))
 
-    def fall_back_if_overflowed(self, bbox_host):
+    def fall_back_if_overflowed(self, bbox_host, epoch=None):
         return False
 
     def range_violations(self, clear=True):
@@ -127,11 +163,16 @@ class TorchModuleDecoder:
 
     def close(self):
         self._sample = None
+        self._copy = None
 
-    # -- the reference's chunk loop body (utils/mesh.py:47-56 + utils/utils.py:561-572) -------------------------------------
-    def _decode_chunk(self, xyz):
+    # -- the reference's chunk loop body (utils/mesh.py:47-56 + utils/utils.py:561-572; deep_sdf/utils.py:64-75 without specs) ---
+    def _decode_chunk(self, module, xyz):
         latent, mano, obj, cam = self._sample
         specs = self.specs
+        if specs is None:
+            out = module(xyz if latent is None else torch.cat([latent.reshape(1, -1).expand(xyz.shape[0], -1), xyz], 1))
+            return (out[0], out[1] if len(out) > 1 and torch.is_tensor(out[1]) and out[1].dim() == 2 else None, None) \
+                if isinstance(out, (tuple, list)) else (out, None, None)
         q = xyz
         if specs["PointFeatSize"] > 3:
             if mano is not None and specs["EncodeStyle"] != "nerf":
@@ -142,20 +183,33 @@ class TorchModuleDecoder:
             lat = pixel_alignment(latent, q[:, :3], cam, mano, specs["ImageSize"][0], specs["SdfScaleFactor"])
         else:
             lat = latent.reshape(1, -1).expand(q.shape[0], -1)
-        return self.module(torch.cat([lat, q], 1))
+        return module(torch.cat([lat, q], 1))
 
     def _decode(self, xyz, want_scores=False):
+        if self._sample is None:
+            raise ValueError("no sample bound: call set_sample first")
         M = xyz.shape[0]
         hand = torch.empty(M, dtype=torch.float32, device=self.device)
         obj = torch.empty(M, dtype=torch.float32, device=self.device)
+        has_obj = True
         scores = torch.empty((M, self.num_class), dtype=torch.float32, device=self.device) if want_scores else None
-        with torch.no_grad():
-            for head in range(0, M, CHUNK):
-                h, o, c = self._decode_chunk(xyz[head:head + CHUNK])
-                hand[head:head + CHUNK], obj[head:head + CHUNK] = h.squeeze(1), o.squeeze(1)
-                if want_scores:
-                    scores[head:head + CHUNK] = c
-        return hand, obj, scores
+        module = self.module
+        was_training = module.training
+        module.eval()
+        try:
+            with torch.no_grad():
+                for head in range(0, M, CHUNK):
+                    h, o, c = self._decode_chunk(module, xyz[head:head + CHUNK])
+                    hand[head:head + CHUNK] = h.reshape(-1)
+                    if o is None:
+                        has_obj = False
+                    else:
+                        obj[head:head + CHUNK] = o.reshape(-1)
+                    if want_scores:
+                        scores[head:head + CHUNK] = c
+        finally:
+            module.train(was_training)
+        return hand, (obj if has_obj else None), scores
 
     def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
         """The coarse pass of the two-pass flow (same interface as HipSdfDecoder.coarse_begin; always an ordinary sweep)."""
@@ -194,7 +248,9 @@ class TorchModuleDecoder:
             _native.check(L.asdf_debug_grid_coords(int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode), 0, N ** 3,
                                                    coords.data_ptr(), stream), "asdf_debug_grid_coords")
             vh, vo, _ = self._decode(coords)
-            vh, vo = vh.reshape(N, N, N), vo.reshape(N, N, N)
+            vh = vh.reshape(N, N, N)
+            vo = vo.reshape(N, N, N) if vo is not None else None
+            obj = obj and vo is not None
             bbox = None
             if want_bbox:
                 bbox = torch.empty(16, dtype=torch.int32, device=self.device)

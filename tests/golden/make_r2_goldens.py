@@ -162,7 +162,7 @@ def variant_state(name, syn, torch):
     return specs, cls, sd, t(mano), t(obj), None if cam is None else torch.from_numpy(cam), torch.from_numpy(latent)
 
 
-VARIANTS = ("tanh", "layernorm", "xyzall", "nomano", "pixelalign")
+VARIANTS = ("tanh", "layernorm", "xyzall", "nomano", "pixelalign", "narrow")     # (narrow: round 3)
 
 
 def variants(ref):
@@ -171,7 +171,7 @@ def variants(ref):
     arch, um, uu, _ = ref
     for name in [v for v in VARIANTS if not os.environ.get("ASDF_ONLY_VARIANT") or v == os.environ["ASDF_ONLY_VARIANT"]]:
         specs, cls, sd, mano, obj, cam, latent = variant_state(name, syn, torch)
-        dec = getattr(arch, cls)(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
+        dec = getattr(arch, cls)(specs["LatentSize"], specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
         dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         g, _ = two_pass(um, dec, latent, mano, obj, specs, 32, cam=cam, keep_full=True)
         g.update(random_points(uu, dec, latent, mano, obj, specs, syn, torch, cam=cam))

@@ -105,9 +105,39 @@ def signs(tags):
 
 if __name__ == "__main__":
     tags = [a for a in sys.argv[1:] if not a.startswith("-")] or ["nerf3", "both9"]
-    if "--mc" in sys.argv:
+    if "--legacy-free" in sys.argv:
+        pass                                   # handled at the end of the file
+    elif "--mc" in sys.argv:
         mc(tags)
     elif "--signs" in sys.argv:
         signs(tags)
     else:
         decode(tags)
+
+
+def legacy_free():
+    """The legacy entry points on a latent-FREE single-output module (deep_sdf/utils.py:64-75 with latent_vector None,
+    deep_sdf/mesh.py:14-61): the reference's create_mesh volume at N = 32 and its decode_sdf on 4096 random points
+    -> ref_legacy_free.npz.      python tests/golden/make_r3_goldens.py --legacy-free"""
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from alignsdf_amd import synthetic as syn
+    import make_ref_goldens as mrg
+    _, _, _, dm = mrg.import_reference()
+    import deep_sdf.utils as du
+    net = syn.latent_free_module()
+    cap = []
+    dm.convert_sdf_samples_to_ply = lambda vol, origin, vs, path: cap.append((vol.numpy().copy(), origin, vs))
+    pts = torch.from_numpy(syn.uniform((4096, 3), 778, -1.0, 1.0).astype(np.float32))
+    with torch.no_grad():
+        dm.create_mesh(net, None, "/tmp/z", N=32, max_batch=32 ** 3)
+        rand = du.decode_sdf(net, None, pts)
+    vol = cap[0][0]
+    print("latent-free volume range", vol.min(), vol.max(), "negative voxels", int((vol < 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "ref_legacy_free.npz"), vol_32=vol, origin=np.array(cap[0][1], dtype=np.float64),
+                        voxel_size=np.array([cap[0][2]]), rand_pts=pts.numpy(), rand_sdf=rand.squeeze(1).numpy())
+
+
+if "--legacy-free" in sys.argv and __name__ == "__main__":
+    legacy_free()

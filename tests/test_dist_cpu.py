@@ -61,3 +61,88 @@ def test_gather_over_gloo(world, n, tmp_path):
         assert m["rank"] == start_rank
         assert (m["V_hand"], m["F_hand"], m["V_obj"], m["F_obj"]) == (10 * i + 1, 20 * i + 2, 3 * i, 4 * i)
         assert m["milliseconds"] == 0.5 * i + start_rank
+
+
+# ---- round 3: the host side of an 8-rank node -------------------------------------------------------------------------------
+
+def test_host_thread_share():
+    """Each rank caps its intra-op pools at its share of the PHYSICAL cores (eight ranks x one thread per logical CPU is how a
+    128-core box ends up running 2048 threads)."""
+    import torch
+    from alignsdf_amd.dist_reconstruct import limit_host_threads, physical_cores
+    before = torch.get_num_threads()
+    try:
+        cores = physical_cores()
+        assert 1 <= cores <= (os.cpu_count() or 1)
+        for world in (1, 2, 8, 1024):
+            n = limit_host_threads(world)
+            assert n == max(1, cores // world) == torch.get_num_threads() and os.environ["OMP_NUM_THREADS"] == str(n)
+        os.environ["ASDF_HOST_THREADS"] = "3"
+        assert limit_host_threads(8) == 3
+    finally:
+        os.environ.pop("ASDF_HOST_THREADS", None)
+        torch.set_num_threads(before)
+        for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+            os.environ.pop(var, None)
+
+
+HOST_TAIL_WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from alignsdf_amd.dist_reconstruct import run_sharded
+per_rank = int(sys.argv[1])
+world = int(os.environ.get("WORLD_SIZE", "1"))
+def host_tail(i):
+    # the shape of one sample's host work: area-weighted surface sampling in numpy, a dense solve and a few GEMMs in torch
+    rng = np.random.default_rng(i)
+    tri = rng.random((60000, 3, 3))
+    area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    pick = np.searchsorted(np.cumsum(area), rng.random(30000) * area.sum())
+    a = torch.from_numpy(tri[pick %% len(tri)].reshape(-1, 9)[:, :8]).float()
+    m = a.t() @ a
+    for _ in range(40):
+        m = torch.tanh(m @ m * 1e-3)
+    return float(m.sum())
+def process(start, end, rank):
+    host_tail(10 ** 6)                              # warm up the pools
+    t0 = time.perf_counter()
+    for i in range(start, end):
+        host_tail(i)
+    dt = time.perf_counter() - t0
+    return [dict(index=i, V_hand=torch.get_num_threads(), F_hand=rank, V_obj=0, F_obj=0, milliseconds=1e3 * dt) for i in range(start, end)]
+merged = run_sharded(per_rank * world, process, backend="gloo")
+if merged is not None:
+    json.dump(merged, open(sys.argv[2], "w"))
+"""
+
+
+def test_eight_ranks_do_not_oversubscribe_the_host(tmp_path):
+    """dist_reconstruct's driver with 8 gloo ranks, each running a synthetic host tail per sample: with the per-rank thread share
+    the slowest rank takes at most 1.5 x what ONE rank takes for the same number of samples on the same share (8 ranks with a full
+    thread pool each run several times slower on this work - measured 9 x on an 8-core container)."""
+    import torch
+    from alignsdf_amd.dist_reconstruct import physical_cores
+    if physical_cores() < 8:
+        pytest.skip("needs 8 cores")
+    script = tmp_path / "worker.py"
+    script.write_text(HOST_TAIL_WORKER % {"root": ROOT})
+    per_rank = 6
+    share = max(1, physical_cores() // 8)
+
+    def run(world, extra_env):
+        out = tmp_path / ("merged_%d.json" % world)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(script), str(per_rank), str(out)]
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "ASDF_HOST_THREADS")}
+        env.update(extra_env)
+        subprocess.run(cmd, check=True, timeout=600, env=env, cwd=ROOT)
+        merged = json.load(open(out))
+        assert len(merged) == per_rank * world
+        return max(m["milliseconds"] for m in merged), {m["V_hand"] for m in merged}
+
+    single, threads1 = run(1, {"ASDF_HOST_THREADS": str(share)})       # one rank on the share a rank of eight gets
+    eight, threads8 = run(8, {})
+    assert threads1 == {share} and threads8 == {share}                 # run_sharded set every rank's pool to its share
+    print("host tail: 1 rank %.0f ms, slowest of 8 ranks %.0f ms" % (single, eight))
+    assert eight <= 1.5 * single + 50.0, (single, eight)

@@ -100,3 +100,26 @@ def test_evaluation_summary_marks_uncomputed_metrics(tmp_path):
     path = write_summary(str(tmp_path), "obman", [("x", 1.5, float("nan"), float("nan"))], 2)
     text = open(path).read()
     assert "mean joints error:nan" in text and "mean verts error:nan" in text and "failure count:1" in text
+
+
+@pytest.mark.gpu
+def test_rccl_backend_executes_the_collectives_of_the_path():
+    """backend "nccl" (RCCL) with world size 1 on the box's GPU: the rank count, the MAX of the elapsed time, the barrier and
+    gather_records - so that the RCCL code path of dist_reconstruct / bench.py has run on an MI355X, not only over gloo."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_rank_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_ok"] and line["backend"] == "nccl" and line["n_ranks"] == 1 and line["max_elapsed"] == 1.25
+    assert [m["index"] for m in line["merged"]] == [1, 3] and line["merged"][1]["icp_skipped"] == 1 and line["empty"] == []

@@ -12,13 +12,13 @@ from alignsdf_amd import synthetic as syn
 def _module(name):
     from alignsdf_amd.networks import model as arch
     specs, cls, sd, mano, obj, cam, latent = syn.variant_config(name)
-    dec = getattr(arch, cls)(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"]).eval()
+    dec = getattr(arch, cls)(specs["LatentSize"], specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"]).eval()
     dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     t = lambda d: None if d is None else {k: torch.from_numpy(v) for k, v in d.items()}
     return specs, dec, t(mano), t(obj), None if cam is None else torch.from_numpy(cam), torch.from_numpy(latent)
 
 
-@pytest.mark.parametrize("name", ["tanh", "layernorm", "xyzall"])
+@pytest.mark.parametrize("name", ["tanh", "layernorm", "xyzall", "narrow"])
 def test_module_containers_reproduce_the_reference_modules_cpu(name, golden_dir):
     g = np.load("%s/ref_variant_%s.npz" % (golden_dir, name))
     specs, dec, _, _, _, latent = _module(name)
@@ -31,7 +31,8 @@ def test_module_containers_reproduce_the_reference_modules_cpu(name, golden_dir)
 def test_which_decoders_take_the_module_path():
     from alignsdf_amd.networks.model import build_decoder
     from alignsdf_amd.torch_decoder import needs_module_path
-    for name, word in (("tanh", "use_tanh"), ("layernorm", "LayerNorm"), ("xyzall", "xyz_in_all"), ("pixelalign", "PixelAlign")):
+    for name, word in (("tanh", "use_tanh"), ("layernorm", "LayerNorm"), ("xyzall", "xyz_in_all"), ("pixelalign", "PixelAlign"),
+                       ("narrow", "LatentSize 128")):
         specs, dec, mano, *_ = _module(name)
         assert word in needs_module_path(dec, specs, mano)
     specs, dec, mano, *_ = _module("nomano")
@@ -119,3 +120,100 @@ def test_encoder_in_the_sample_pipeline(monkeypatch):
     for (_, ra), (_, rb) in zip(a, b):        # (the convolutions need not be bit-reproducible from call to call)
         assert (ra["vol_hand"] - rb["vol_hand"]).abs().max().item() <= 1e-5 and abs(ra["F_obj"] - rb["F_obj"]) <= 16
     dec.close()
+
+
+# ---- round 3: decoder generality --------------------------------------------------------------------------
+
+def test_shape_routing_of_legal_network_specs():
+    """NetworkSpecs other than dims [512] * 4 / latent_in [2] / LatentSize 256 are legal (networks/model.py:192-282): they must be
+    ROUTED to the module path, not refused with ASDF_EINVAL."""
+    from alignsdf_amd.hip_decoder import unsupported_reason
+    from alignsdf_amd.networks.model import CombinedDecoder, SeparateDecoder
+    from alignsdf_amd.torch_decoder import needs_module_path
+    wn = dict(weight_norm=True)
+    cases = [
+        (SeparateDecoder(128, 3, "nerf", [256] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], **wn), "LatentSize 128"),
+        (SeparateDecoder(256, 3, "nerf", [512] * 3, latent_in=[2], norm_layers=[0, 1, 2], **wn), "five layers"),
+        (SeparateDecoder(256, 3, "nerf", [512] * 5, latent_in=[2], norm_layers=[0, 1, 2, 3, 4], **wn), "five layers"),
+        (SeparateDecoder(256, 3, "nerf", [512] * 4, latent_in=[1], norm_layers=[0, 1, 2, 3], **wn), "linh0"),
+        (SeparateDecoder(256, 3, "nerf", [512, 768, 512, 512], latent_in=[2], norm_layers=[0, 1, 2, 3], **wn), "linh1"),
+        (SeparateDecoder(256, 3, "nerf", [512] * 4, latent_in=[], norm_layers=[0, 1, 2, 3], **wn), "linh1"),
+        (SeparateDecoder(256, 21, "nerf", [512] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], **wn), "PointFeatSize 21"),
+        (CombinedDecoder(256, 3, "nerf", [384] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], **wn), "lin0"),
+        (torch.nn.Linear(259, 1), "not a SeparateDecoder"),
+    ]
+    for dec, word in cases:
+        why = needs_module_path(dec, None, None)
+        assert why is not None and word in why, (word, why)
+    ok = SeparateDecoder(256, 3, "nerf", [512] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], **wn)
+    assert needs_module_path(ok, None, None) is None
+    assert unsupported_reason(ok.state_dict(), 256, 3, "nerf") is None
+    with pytest.raises(NotImplementedError, match="module path"):
+        from alignsdf_amd.hip_decoder import HipSdfDecoder
+        HipSdfDecoder(cases[0][0].state_dict(), 128, 3, "nerf")          # (raised before any device is touched)
+
+
+def test_latent_free_module_matches_the_reference_cpu(golden_dir):
+    """The fixture's network is what the reference evaluated (same parameters, same outputs on the CPU)."""
+    g = np.load(golden_dir + "/ref_legacy_free.npz")
+    net = syn.latent_free_module()
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["rand_pts"]))
+    assert np.abs(out[:, 0].numpy() - g["rand_sdf"]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_legacy_entry_points_take_any_single_output_module(golden_dir, tmp_path):
+    """deep_sdf.utils.decode_sdf / deep_sdf.mesh.create_mesh with latent_vector None and a plain nn.Module
+    (deep_sdf/utils.py:64-75, deep_sdf/mesh.py:14-61): values within 1e-5 of the reference's run, the mesh written."""
+    from alignsdf_amd.deep_sdf import mesh as legacy
+    from alignsdf_amd.deep_sdf.utils import decode_sdf
+    from alignsdf_amd.marching_cubes import marching_cubes_lewiner
+    g = np.load(golden_dir + "/ref_legacy_free.npz")
+    net = syn.latent_free_module()                       # CPU module: evaluated through a device copy, left where it is
+    sdf = decode_sdf(net, None, torch.from_numpy(g["rand_pts"]).cuda())
+    assert sdf.shape == (4096, 1) and np.abs(sdf[:, 0].cpu().numpy() - g["rand_sdf"]).max() <= 1e-5
+    assert next(net.parameters()).device.type == "cpu" and not net.training
+    seen = {}
+    real = legacy.convert_sdf_samples_to_ply
+    legacy.convert_sdf_samples_to_ply = lambda vol, origin, vs, path: seen.setdefault("vol", vol.cpu().numpy()) is None or real(vol, origin, vs, path)
+    try:
+        pts, faces = legacy.create_mesh(net, None, str(tmp_path / "free"), N=32)
+    finally:
+        legacy.convert_sdf_samples_to_ply = real
+    assert np.abs(seen["vol"] - g["vol_32"]).max() <= 1e-5
+    v, f = marching_cubes_lewiner(torch.from_numpy(g["vol_32"]).cuda(), 0.0, spacing=[float(g["voxel_size"][0])] * 3)
+    assert abs(len(faces) - len(f)) <= 8 and (tmp_path / "free.ply").exists()
+    # a module in TRAINING mode comes back in training mode, and a latent-carrying generic module works the same way
+    net.train()
+    decode_sdf(net, None, torch.from_numpy(g["rand_pts"][:64]).cuda())
+    assert net.training
+    wide = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1)).eval()
+    lat = torch.randn(1, 4)
+    q = torch.from_numpy(g["rand_pts"][:100])
+    with torch.no_grad():
+        want = wide(torch.cat([lat.expand(100, -1), q], 1))
+    got = decode_sdf(wide, lat.cuda(), q.cuda())
+    assert np.abs(got.cpu().numpy() - want.numpy()).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_module_path_does_not_keep_or_move_the_callers_module():
+    """the module path must not move the caller's module to the GPU or pin it (and its device copy) forever."""
+    import gc
+    import weakref
+    from alignsdf_amd.utils.utils import decoder_for
+    specs, dec, mano, obj, cam, latent = _module("tanh")
+    dec.train()
+    ev = decoder_for(dec, specs, mano)
+    ev.set_sample(latent.cuda())
+    ev.decode_points(torch.zeros(8, 3).cuda())
+    assert dec.training and all(p.device.type == "cpu" for p in dec.parameters())
+    first = ev.module
+    with torch.no_grad():
+        dec.linh0.bias.add_(1.0)                  # an optimiser step: the device copy must follow
+    assert ev.module is not first
+    ref = weakref.ref(dec)
+    del dec, first
+    gc.collect()
+    assert ref() is None                          # nothing holds the module but the caller
