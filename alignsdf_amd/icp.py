@@ -16,18 +16,67 @@ from . import _native, synthetic
 
 
 def load_obj(path):
-    """Minimal Wavefront OBJ reader: (verts float64 [V,3], faces int64 [F,3]); polygons are fan-triangulated."""
-    verts, faces = [], []
+    """Minimal Wavefront OBJ reader: (verts float64 [V,3], faces int64 [F,3]); polygons are fan-triangulated.
+    Vertex lines are parsed in one numpy call, triangle faces too when every face line is a plain or slashed triple (what mesh
+    exporters write); anything else takes the line-by-line path.  ~10 x the speed of the loop on a 10 k-face mesh."""
     with open(path, "r") as f:
-        for line in f:
-            if line.startswith("v "):
-                verts.append([float(x) for x in line.split()[1:4]])
-            elif line.startswith("f "):
-                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
-                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
-                for k in range(1, len(idx) - 1):
-                    faces.append([idx[0], idx[k], idx[k + 1]])
+        lines = f.read().split("\n")
+    vlines = [ln for ln in lines if ln.startswith("v ")]
+    flines = [ln for ln in lines if ln.startswith("f ")]
+    verts = None
+    if vlines:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")        # (np.fromstring's text mode is deprecated, and still the fastest parser here)
+            flat = np.fromstring(" ".join(ln[2:] for ln in vlines), dtype=np.float64, sep=" ")
+        if flat.size % len(vlines) == 0 and flat.size // len(vlines) >= 3:
+            verts = flat.reshape(len(vlines), -1)[:, :3]
+    if verts is None:
+        verts = np.asarray([[float(x) for x in ln.split()[1:4]] for ln in vlines], dtype=np.float64).reshape(-1, 3)
+    faces = None
+    if flines:
+        text = " ".join(ln[2:] for ln in flines)
+        if "/" in text:                                        # v/vt/vn forms: keep the vertex index of every corner
+            import re
+            text = re.sub(r"/[^ ]*", "", text)
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                idx = np.fromstring(text, dtype=np.int64, sep=" ")
+            if idx.size == 3 * len(flines):                    # every face a triangle
+                idx = idx.reshape(-1, 3)
+                faces = np.where(idx > 0, idx - 1, len(verts) + idx)
+        except ValueError:
+            faces = None
+    if faces is None:
+        out = []
+        for ln in flines:
+            idx = [int(tok.split("/")[0]) for tok in ln.split()[1:]]
+            idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+            for k in range(1, len(idx) - 1):
+                out.append([idx[0], idx[k], idx[k + 1]])
+        faces = np.asarray(out, dtype=np.int64)
     return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+# The sampler picks faces by cumulative area.  A cumulative sum of floating-point areas depends on the order of the additions - a
+# sequential numpy cumsum and a parallel scan on the device round differently and would, rarely, pick different faces.  So the
+# areas are QUANTISED first: q = rint(area / max(area) * 2^31), an exact function of each area and of the (order-independent)
+# maximum; integer sums are exact in any order, and a draw u selects the first face whose cumulative q exceeds floor(u * total).
+# Host (numpy) and device (torch) then produce the same picks bit for bit (tests/test_gpu_icp.py), the distribution is
+# area-weighted to 2^-31 of the largest face, and the sampler stays what it stands in for: trimesh.sample.sample_surface,
+# which the reference calls UNSEEDED (utils/mesh.py:336).
+_AREA_QUANTUM = 2147483648.0
+
+
+def _uniforms(count, seed):
+    """The draws of one sampling call: u for the face pick [count], (r1, r2) barycentric pair [count, 2] (reflected)."""
+    u = synthetic.uniform((count,), 9100 + seed)
+    r = synthetic.uniform((count, 2), 9200 + seed)
+    flip = r.sum(1) > 1.0
+    r[flip] = np.abs(r[flip] - 1.0)
+    return u, r
 
 
 def sample_surface(verts, faces, count, seed=0):
@@ -36,8 +85,7 @@ def sample_surface(verts, faces, count, seed=0):
     v = np.asarray(verts, dtype=np.float64)
     f = np.asarray(faces, dtype=np.int64)
     # areas of all faces (190 k per hand surface at N = 256) on column vectors: the same products, differences and sums as
-    # 0.5 * norm(cross(b - a, c - a)) - bit for bit - at a third of the time of the [F, 3] gathers + np.cross (this runs on
-    # the host between two decoder passes of the sample pipeline)
+    # 0.5 * norm(cross(b - a, c - a)) at a third of the time of the [F, 3] gathers + np.cross
     vx, vy, vz = np.ascontiguousarray(v[:, 0]), np.ascontiguousarray(v[:, 1]), np.ascontiguousarray(v[:, 2])
     i0, i1, i2 = f[:, 0], f[:, 1], f[:, 2]
     ax, ay, az = vx[i0], vy[i0], vz[i0]
@@ -45,13 +93,49 @@ def sample_surface(verts, faces, count, seed=0):
     e2x, e2y, e2z = vx[i2] - ax, vy[i2] - ay, vz[i2] - az
     cx, cy, cz = e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x
     area = 0.5 * np.sqrt(cx * cx + cy * cy + cz * cz)
-    cum = np.cumsum(area)
-    pick = np.searchsorted(cum, synthetic.uniform((count,), 9100 + seed) * cum[-1])
-    pick = np.minimum(pick, len(f) - 1)
-    r = synthetic.uniform((count, 2), 9200 + seed)
-    flip = r.sum(1) > 1.0
-    r[flip] = np.abs(r[flip] - 1.0)
+    q = np.rint(area / area.max() * _AREA_QUANTUM).astype(np.int64)
+    cum = np.cumsum(q)
+    u, r = _uniforms(count, seed)
+    target = np.floor(u * float(cum[-1])).astype(np.int64)
+    pick = np.minimum(np.searchsorted(cum, target, side="right"), len(f) - 1)
     a, b, c = v[f[pick, 0]], v[f[pick, 1]], v[f[pick, 2]]          # only the picked faces
+    return a + (b - a) * r[:, :1] + (c - a) * r[:, 1:]
+
+
+_uniform_cache = {}
+
+
+def sample_surface_device(verts_d, faces_d, count, seed=0, num_faces_dev=None):
+    """sample_surface on the device, bit for bit: verts_d [V,3] (any float dtype, converted to fp64 exactly), faces_d [F,3] integer
+    device tensors -> [count,3] fp64 device tensor.  `num_faces_dev` (optional 0-dim / 1-element device tensor): only the first
+    that many rows of faces_d are faces - the others get area zero and can never be picked - so a mesh whose size is known only on
+    the device (the largest-component filter's output) is sampled without a host synchronisation.  Elementwise fp64 products and
+    sums in the host sampler's order (torch does not contract them), integer cumulative sums: same picks, same points."""
+    dev = verts_d.device
+    v = verts_d.to(torch.float64)
+    f = faces_d.to(torch.int64)
+    vx, vy, vz = v[:, 0].contiguous(), v[:, 1].contiguous(), v[:, 2].contiguous()
+    i0, i1, i2 = f[:, 0], f[:, 1], f[:, 2]
+    if num_faces_dev is not None:
+        live = torch.arange(f.shape[0], device=dev) < num_faces_dev.reshape(-1)[0].to(torch.int64)
+        i0, i1, i2 = torch.where(live, i0, 0), torch.where(live, i1, 0), torch.where(live, i2, 0)      # (padding rows: a degenerate face)
+    ax, ay, az = vx[i0], vy[i0], vz[i0]
+    e1x, e1y, e1z = vx[i1] - ax, vy[i1] - ay, vz[i1] - az
+    e2x, e2y, e2z = vx[i2] - ax, vy[i2] - ay, vz[i2] - az
+    cx, cy, cz = e1y * e2z - e1z * e2y, e1z * e2x - e1x * e2z, e1x * e2y - e1y * e2x
+    area = 0.5 * torch.sqrt(cx * cx + cy * cy + cz * cz)
+    q = torch.round(area / area.max() * _AREA_QUANTUM).to(torch.int64)       # torch.round = rint (half to even)
+    cum = torch.cumsum(q, 0)
+    key = (count, seed, str(dev))
+    if key not in _uniform_cache:
+        u, r = _uniforms(count, seed)
+        _uniform_cache[key] = (torch.from_numpy(u).to(dev), torch.from_numpy(r).to(dev))
+    u, r = _uniform_cache[key]
+    target = torch.floor(u * cum[-1].to(torch.float64)).to(torch.int64)
+    pick = torch.clamp(torch.searchsorted(cum, target, right=True), max=f.shape[0] - 1)
+    a = torch.stack([vx[i0[pick]], vy[i0[pick]], vz[i0[pick]]], 1)
+    b = torch.stack([vx[i1[pick]], vy[i1[pick]], vz[i1[pick]]], 1)
+    c = torch.stack([vx[i2[pick]], vy[i2[pick]], vz[i2[pick]]], 1)
     return a + (b - a) * r[:, :1] + (c - a) * r[:, 1:]
 
 
@@ -123,11 +207,47 @@ def start_icp(points_source, points_target, max_iter=100, device="cuda", stop_er
     return job
 
 
+def start_icp_device(points_source_dev, points_target_dev, max_iter=100, stop_error=1e-3, stop_improvement=1e-5):
+    """start_icp for sample sets that are ALREADY on the device (sample_surface_device): the normalisation of
+    ICP_T_S.sample_mesh (icp_trans_scale.py:25-31) runs there too (fp64 reductions; the sums are associated differently from
+    numpy's, a 1e-16-class difference in the statistics), its four statistics travel to pinned host memory behind the run, and
+    nothing here waits for the device.  Both inputs [n,3] fp64 on the same device."""
+    ps, pt = points_source_dev, points_target_dev
+    dev = ps.device
+    offset_s = ps.mean(0)
+    scale_s = torch.sqrt(((ps - offset_s) ** 2).sum() / ps.shape[0])
+    offset_t = pt.mean(0)
+    scale_t = torch.sqrt(((pt - offset_t) ** 2).sum() / pt.shape[0])
+    job = IcpJob()
+    job.device = dev
+    job.stream = torch.cuda.current_stream(dev)
+    job.src = ((ps - offset_s) / scale_s * scale_t + offset_t).contiguous()
+    job.tgt = pt.contiguous()
+    job.host = [torch.zeros(8, dtype=torch.float64).pin_memory()]
+    job.host[0].copy_(torch.cat([offset_s, scale_s.reshape(1), offset_t, scale_t.reshape(1)]), non_blocking=True)
+    job.norm = None                   # read from job.host[0] once the run is done (finish_icp)
+    L = _native.lib()
+    nbytes = ctypes.c_size_t()
+    _native.check(L.asdf_icp_workspace_bytes(job.src.shape[0], job.tgt.shape[0], ctypes.byref(nbytes)), "asdf_icp_workspace_bytes")
+    job.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    job.result = torch.zeros(8, dtype=torch.float64).pin_memory()
+    with torch.cuda.device(dev):
+        _native.check(L.asdf_icp_ts_enqueue(job.src.data_ptr(), job.src.shape[0], job.tgt.data_ptr(), job.tgt.shape[0], int(max_iter),
+                                            float(stop_error), float(stop_improvement), job.ws.data_ptr(), job.ws.numel(),
+                                            job.result.data_ptr(), ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_ts_enqueue")
+        job.done = torch.cuda.Event()
+        job.done.record(job.stream)
+    return job
+
+
 def finish_icp(job, vertices):
-    """Wait for a start_icp job; returns the dict of icp_trans_scale for `vertices`."""
+    """Wait for a start_icp / start_icp_device job; returns the dict of icp_trans_scale for `vertices`."""
     job.done.synchronize()            # the ICP only - not whatever was queued behind it
     res = job.result.tolist()
     scale, trans, iters, error = res[0], np.array([res[1], res[2], res[3]]), int(res[4]), res[5]
+    if job.norm is None:
+        n = job.host[0].numpy()
+        job.norm = (n[0:3].copy(), float(n[3]), n[4:7].copy(), float(n[7]))
     offset_s, scale_s, offset_t, scale_t = job.norm
     v = (np.asarray(vertices, np.float64) - offset_s) / scale_s * scale_t + offset_t
     return dict(scale=scale, trans=trans, iterations=iters, error=error, all_scale=scale_t * scale / scale_s,
@@ -139,6 +259,23 @@ def start_alignment(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=10
     ps = sample_surface(verts, faces, samples, seed)
     pt = sample_surface(gt_verts, gt_faces, samples, seed + 1)
     return start_icp(ps, pt, max_iter, device)
+
+
+def start_alignment_device(kept_verts_dev, kept_faces_dev, counts_dev, origin, voxel_size, target_points, samples=30000, max_iter=100, seed=0):
+    """start_alignment for a surface that lives on the device - the largest-component filter's output (lattice-unit vertices and
+    faces at input capacity, counts_dev[1] = number of kept faces): vertex placement in the exporter's fp32 arithmetic
+    (utils/mesh.py:360-369), the area-weighted sampling, the normalisation and the ICP are all enqueued on the current stream;
+    no step waits for the device.  `target_points` [samples,3] fp64: the ground-truth mesh's samples (host array or pinned
+    tensor; sampled with seed + 1 like start_alignment does)."""
+    dev = kept_verts_dev.device
+    vs = np.float32(voxel_size.item() if hasattr(voxel_size, "item") else voxel_size)
+    org = torch.tensor([np.float32(o) for o in origin], dtype=torch.float32, device=dev)
+    placed = kept_verts_dev * float(vs) + org                       # fp32 multiply, fp32 add: place_vertices on the device
+    ps = sample_surface_device(placed, kept_faces_dev, samples, seed, counts_dev[1:2])
+    pt = target_points if torch.is_tensor(target_points) else torch.from_numpy(np.ascontiguousarray(target_points, dtype=np.float64)).pin_memory()
+    job = start_icp_device(ps, pt.to(dev, non_blocking=True), max_iter)
+    job.host.append(pt)               # keep the pinned staging buffer alive until the run is done
+    return job
 
 
 def align_to_ground_truth(verts, faces, gt_verts, gt_faces, samples=30000, max_iter=100, seed=0, device="cuda"):

@@ -156,6 +156,7 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     # host, plus the whole surface when the label pass needs every vertex
                     from .mesh_post import keep_largest_component_device
                     kv, kf, counts = keep_largest_component_device(v, f, r["voxel_size"], r["origin"])
+                    r["kept_dev_" + part] = (kv, kf, counts)       # (the eval-mode hook samples the kept surface on the device)
                     to_host(r, "kept_verts_" + part, kv)
                     to_host(r, "kept_faces_" + part, kf)
                     done = to_host(r, "kept_counts_" + part, counts)
@@ -187,6 +188,66 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         if nxt is None:
             return
         cur, r, nxt, bbox_next = nxt, r_next, after, bbox_after
+
+
+class GroundTruthPrefetcher:
+    """Eval mode reads one ground-truth mesh per sample (utils/mesh.py:386-389) and samples 30 000 points from it
+    (deep_sdf/metrics/icp_trans_scale.py:19-23): file parsing and sampling run on a worker thread, one or two samples ahead of
+    the consumer, so that neither sits between two decoder passes.  get() returns the pinned [samples, 3] fp64 target points, or
+    None when the file is missing and allow_missing_gt is set; a missing file otherwise raises like the reference's trimesh.load."""
+
+    def __init__(self, task, data_root, allow_missing_gt=False, samples=30000, seed=1):
+        from concurrent.futures import ThreadPoolExecutor
+        self.task, self.data_root, self.allow_missing, self.samples, self.seed = task, data_root, allow_missing_gt, samples, seed
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-gt")
+        self.jobs = {}
+
+    def _load(self, ply_filename_out):
+        from .icp import load_obj, sample_surface
+        path = mesh_utils.ground_truth_mesh_path(ply_filename_out, self.task, self.data_root)
+        if not os.path.exists(path):
+            return path, None
+        gv, gf = load_obj(path)
+        pts = torch.from_numpy(np.ascontiguousarray(sample_surface(gv, gf, self.samples, self.seed)))
+        return path, (pts.pin_memory() if torch.cuda.is_available() else pts)
+
+    def prefetch(self, ply_filename_out):
+        if ply_filename_out not in self.jobs:
+            self.jobs[ply_filename_out] = self.pool.submit(self._load, ply_filename_out)
+
+    def get(self, ply_filename_out):
+        self.prefetch(ply_filename_out)
+        path, pts = self.jobs.pop(ply_filename_out).result()
+        if pts is None:
+            if not self.allow_missing:
+                raise FileNotFoundError("eval_mode: ground-truth mesh %s not found (data_root=%r); pass allow_missing_gt to write "
+                                        "unaligned meshes instead" % (path, self.data_root))
+            import logging
+            logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh (allow_missing_gt)" % path)
+        return pts
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+class FileWriter:
+    """PLY files are written on a worker thread (tobytes + write release the GIL): the consumer hands over host arrays and
+    moves on to the next sample; close() waits for every file and re-raises the first failure."""
+
+    def __init__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-ply")
+        self.jobs = []
+
+    def write_ply(self, path, verts, faces):
+        from .ply import write_ply
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self.jobs.append(self.pool.submit(write_ply, path, verts, faces))
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        for j in self.jobs:
+            j.result()
 
 
 def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
@@ -245,71 +306,85 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         # synthetic latents here, which wrote meaningless <real sample>_hand.ply files that the evaluation then scored.)
         raise ValueError("reconstruct() needs a code_source: npz_code_source(<dir of per-sample .npz codes>), "
                          "model_output_code_source(<encoder callable>), or synthetic_code_source(...) for tests and benchmarks")
+    hand_on = specs.get("HandBranch", True)
+    gt = GroundTruthPrefetcher(task, data_root, allow_missing_gt) if eval_mode and hand_on else None
+    writer = FileWriter()
+
     def samples():
         for k, path in enumerate(names):
             name = path.split("/")[-1].split(".")[0]                       # reconstruct.py:78
+            if gt is not None:
+                gt.prefetch(os.path.join(mesh_dir, "%s_hand.ply" % name))  # parsed + sampled by the time the ICP hook wants it
             latent, mano_results, obj_results = code_source(name, int(start_point) + k)
             yield (int(start_point) + k, name), latent, mano_results, obj_results
 
     records = []
-    with torch.no_grad():
-        t_prev = time.perf_counter()
-        hand_on = specs.get("HandBranch", True)
+    try:
+        with torch.no_grad():
+            t_prev = time.perf_counter()
 
-        def hand_path(name):
-            return os.path.join(mesh_dir, "%s_hand" % name)
+            def hand_path(name):
+                return os.path.join(mesh_dir, "%s_hand" % name)
 
-        def kept(r, part):
-            c = r["host_kept_counts_" + part].numpy()
-            return r["host_kept_verts_" + part][:c[0]], r["host_kept_faces_" + part][:c[1]]
+            def kept(r, part):
+                c = r["host_kept_counts_" + part].numpy()
+                return r["host_kept_verts_" + part][:c[0]], r["host_kept_faces_" + part][:c[1]]
 
-        def begin_hand(key, r):
-            """Eval mode: surface sampling and the ICP launch of the hand mesh, slotted between two decoder passes (see
-            pipelined_two_pass); the consumer below only waits for the result."""
-            if "verts_hand" in r:
-                r["copy_done_hand"].synchronize()
-                kv, kf = kept(r, "hand")
-                r["pending_hand"] = mesh_utils.begin_export_surface(
-                    kv, kf, r["origin"], r["voxel_size"], hand_path(key[1]) + ".ply", None, None, True, task, False, data_root,
-                    allow_missing_gt=allow_missing_gt)
+            def begin_hand(key, r):
+                """Eval mode: the ICP of the hand mesh, slotted between two decoder passes (see pipelined_two_pass).  Everything
+                it needs is on the device already - the largest component straight from K8, sampled there (bit-identical to the
+                host sampler), normalised there - and the ground truth's samples come from the prefetch thread: the hook only
+                enqueues, the consumer below only waits for the result."""
+                if "verts_hand" in r:
+                    from .icp import start_alignment_device
+                    target = gt.get(hand_path(key[1]) + ".ply")
+                    r["icp_job"] = None if target is None else start_alignment_device(*r["kept_dev_hand"], r["origin"], r["voxel_size"], target)
 
-        for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
-                                                    label_out=label_out and hand_on, midpoint=begin_hand if eval_mode else None):
-            rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
-                   "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
-            # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
-            # is on - zeros / one outside eval mode or when the hand has no surface (utils/mesh.py:123-133,186-195)
-            offset, sc = (np.array([0, 0, 0]), np.array([1])) if hand_on else (None, scale)
-            for part in ("hand", "obj"):
-                if "verts_" + part in r:
-                    r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
-                    base = os.path.join(mesh_dir, "%s_%s" % (name, part))
-                    if part == "hand" and "pending_hand" in r:
-                        pending = r.pop("pending_hand")
-                        if eval_mode and pending[2][2] is None:
-                            rec["icp_skipped"] = True          # allow_missing_gt: no ground-truth mesh, written unaligned
-                        _, _, trans, icp_scale = mesh_utils.end_export_surface(pending)
-                    else:
+            for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
+                                                        label_out=label_out and hand_on, midpoint=begin_hand if gt is not None else None):
+                rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
+                       "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
+                # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
+                # is on - zeros / one outside eval mode or when the hand has no surface (utils/mesh.py:123-133,186-195)
+                offset, sc = (np.array([0, 0, 0]), np.array([1])) if hand_on else (None, scale)
+                for part in ("hand", "obj"):
+                    if "verts_" + part in r:
+                        r["copy_done_" + part].synchronize()          # side-stream D2H of this mesh only
+                        base = os.path.join(mesh_dir, "%s_%s" % (name, part))
                         kv, kf = kept(r, part)
-                        _, _, trans, icp_scale = mesh_utils.export_surface(
-                            kv, kf, r["origin"], r["voxel_size"], base + ".ply", None if part == "hand" else offset,
-                            None if part == "hand" else sc, False, task, False, data_root)
-                    if part == "hand":
-                        offset, sc = trans, icp_scale
-                        rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])
-                        if "host_labels_hand" in r:
-                            verts, faces, vertices = mesh_utils.place_vertices(r["host_verts_hand"], r["host_faces_hand"], r["origin"],
-                                                                               r["voxel_size"])
-                            labels = r["host_labels_hand"].float()
-                            mesh_utils.write_label_outputs(vertices, faces, labels, base, offset, sc, viz)
-                            rec["labels_hand"] = np.bincount(labels.long().numpy(), minlength=1).tolist()
-                elif "mc_error_" + part in r:
-                    import logging
-                    logging.warning("Cannot reconstruct mesh from '{}'".format(os.path.join(mesh_dir, "%s_%s.ply" % (name, part))))
-                    print(r["mc_error_" + part])
-            now = time.perf_counter()
-            rec["seconds"], t_prev = now - t_prev, now
-            records.append(rec)
+                        _, faces, points = mesh_utils.place_vertices(kv, kf, r["origin"], r["voxel_size"], None if part == "hand" else offset,
+                                                                     None if part == "hand" else sc)
+                        trans, icp_scale = np.array([0, 0, 0]), np.array([1])
+                        if part == "hand" and gt is not None:
+                            job = r.pop("icp_job", None)
+                            if job is None:
+                                rec["icp_skipped"] = True          # allow_missing_gt: no ground-truth mesh, written unaligned
+                            else:
+                                from .icp import finish_icp
+                                out = finish_icp(job, points)
+                                points = out["vertices"]
+                                trans, icp_scale = np.asarray(out["all_trans"]).reshape(1, 3), np.asarray(out["all_scale"]).reshape(1)
+                        writer.write_ply(base + ".ply", points, faces)
+                        if part == "hand":
+                            offset, sc = trans, icp_scale
+                            rec["icp_trans"], rec["icp_scale"] = np.asarray(trans).reshape(-1).tolist(), float(np.asarray(icp_scale).reshape(-1)[0])
+                            if "host_labels_hand" in r:
+                                verts, faces, vertices = mesh_utils.place_vertices(r["host_verts_hand"], r["host_faces_hand"], r["origin"],
+                                                                                   r["voxel_size"])
+                                labels = r["host_labels_hand"].float()
+                                mesh_utils.write_label_outputs(vertices, faces, labels, base, offset, sc, viz)
+                                rec["labels_hand"] = np.bincount(labels.long().numpy(), minlength=1).tolist()
+                    elif "mc_error_" + part in r:
+                        import logging
+                        logging.warning("Cannot reconstruct mesh from '{}'".format(os.path.join(mesh_dir, "%s_%s.ply" % (name, part))))
+                        print(r["mc_error_" + part])
+                now = time.perf_counter()
+                rec["seconds"], t_prev = now - t_prev, now
+                records.append(rec)
+    finally:
+        if gt is not None:
+            gt.close()
+        writer.close()                  # every file is on disk (or its error raised) before reconstruct() returns
     return records
 
 

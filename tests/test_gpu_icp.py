@@ -1,6 +1,7 @@
 """GPU parity of the eval-mode ICP (K7) against the reference class' goldens and the CPU oracle."""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -52,3 +53,70 @@ def test_eval_mode_alignment_recovers_known_transform(tmp_path):
     aligned, trans, scale, info = align_to_ground_truth(pred, f, lv, lf, samples=20000)
     assert abs(scale - 1.12) < 5e-3 and np.abs(aligned - gt_v).max() < 1e-3
     assert info["iterations"] <= 100
+
+
+def _sphere_volume(n=64, r=0.55):
+    ax = torch.linspace(-1, 1, n)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    return (torch.sqrt(zz * zz * 1.0 + yy * yy * 1.6 + xx * xx * 2.3) - r).cuda()
+
+
+def test_device_surface_sampler_is_the_host_sampler_bit_for_bit():
+    """The eval-mode hook samples the predicted surface on the device (alignsdf_amd.icp.sample_surface_device): same faces picked,
+    same points, bit for bit, as the host sampler on the same mesh - for a marching-cubes surface, for a mesh padded to a larger
+    capacity with its face count on the device (the largest-component filter's output), and for other seeds / counts."""
+    from alignsdf_amd.icp import sample_surface, sample_surface_device
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.mesh_post import keep_largest_component_device
+    v, f = marching_cubes_device(_sphere_volume(), 0.0)
+    vs, org = np.float32(2.0 / 63), [-1.0, -1.0, -1.0]
+    placed = v * float(vs) + torch.tensor(org, dtype=torch.float32, device="cuda")
+    host_v, host_f = placed.cpu().numpy(), f.cpu().numpy()
+    for count, seed in ((30000, 0), (30000, 1), (1000, 7)):
+        want = sample_surface(host_v, host_f, count, seed)
+        got = sample_surface_device(placed, f, count, seed)
+        assert got.dtype == torch.float64 and np.array_equal(got.cpu().numpy(), want), (count, seed)
+    # K8's output: capacity of the input, the kept counts on the device
+    kv, kf, counts = keep_largest_component_device(v, f, vs, org)
+    c = counts.cpu().numpy()
+    kept_placed = kv * float(vs) + torch.tensor(org, dtype=torch.float32, device="cuda")
+    want = sample_surface(kept_placed[:c[0]].cpu().numpy(), kf[:c[1]].cpu().numpy(), 30000, 0)
+    got = sample_surface_device(kept_placed, kf, 30000, 0, counts[1:2])
+    assert np.array_equal(got.cpu().numpy(), want)
+    # a padded copy with garbage behind the live faces gives the same samples
+    pad = torch.cat([kf[:c[1]], torch.randint(0, int(c[0]), (5000, 3), dtype=kf.dtype, device="cuda")], 0)
+    got = sample_surface_device(kept_placed, pad, 30000, 0, counts[1:2])
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_device_alignment_equals_the_host_alignment(tmp_path):
+    """start_alignment_device (placement, sampling, normalisation and ICP enqueued on the device, nothing waited for) against the
+    host-prepared start_alignment on the same surface and ground truth: same samples, so the same transform to 1e-9."""
+    from alignsdf_amd.icp import finish_icp, sample_surface, start_alignment, start_alignment_device
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.mesh_post import keep_largest_component_device
+    v, f = marching_cubes_device(_sphere_volume(), 0.0)
+    vs, org = np.float32(2.0 / 63), [-1.0, -1.0, -1.0]
+    kv, kf, counts = keep_largest_component_device(v, f, vs, org)
+    c = counts.cpu().numpy()
+    placed = (kv[:c[0]] * float(vs) + torch.tensor(org, dtype=torch.float32, device="cuda")).cpu().numpy()
+    faces = kf[:c[1]].cpu().numpy()
+    gt_v = placed.astype(np.float64) * 1.07 + np.array([0.02, -0.03, 0.01])
+    host = finish_icp(start_alignment(placed, faces, gt_v, faces), placed)
+    target = sample_surface(gt_v, faces, 30000, 1)
+    dev = finish_icp(start_alignment_device(kv, kf, counts, org, vs, target), placed)
+    assert dev["iterations"] == host["iterations"]
+    assert abs(dev["all_scale"] - host["all_scale"]) <= 1e-9 and np.abs(dev["all_trans"] - host["all_trans"]).max() <= 1e-9
+    assert np.abs(dev["vertices"] - host["vertices"]).max() <= 1e-9
+    assert abs(dev["all_scale"] - 1.07) < 5e-3
+
+
+def test_obj_reader_forms(tmp_path):
+    from alignsdf_amd.icp import load_obj
+    p = tmp_path / "a.obj"
+    p.write_text("# c\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1/1/1 3/3/1 4/4/1\n")
+    v, f = load_obj(str(p))
+    assert v.shape == (4, 3) and f.tolist() == [[0, 1, 2], [0, 2, 3]]
+    p.write_text("v 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 1 1 0 0 0 1\nv 0 1 0 1 1 1\nf 1 2 3 4\nf -4 -3 -2\n")      # colours, a quad, negative indices
+    v, f = load_obj(str(p))
+    assert v.tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]] and f.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]

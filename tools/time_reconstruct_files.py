@@ -50,6 +50,17 @@ if EVAL:
         out = icp.icp_trans_scale(src, tgt, src)
         torch.cuda.synchronize(); t1 = time.perf_counter()
     print("stand-alone ICP 30k x 30k: %d iterations, %.1f ms total, %.2f ms / iteration" % (out["iterations"], 1e3 * (t1 - t0), 1e3 * (t1 - t0) / out["iterations"]))
+# the GPU-side reference of the same configuration: the product's sample pipeline without files (what bench.py times)
+def pipeline_ms(n):
+    src = rc.synthetic_code_source("nerf3")
+    items = [(i,) + src("s", i) for i in range(1, n + 1)]
+    list(rc.pipelined_two_pass(dec, specs, iter(items[:2]), N))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    list(rc.pipelined_two_pass(dec, specs, iter(items), N))
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+base = pipeline_ms(n_samples)
+print("sample pipeline without files (bench.py's step): %.1f ms/sample -> file flow / pipeline = %.2f" % (base, 1e3 * dt / n_samples / base))
 # host tail breakdown on the last sample's hand mesh
 from alignsdf_amd.ply import read_ply
 r = next(iter(rc.pipelined_two_pass(dec, specs, [(0, torch.from_numpy(syn.latent_code(1)).cuda(), None, None)], N)))[1]
