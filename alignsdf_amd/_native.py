@@ -27,7 +27,7 @@ EXPORTS = (
     "asdf_debug_pack_host", "asdf_decoder_set_classifier", "asdf_decode_points_cls",
     "asdf_icp_ts_enqueue", "asdf_icp_ts_result", "asdf_chamfer",
     "asdf_decoder_set_math", "asdf_decoder_get_math", "asdf_debug_pack_host_f16",
-    "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit",
+    "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -96,10 +96,12 @@ def lib():
     L.asdf_mc_count_enqueue.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, vp, vp]
     L.asdf_mc_result_status.argtypes = [vp, ctypes.c_double]
     L.asdf_mc_emit.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, vp, vp, vp]
+    L.asdf_icp_set_search.argtypes = [i32]
     L.asdf_icp_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.asdf_icp_ts.argtypes = [vp, i32, vp, i32, i32, ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t,
                               ctypes.POINTER(ctypes.c_double), vp]
     L.asdf_icp_ts_enqueue.argtypes = [vp, i32, vp, i32, i32, ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t, vp, vp]
+    L.asdf_icp_ts_enqueue_range.argtypes = [vp, i32, vp, i32, i32, i32, ctypes.c_double, ctypes.c_double, vp, ctypes.c_size_t, vp, vp]
     L.asdf_icp_ts_result.argtypes = [vp, ctypes.POINTER(ctypes.c_double), vp]
     L.asdf_decoder_set_math.argtypes = [vp, i32]
     L.asdf_decoder_get_math.argtypes = [vp]

@@ -80,3 +80,104 @@ def encoder_code_source(encoder, image_of, device="cuda"):
             img = image_of(name, index).to(device, non_blocking=True)
             return encoder(img), None, None
     return source
+
+
+def quick_gil_handover(interval=5e-4):
+    """Worker threads (image decode, ground-truth parsing, PLY writes) hold the interpreter lock between their C calls; with
+    CPython's default 5 ms switch interval the main thread - whose job is to keep the GPU's queue full - can wait that long
+    for it every time.  0.5 ms makes a worker hand it back promptly."""
+    import sys
+    if sys.getswitchinterval() > interval:
+        sys.setswitchinterval(interval)
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # transforms.Normalize of utils/data.py:220
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def load_image_tensor(path, image_size, out=None):
+    """One encoder input as utils.data.ImagesInput.__getitem__ prepares it (utils/data.py:235-244): decode the file (RGB), take the
+    centre crop of `image_size` = (H, W) (generate_patch_image with a centre box, no scale / rotation; outside the picture is
+    black), scale to [0, 1], normalise with the ImageNet statistics.  Returns (or fills `out`, a [1, 3, H, W] fp32 tensor)."""
+    import numpy as np
+    from PIL import Image
+    H, W = int(image_size[0]), int(image_size[1])
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert("RGB"))
+    h, w = rgb.shape[:2]
+    top, left = (h - H) // 2, (w - W) // 2
+    crop = np.zeros((H, W, 3), dtype=np.uint8)
+    ys, xs = max(top, 0), max(left, 0)
+    ye, xe = min(top + H, h), min(left + W, w)
+    crop[ys - top:ye - top, xs - left:xe - left] = rgb[ys:ye, xs:xe]
+    x = torch.from_numpy(crop).permute(2, 0, 1).to(torch.float32).div_(255.0)
+    x = (x - torch.tensor(IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    if out is None:
+        return x.unsqueeze(0)
+    out[0].copy_(x)
+    return out
+
+
+class ImageFilePrefetcher:
+    """`image_of(name, index)` for encoder_code_source, from image FILES: the counterpart of the reference's
+    ImagesInput + DataLoader(num_workers=1) (reconstruct.py:54-66).  `ahead` samples in advance a worker thread decodes
+    <image_root>/<name><ext> (PIL), crops / normalises it into a pinned [1, 3, H, W] buffer and uploads it on a side stream;
+    the call for sample k makes the compute stream wait for that upload's event and hands the device tensor over - the host
+    never waits for the device, and the decode of image k+2 runs while the GPU is inside the passes of sample k."""
+
+    def __init__(self, image_root, names, image_size=(256, 256), ext=".jpg", ahead=2, device="cuda"):
+        from concurrent.futures import ThreadPoolExecutor
+        quick_gil_handover()
+        self.root, self.names, self.size, self.ext, self.ahead = image_root, list(names), tuple(image_size), ext, max(1, int(ahead))
+        self.device = torch.device(device)
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-img")
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.order = {n: i for i, n in enumerate(self.names)}
+        self.jobs = {}
+        self.decode_seconds = 0.0
+        # a ring of pinned staging buffers, allocated ONCE: pinning memory per image costs a millisecond and takes a runtime lock
+        # the main thread's kernel launches queue behind
+        self.ring = []
+        if self.side is not None:
+            self.ring = [[torch.empty((1, 3) + self.size, dtype=torch.float32).pin_memory(), None] for _ in range(self.ahead + 3)]
+        self.turn = 0
+
+    def _load(self, name):
+        import os
+        import time
+        t0 = time.perf_counter()
+        if self.side is None:
+            host = load_image_tensor(os.path.join(self.root, name + self.ext), self.size)
+            self.decode_seconds += time.perf_counter() - t0
+            return host, None
+        slot = self.ring[self.turn % len(self.ring)]
+        self.turn += 1
+        if slot[1] is not None:
+            slot[1].synchronize()         # the upload that last used this buffer (ahead + 3 images ago) is long done
+        load_image_tensor(os.path.join(self.root, name + self.ext), self.size, out=slot[0])
+        self.decode_seconds += time.perf_counter() - t0
+        with torch.cuda.stream(self.side):
+            dev = slot[0].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        slot[1] = ev
+        return dev, ev
+
+    def _schedule(self, name):
+        if name not in self.jobs:
+            self.jobs[name] = self.pool.submit(self._load, name)
+
+    def __call__(self, name, index):
+        k = self.order.get(name)
+        self._schedule(name)
+        if k is not None:
+            for nxt in self.names[k + 1:k + 1 + self.ahead]:
+                self._schedule(nxt)
+        dev, ev = self.jobs.pop(name).result()
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            dev.record_stream(torch.cuda.current_stream(self.device))
+        return dev
+
+    def close(self):
+        self.pool.shutdown(wait=True)

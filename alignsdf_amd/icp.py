@@ -172,9 +172,21 @@ def icp_trans_scale(points_source, points_target, vertices, max_iter=100, device
     return finish_icp(start_icp(points_source, points_target, max_iter, device), vertices)
 
 
+FIRST_BATCH = 16      # iterations enqueued up front; the run is continued at finish time only if it has not converged by then
+
+
+def _enqueue_range(job, first, last):
+    max_iter, stop_error, stop_improvement = job.args
+    with torch.cuda.device(job.device):
+        _native.check(_native.lib().asdf_icp_ts_enqueue_range(
+            job.src.data_ptr(), job.src.shape[0], job.tgt.data_ptr(), job.tgt.shape[0], int(first), int(last), float(stop_error),
+            float(stop_improvement), job.ws.data_ptr(), job.ws.numel(), job.result.data_ptr(),
+            ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_ts_enqueue_range")
+
+
 class IcpJob:
     """An ICP run in flight on the device (start_icp); finish_icp waits for it."""
-    __slots__ = ("src", "tgt", "ws", "host", "norm", "stream", "device", "done", "result")
+    __slots__ = ("src", "tgt", "ws", "host", "norm", "stream", "device", "done", "result", "args")
 
 
 
@@ -198,10 +210,9 @@ def start_icp(points_source, points_target, max_iter=100, device="cuda", stop_er
     # blit kernel, which cannot start while a decoder pass (one wave per SIMD holding the whole register file) is on
     # the machine - the caller would wait for whatever it queued behind the ICP
     job.result = torch.zeros(8, dtype=torch.float64).pin_memory()
+    job.args = (int(max_iter), float(stop_error), float(stop_improvement))
     with torch.cuda.device(dev):
-        _native.check(L.asdf_icp_ts_enqueue(job.src.data_ptr(), job.src.shape[0], job.tgt.data_ptr(), job.tgt.shape[0], int(max_iter),
-                                            float(stop_error), float(stop_improvement), job.ws.data_ptr(), job.ws.numel(),
-                                            job.result.data_ptr(), ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_ts_enqueue")
+        _enqueue_range(job, 0, min(FIRST_BATCH, int(max_iter)))
         job.done = torch.cuda.Event()
         job.done.record(job.stream)
     return job
@@ -231,10 +242,9 @@ def start_icp_device(points_source_dev, points_target_dev, max_iter=100, stop_er
     _native.check(L.asdf_icp_workspace_bytes(job.src.shape[0], job.tgt.shape[0], ctypes.byref(nbytes)), "asdf_icp_workspace_bytes")
     job.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     job.result = torch.zeros(8, dtype=torch.float64).pin_memory()
+    job.args = (int(max_iter), float(stop_error), float(stop_improvement))
     with torch.cuda.device(dev):
-        _native.check(L.asdf_icp_ts_enqueue(job.src.data_ptr(), job.src.shape[0], job.tgt.data_ptr(), job.tgt.shape[0], int(max_iter),
-                                            float(stop_error), float(stop_improvement), job.ws.data_ptr(), job.ws.numel(),
-                                            job.result.data_ptr(), ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_ts_enqueue")
+        _enqueue_range(job, 0, min(FIRST_BATCH, int(max_iter)))
         job.done = torch.cuda.Event()
         job.done.record(job.stream)
     return job
@@ -244,6 +254,13 @@ def finish_icp(job, vertices):
     """Wait for a start_icp / start_icp_device job; returns the dict of icp_trans_scale for `vertices`."""
     job.done.synchronize()            # the ICP only - not whatever was queued behind it
     res = job.result.tolist()
+    if res[6] == 0.0 and int(res[4]) < job.args[0]:
+        # not converged within the first batch (rare: runs take a handful of iterations): the remaining ones, now
+        with torch.cuda.stream(job.stream):
+            _enqueue_range(job, int(res[4]), job.args[0])
+            job.done.record(job.stream)
+        job.done.synchronize()
+        res = job.result.tolist()
     scale, trans, iters, error = res[0], np.array([res[1], res[2], res[3]]), int(res[4]), res[5]
     if job.norm is None:
         n = job.host[0].numpy()

@@ -198,9 +198,15 @@ class GroundTruthPrefetcher:
 
     def __init__(self, task, data_root, allow_missing_gt=False, samples=30000, seed=1):
         from concurrent.futures import ThreadPoolExecutor
+        from .frontend import quick_gil_handover
+        quick_gil_handover()
         self.task, self.data_root, self.allow_missing, self.samples, self.seed = task, data_root, allow_missing_gt, samples, seed
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-gt")
         self.jobs = {}
+        # pinned staging for the target samples, allocated once (pinning per sample takes a runtime lock that the main thread's
+        # launches queue behind); a slot is reused four samples later, long after its ICP has been waited for
+        self.ring = [torch.empty((samples, 3), dtype=torch.float64).pin_memory() for _ in range(4)] if torch.cuda.is_available() else []
+        self.turn = 0
 
     def _load(self, ply_filename_out):
         from .icp import load_obj, sample_surface
@@ -209,7 +215,12 @@ class GroundTruthPrefetcher:
             return path, None
         gv, gf = load_obj(path)
         pts = torch.from_numpy(np.ascontiguousarray(sample_surface(gv, gf, self.samples, self.seed)))
-        return path, (pts.pin_memory() if torch.cuda.is_available() else pts)
+        if self.ring:
+            slot = self.ring[self.turn % len(self.ring)]
+            self.turn += 1
+            slot.copy_(pts)
+            pts = slot
+        return path, pts
 
     def prefetch(self, ply_filename_out):
         if ply_filename_out not in self.jobs:
@@ -236,6 +247,8 @@ class FileWriter:
 
     def __init__(self):
         from concurrent.futures import ThreadPoolExecutor
+        from .frontend import quick_gil_handover
+        quick_gil_handover()
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-ply")
         self.jobs = []
 

@@ -275,13 +275,17 @@ int asdf_mesh_largest_component(const float* verts_dev, int32_t num_verts, const
  * The iteration (both nearest-neighbour sweeps, the sums, the stopping rules and the solve) stays on the device;
  * asdf_icp_ts enqueues 8 iterations at a time and synchronises the stream between batches to read the 64-byte state. */
 int asdf_icp_workspace_bytes(int32_t ns, int32_t nt, size_t* bytes);
+/* Nearest-neighbour search of the ICP / Chamfer kernels (process-wide; for tests and measurements): 0 = automatic - a uniform grid
+ * per reference set, built once per run, when both sets have at least 1024 points, brute force otherwise; 1 = brute force;
+ * 2 = grid.  Both are exact and return identical neighbours (on exact distance ties: the lowest index). */
+int asdf_icp_set_search(int32_t mode);
 int asdf_icp_ts(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, double stop_error,
                 double stop_improvement, void* workspace_dev, size_t workspace_bytes, double* result, void* stream);
 
 /* The same run without any host synchronisation: every one of the max_iter iterations is enqueued (iterations past
  * convergence return at once), the outcome stays in the workspace.  asdf_icp_ts_result copies it to result[6] (layout
  * above) and synchronises the stream; the workspace and both point sets must stay alive until then.
- * result_mapped (optional) is device-accessible HOST memory (hipHostMalloc / hipHostRegister, 6 doubles) that the last
+ * result_mapped (optional) is device-accessible HOST memory (hipHostMalloc / hipHostRegister, 7 doubles: [6] = converged) that the last
  * kernel of the run fills: a caller that has queued further work behind the ICP waits on an event recorded after this
  * call and reads it - any copy, even from a side stream, would be a kernel that cannot start while a decoder pass
  * holds the whole register file of every SIMD. */
@@ -289,6 +293,14 @@ int asdf_icp_ts_enqueue(const double* src_dev, int32_t ns, const double* tgt_dev
                         double stop_error, double stop_improvement, void* workspace_dev, size_t workspace_bytes,
                         double* result_mapped, void* stream);
 int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream);
+/* asdf_icp_ts_enqueue for iterations [first_iter, last_iter) only: first_iter == 0 begins the run (initial state, search grids),
+ * first_iter > 0 continues the run that lives in the workspace.  result_mapped takes 7 doubles here: the six of the layout above
+ * and [6] = 1 if the reference's stopping rules have fired.  A run converges in a handful of iterations, and every enqueued
+ * iteration past convergence is still two (empty) launches: a caller enqueues the first 16 behind its other work and, only when
+ * [6] is still 0 at the time it needs the result, the remaining ones (alignsdf_amd/icp.py: start_icp_device / finish_icp). */
+int asdf_icp_ts_enqueue_range(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t first_iter, int32_t last_iter,
+                              double stop_error, double stop_improvement, void* workspace_dev, size_t workspace_bytes,
+                              double* result_mapped, void* stream);
 
 /* Symmetric Chamfer distance of the reference's evaluation (compute_trimesh_chamfer, deep_sdf/metrics/chamfer.py:217-229):
  * exact nearest neighbours both ways between a_dev [na][3] and b_dev [nb][3] (fp64, device), result[0] = mean squared

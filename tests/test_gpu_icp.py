@@ -120,3 +120,51 @@ def test_obj_reader_forms(tmp_path):
     p.write_text("v 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 1 1 0 0 0 1\nv 0 1 0 1 1 1\nf 1 2 3 4\nf -4 -3 -2\n")      # colours, a quad, negative indices
     v, f = load_obj(str(p))
     assert v.tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]] and f.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+
+
+def _nn_both_ways(a, b, mode):
+    """Nearest-neighbour structure through the C ABI under a search mode: the Chamfer sums and one ICP run."""
+    import ctypes
+    from alignsdf_amd import _native
+    from alignsdf_amd.icp import run_icp_f
+    L = _native.lib()
+    _native.check(L.asdf_icp_set_search(mode), "asdf_icp_set_search")
+    try:
+        A, B = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        nbytes = ctypes.c_size_t()
+        _native.check(L.asdf_icp_workspace_bytes(len(a), len(b), ctypes.byref(nbytes)), "ws")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device="cuda")
+        out = (ctypes.c_double * 2)()
+        _native.check(L.asdf_chamfer(A.data_ptr(), len(a), B.data_ptr(), len(b), ws.data_ptr(), ws.numel(), out,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "asdf_chamfer")
+        return (out[0], out[1]), run_icp_f(a, b)
+    finally:
+        L.asdf_icp_set_search(0)
+
+
+@pytest.mark.parametrize("case", ["surfaces", "offset", "clustered", "ties", "small"])
+def test_grid_search_equals_brute_force(case):
+    """The uniform-grid nearest-neighbour search (round 3) against the brute-force kernel: identical Chamfer sums (bit for bit: the
+    same neighbours, the same fixed-order reduction) and an identical ICP run, on overlapping surfaces, on sets that barely
+    overlap (long shell walks, queries outside the grid), on clustered points, on lattice points with many exact distance ties,
+    and on a set smaller than the grid resolution."""
+    rng = np.random.default_rng(11)
+    if case == "surfaces":
+        u = rng.normal(size=(30000, 3)); a = 0.35 * u / np.linalg.norm(u, axis=1, keepdims=True) + np.array([-0.25, 0.0, 0.0])
+        w = rng.normal(size=(30000, 3)); b = 0.37 * w / np.linalg.norm(w, axis=1, keepdims=True) + np.array([-0.23, 0.01, 0.0])
+    elif case == "offset":
+        a = rng.random((20000, 3)) * 0.3
+        b = rng.random((15000, 3)) * 0.3 + np.array([0.5, -0.4, 0.2])
+    elif case == "clustered":
+        a = np.concatenate([rng.normal(size=(10000, 3)) * 0.01, rng.normal(size=(10000, 3)) * 0.2 + 0.5])
+        b = np.concatenate([rng.normal(size=(12000, 3)) * 0.02 + 0.01, rng.random((3000, 3))])
+    elif case == "ties":
+        g = np.stack(np.meshgrid(*[np.arange(24) / 8.0] * 3, indexing="ij"), -1).reshape(-1, 3)
+        a, b = g + 1.0 / 16.0, g.copy()                    # every query has 8 equidistant neighbours
+    else:
+        a, b = rng.random((1500, 3)), rng.random((1100, 3)) * np.array([1.0, 1e-3, 1.0])
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    brute, icp_brute = _nn_both_ways(a, b, 1)
+    grid, icp_grid = _nn_both_ways(a, b, 2)
+    assert brute == grid, (brute, grid)
+    assert icp_brute[0] == icp_grid[0] and np.array_equal(icp_brute[1], icp_grid[1]) and icp_brute[2:] == icp_grid[2:]
