@@ -73,6 +73,50 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
   }
 }
 
+// K0b: the point-feature columns and bias rows of layers 0 / 2 of the split-half constants image -> fp16 A operands of the
+// one-plane kernels (sdf_layout.h: kA16Floats).  One workgroup per (head, layer), one thread per output row: the largest
+// magnitude of the layer's 4 x 512 values picks the power of two T = 2^e (0 <= e <= 15) that brings them under 2^14; every
+// value is stored as the two fp16 planes of v / T and the kernel multiplies the point operand by T.  More than 2^29 cannot be
+// carried: counted in status[0] like any other fp16 range violation (the sweep is then refused and repeated as an ordinary one).
+__global__ __launch_bounds__(512) void fold_points_f16_kernel(const float* __restrict__ cst_all, float* __restrict__ a16_all, int* status) {
+  const int head = blockIdx.x >> 1, layer = blockIdx.x & 1;
+  const CstOffsets co = cst_offsets(2);
+  const float* cst = cst_all + (size_t)head * co.floats;
+  float* a16 = a16_all + (size_t)head * kA16Floats;
+  const int row = threadIdx.x, t = row >> 5, rr = row & 31;
+  const int abase = layer ? co.a2 : co.a0, cbase = layer ? co.c2 : co.c0;
+  float v[4];
+  v[0] = cst[abase + (t * 2 + 0) * 64 + 0 * 32 + rr];      // feature d = 2 step + lane half
+  v[1] = cst[abase + (t * 2 + 0) * 64 + 1 * 32 + rr];
+  v[2] = cst[abase + (t * 2 + 1) * 64 + 0 * 32 + rr];
+  v[3] = cst[cbase + (t * 2 + ((rr >> 2) & 1)) * 16 + (rr & 3) + 4 * (rr >> 3)];
+  float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  if (!(m == m)) m = INFINITY;
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+  __shared__ float wmax[8];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = wmax[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) m = fmaxf(m, wmax[k]);
+  int e = 0;
+  if (m > 16384.0f) { int ex; (void)frexpf(m, &ex); e = ex - 14; }       // m in [2^(ex-1), 2^ex): m / 2^e < 2^14
+  if (e > 15 || !(m < INFINITY)) { e = 15; if (threadIdx.x == 0 && status) atomicAdd(status, 1); }
+  const float T = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+  _Float16 hi[4], lo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const float sv = v[k] * inv; hi[k] = (_Float16)sv; lo[k] = (_Float16)(sv - (float)hi[k]); }
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  h8v a, b;
+  a[0] = hi[0]; a[1] = hi[1]; a[2] = hi[2]; a[3] = hi[0]; a[4] = hi[1]; a[5] = hi[2]; a[6] = hi[3]; a[7] = lo[3];
+  b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = b[4] = b[5] = b[6] = b[7] = (_Float16)0.0f;
+  h8v* out = reinterpret_cast<h8v*>(a16 + layer * kA16LayerFloats + t * kA16TileFloats);
+  out[rr] = a;              // lane rr:      lane half 0
+  out[32 + rr] = b;         // lane 32 + rr: lane half 1
+  if (threadIdx.x == 0) a16[2 * kA16LayerFloats + layer] = T;
+}
+
 __global__ void bbox_init_kernel(int* bbox) {   // 16 ints: two records of {min[3], max[3], count, pad}
   const int i = threadIdx.x;
   if (i < 16) {
@@ -366,6 +410,7 @@ struct asdf_decoder {
   float* stream16;
   float* stream16_hi;   // the high planes alone (1 KiB records): weight stream of the one-plane kernel (asdf_decode_grid_box)
   float* cst16;
+  float* a16;       // [heads][kA16Floats] fp16 point-feature / bias operands of the one-plane kernels (K0b, per sample)
   float s2[ASDF_MAX_HEADS];
   int math;
   bool sample_bound;
@@ -461,7 +506,7 @@ int asdf_device_count(void) {
 
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
-  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi};
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi, d->a16};
   if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
   if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
   if (d->ev_join) (void)hipEventDestroy(d->ev_join);
@@ -528,6 +573,8 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
       for (size_t r = 0; r < nrec; ++r) std::memcpy(&hi[r * 512], &hp.stream16[r * 1024], 512 * sizeof(uint16_t));
       e = hipMalloc((void**)&d->stream16_hi, hi.size() * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMemcpy(d->stream16_hi, hi.data(), hi.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc((void**)&d->a16, (size_t)kHeads * kA16Floats * sizeof(float));
+      if (e == hipSuccess) e = hipMemset(d->a16, 0, (size_t)kHeads * kA16Floats * sizeof(float));
     }
     for (int h = 0; h < kHeads; ++h) {
       d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
@@ -614,6 +661,8 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
     fp.cst = d->cst16;
     for (int h = 0; h < kHeads; ++h) fp.s2[h] = d->s2[h];
     hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+    if (d->a16)       // the one-plane kernels' fp16 point-feature / bias operands, from the image just folded
+      hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16, d->a16, d->status);
   }
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
@@ -775,7 +824,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   p.sdf0 = scratch_hand_dev; p.sdf1 = scratch_obj_dev; p.bbox = bbox_dev;
   p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
-  p.stream = d->stream16_hi; p.cst = d->cst16; p.status = d->status;
+  p.stream = d->stream16_hi; p.cst = d->cst16; p.a16 = d->a16; p.status = d->status;
   p.first_mlp = 0; p.num_mlps = d->spec.num_heads; p.pf = d->spec.point_feats[0];
   if (!two_out) {
     if (!p.sdf1) p.num_mlps = 1;
@@ -843,7 +892,7 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = rec_dev;      // (the box words are by-products; 7 / 15 carry the range report)
   p.P = P; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
-  p.stream = d->stream16_hi; p.cst = d->cst16; p.status = d->status;
+  p.stream = d->stream16_hi; p.cst = d->cst16; p.a16 = d->a16; p.status = d->status;
   p.first_mlp = 0; p.num_mlps = 2; p.pf = d->spec.point_feats[0];
   if (!p.sdf1) p.num_mlps = 1;
   else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }

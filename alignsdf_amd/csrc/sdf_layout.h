@@ -85,6 +85,18 @@ __host__ __device__ constexpr CstOffsets cst_offsets(int kp) {
   return o;
 }
 
+// One-plane kernels, affine point features: layers 0 and 2 take their K = 4 point-feature products AND their bias row from one
+// fp16 MFMA (K = 16) instead of a bias load + two fp32 MFMAs.  Per head: [layer 0 | layer 2][tile 0..15][lane 0..63][8 halves],
+// then T0, T2 (the power of two the values are divided by; the point operand is multiplied by it) + pad.
+//   A lane l (row i = l & 31), half 0 (k 0..7):  w_hi[0..2], w_hi[0..2], c_hi, c_lo        w = point-feature column, c = bias
+//                              half 1 (k 8..15): w_lo[0..2], 0, 0, 0, 0, 0
+//   B lane l (point j = l & 31), half 0:          x_hi[0..2], x_lo[0..2], T, T              x_hi + x_lo = x T in two fp16 planes
+//                              half 1:            x_hi[0..2], 0, 0, 0, 0, 0
+// = (w_hi + w_lo) x + c to 2^-22 of each term (the w_lo x_lo products are dropped): more than the kernel's other operands carry.
+constexpr int kA16TileFloats = 64 * 4;                                  // 64 lanes x 8 halves
+constexpr int kA16LayerFloats = kTilesHidden * kA16TileFloats;          // 4096
+constexpr int kA16Floats = 2 * kA16LayerFloats + 8;                     // + T0, T2, pad
+
 // feature row held by (register r, lane half h) of a 32x32 D tile
 __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // input feature consumed by K-step s (s = 16 * in_tile + r) on lane half h

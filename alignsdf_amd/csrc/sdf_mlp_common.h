@@ -68,6 +68,8 @@ struct DecodeParams {
                             // |new - old| over them (float bits), [1] += picks whose sign changed, [2] += picks evaluated;
                             // the other positions report to status[3] as usual
   const int* audit_from;
+  const float* a16;         // one-plane kernels (affine point features): [heads][kA16Floats] - the point-feature columns and bias rows
+                            // of layers 0 and 2 as fp16 A operands of ONE v_mfma_f32_32x32x16_f16 per tile (fold_points_f16_kernel)
   float neg_thr;            // a voxel counts as negative for the fused box when sdf < neg_thr: 0 for the ordinary sweeps, -tau
                             // for the one-plane sweep of asdf_decode_grid_box (certainly negative); kGridSubset patches
                             // compare the value they replace against it

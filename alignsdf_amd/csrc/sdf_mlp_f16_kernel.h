@@ -127,6 +127,12 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #endif
 // one-plane kernel (PL = 1) only - its K-blocks are 32 / 64 matrix-pipe cycles, not 96, so what hides behind a K-block of the
 // split-half kernel does not hide here:
+#ifndef ASDF16_P1_FP16PT
+#define ASDF16_P1_FP16PT 1       // point features and bias rows of layers 0 / 2 on ONE fp16 MFMA per tile (sdf_layout.h: kA16Floats)
+#endif
+#ifndef ASDF16_P1_FP16PT_L2
+#define ASDF16_P1_FP16PT_L2 0    // ... layer 2 as well: measured SLOWER (its two point operands are 8 more live registers in the part of the
+#endif                           // kernel that sits at the 512-register limit: layers 2 / 3 lose 6 k cycles to spills, layer 0 gains 2.6 k)
 #ifndef ASDF16_PK_RELU
 #define ASDF16_PK_RELU 0         // ReLU and the range maximum on the PACKED fp16 pair (v_pk_max_f16) behind the conversion: 4 VALU per pair, not 6
 #endif
@@ -176,8 +182,9 @@ constexpr int kS16WaveFloats = S16<2>::kWaveFloats;
 constexpr int kRing16Floats = S16<2>::kRingFloats;
 // LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
 constexpr int kWrecInts = 20;    // per wave: two 8-int negative-voxel records + the largest plane value of layers 0..2 (+ pad)
+constexpr bool pt16(int kp, int planes) { return ASDF16_P1_FP16PT && planes == 1 && kp == 2; }
 constexpr int lds_bytes_f16(int kp, int planes = 2) {
-  return (kRing * kS16Kb * 256 * planes + cst_offsets(kp).floats) * 4 + kWaves * kWrecInts * 4;
+  return (kRing * kS16Kb * 256 * planes + cst_offsets(kp).floats + (pt16(kp, planes) ? kA16Floats : 0)) * 4 + kWaves * kWrecInts * 4;
 }
 constexpr int kLdsBytesF16 = lds_bytes_f16(2);
 constexpr int kLdsBytesF16P1 = lds_bytes_f16(2, 1);
@@ -416,6 +423,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
       for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
     }
+    // (one-plane kernels: the fp16 point-feature / bias operands of layers 0 and 2, behind the per-wave records)
+    constexpr bool kPt16 = pt16(KP, PL);
+    constexpr bool kPt16L2 = kPt16 && ASDF16_P1_FP16PT_L2;
+    static_assert(!kPt16 || ASDF16_L0_PIPE, "the fp16 point operands are wired into the pipelined layer 0");
+    float* a16s = cst + CL::kFloats + kWaves * kWrecInts;
+    if (kPt16) {
+      const f32x4* src4 = reinterpret_cast<const f32x4*>(p.a16 + (size_t)head * kA16Floats);
+      for (int i = tid; i < kA16Floats / 4; i += 256)
+        if (kPt16L2 || i < kA16LayerFloats / 4 || i >= 2 * kA16LayerFloats / 4) reinterpret_cast<f32x4*>(a16s)[i] = src4[i];
+    }
     const float* sbase0 = p.stream + (size_t)head * kS16Head * SG::kFloats;
 #pragma unroll
     for (int s = 0; s < ((ABL & 33) ? kRing : kRing - 1); ++s) {
@@ -462,8 +479,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const long long pib = pi + kWavePts;
       const bool validb = G == 2 && pib < npts;
       float bpb[2] = {0.0f, 0.0f};
+      float y0 = 0.f, y1 = 0.f, y2 = 0.f;
       if (G == 2) {
-        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
         if (p.mode == kPointList) {
           if (validb) { y0 = p.xyz[pib * 3 + 0]; y1 = p.xyz[pib * 3 + 1]; y2 = p.xyz[pib * 3 + 2]; }
         } else {
@@ -484,6 +501,30 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
       }
+      // one-plane kernels: the points as the fp16 B operand of layers 0 / 2 (sdf_layout.h: kA16Floats) - x T in two planes, T twice
+      // (the bias planes' multiplier) on lane half 0; the high planes again on lane half 1 (they meet the weights' low planes)
+      auto point_operand = [&](float c0, float c1, float c2, float T) -> h8 {
+        const float s0 = c0 * T, s1 = c1 * T, s2 = c2 * T;
+        const _Float16 a0 = (_Float16)s0, a1 = (_Float16)s1, a2 = (_Float16)s2;
+        h8 r;
+        r[0] = a0; r[1] = a1; r[2] = a2;
+        if (half == 0) {
+          r[3] = (_Float16)(s0 - (float)a0); r[4] = (_Float16)(s1 - (float)a1); r[5] = (_Float16)(s2 - (float)a2);
+          r[6] = (_Float16)T; r[7] = (_Float16)T;
+        } else {
+          r[3] = r[4] = r[5] = r[6] = r[7] = (_Float16)0.0f;
+        }
+        return r;
+      };
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      h8 bq0, bq0b, bq2, bq2b;
+      if (kPt16) {
+        bq0 = point_operand(x0, x1, x2, a16s[2 * kA16LayerFloats]);
+        if (G == 2) bq0b = point_operand(y0, y1, y2, a16s[2 * kA16LayerFloats]);
+      }
+      auto a16_frag = [&](int layer, int t) -> h8 {      // this lane's 8 halves of tile t's operand
+        return *reinterpret_cast<const h8*>(a16s + layer * kA16LayerFloats + t * kA16TileFloats + lane * 4);
+      };
       const float* sbase = sbase0;
       asm volatile("" : "+s"(sbase));
       auto src_of = [&](int s) -> const float* {   // s = stage index within the head + 3
@@ -496,6 +537,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       f32x16 acc1[2], acc2[2], acc3[2];
       f32x16 acc1b[2], acc2b[2], acc3b[2];      // G == 2: the accumulators of the second point group
       float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
+      h8 pq2;                                   // ... one-plane kernels: its fp16 point / bias operand
       float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
       // one-plane kernel: all 16 of a tile's, read half a tile ahead (a K-block of 64 cycles is shorter than the LDS latency)
       constexpr bool kW4Tile = ASDF16_W4_TILE && PL == 1 && !TWO_OUT;
@@ -555,13 +597,20 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         // MFMAs, then converted.)
         f32x16 la[3], lb[3];
         float lf[3][KP];
+        h8 lq[3];
         auto l0p_load = [&](int t) {
+          if (kPt16) { lq[t % 3] = a16_frag(0, t); return; }      // bias and point-feature columns in one fp16 operand
           la[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
           if (G == 2) lb[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
 #pragma unroll
           for (int s = 0; s < KP; ++s) lf[t % 3][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
         };
         auto l0p_mfma = [&](int t) {
+          if (kPt16) {
+            la[t % 3] = ASDF_MFMA16(lq[t % 3], bq0, zero16);
+            if (G == 2) lb[t % 3] = ASDF_MFMA16(lq[t % 3], bq0b, zero16);
+            return;
+          }
 #pragma unroll
           for (int s = 0; s < KP; ++s) {
             la[t % 3] = ASDF_MFMA(lf[t % 3][s], bp[s], la[t % 3]);
@@ -630,6 +679,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
+          else if (kPt16L2) pq2 = a16_frag(1, 0);
           else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
 #if ASDF16_STAGE_KB == 8
@@ -649,6 +699,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
       ASDF16_MARK(2);
+      if (kPt16L2) {
+        bq2 = point_operand(x0, x1, x2, a16s[2 * kA16LayerFloats + 1]);
+        if (G == 2) bq2b = point_operand(y0, y1, y2, a16s[2 * kA16LayerFloats + 1]);
+      }
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
@@ -657,12 +711,18 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
         f32x16& accb = (G == 2 ? acc2b : acc2)[t & 1];
+        if (kPt16L2) {
+          if (!ASDF16_PRELOAD) pq2 = a16_frag(1, t);
+          acc = ASDF_MFMA16(pq2, bq2, zero16);
+          if (G == 2) accb = ASDF_MFMA16(pq2, bq2b, zero16);
+        } else {
         if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
 #pragma unroll
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
           acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
+        }
         }
         auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
@@ -682,7 +742,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         };
         auto pre_last = [&](int c) {
           if (!ASDF16_PRELOAD || c != kPreKb) return;
-          if (t + 1 < kTilesHidden) {
+          if (t + 1 < kTilesHidden && kPt16L2) {
+            pq2 = a16_frag(1, t + 1);
+          } else if (t + 1 < kTilesHidden) {
             acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
             if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
             load_pf2(t + 1);
