@@ -37,6 +37,18 @@ def evaluate(experiment_directory, data_dir, task="obman", obj=False, optim=Fals
     return out, len(names)
 
 
+def evaluate_queue(queue, experiment_directory, data_dir, start_point, end_point, optim, mano, optim_mano, fit, rot, obj, task):
+    """The reference's worker signature (evaluate.py:19): one `queue.put([(name, chamfer_dist, joints_dist, verts_dist)])` per
+    evaluated mesh of [start_point, end_point), so that a caller written against the reference's multiprocess driver
+    (evaluate.py:200-228) can use this worker.  Names are taken in sorted order (the reference iterates os.listdir's); the `mano`,
+    `optim_mano`, `fit` and `rot` modes read the image encoder's outputs and are not reproduced (NotImplementedError)."""
+    if mano or optim_mano or fit or rot:
+        raise NotImplementedError("the --mano / --optim_mano / --fit / --rot modes evaluate encoder outputs, which are outside this build")
+    results, _ = evaluate(experiment_directory, data_dir, task, obj, optim, start_point, end_point)
+    for rec in results:
+        queue.put([rec])
+
+
 def write_summary(experiment_directory, task, summary, n_pred, obj=False):
     """chamfer_hand.txt / chamfer_obj.txt (evaluate.py:254-310)."""
     summary = sorted(summary, reverse=True, key=lambda r: r[1])

@@ -288,12 +288,12 @@ def decode_two_pass(hand_branch, obj_branch, decoder, latent_vec, mano_results, 
 
 def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, latent_vec, mano_results, obj_results, cam_intr,
                                  specs, filename, N=256, max_batch=32 ** 3, offset=None, scale=None, device="cpu",
-                                 label_out=False, viz=False, eval_mode=False, task="obman", grid_mode="reference"):
+                                 label_out=False, viz=False, eval_mode=False, task="obman", grid_mode="reference", return_stats=False):
     """Hand + object meshes of one sample (utils/mesh.py:17-195): writes <filename>_hand.ply / _obj.ply.
     `max_batch` and `device` are accepted for signature compatibility; chunking is internal to the kernel and
     the decoder's device is used.  `grid_mode="reference"` reproduces the true-division lattice of
-    utils/mesh.py:33-34 bit for bit; "integer" is the axis-aligned lattice.  Returns a dict of per-surface
-    (V, F) counts (the reference returns None).
+    utils/mesh.py:33-34 bit for bit; "integer" is the axis-aligned lattice.  Returns None like the reference; with
+    `return_stats=True` a dict of per-surface (V, F) counts (and the labels of the label pass).
 
     `cls_branch` only makes the reference store a per-voxel class column that nothing reads (utils/mesh.py:59-60,
     111-112); it is accepted and has no effect.  `label_out` runs the label pass over the hand mesh vertices
@@ -320,4 +320,4 @@ def create_mesh_combined_decoder(hand_branch, obj_branch, cls_branch, decoder, l
         v, f, _, _ = convert_sdf_samples_to_ply(r["vol_obj"], r["origin"], r["voxel_size"], filename + "_obj.ply", offset, scale,
                                                 False)
         stats["obj"] = (0, 0) if v is None else (len(v), len(f))
-    return stats
+    return stats if return_stats else None

@@ -90,6 +90,16 @@ def test_evaluate_writes_reference_summary(tmp_path):
     vals = [float(l.split(",")[1]) for l in lines[1:4]]
     assert lines[4] == "mean chamfer distance:{}".format(np.mean(vals)) and lines[5] == "median chamfer distance:{}".format(np.median(vals))
     assert lines[-1] == "failure count:1"
+    # the reference's worker signature (evaluate.py:19): one queue.put([(name, chamfer, joints, verts)]) per mesh
+    import queue
+    q = queue.Queue()
+    ev.evaluate_queue(q, str(tmp_path / "exp"), str(tmp_path / "data" / "obman" / "test"), 0, None, False, False, False, False, False, False, "obman")
+    got = []
+    while not q.empty():
+        got += q.get()
+    assert sorted(r[0] for r in got) == ["00000000", "00000001", "00000002"] and {r[0]: r[1] for r in got} == {r[0]: r[1] for r in summary}
+    with pytest.raises(NotImplementedError):
+        ev.evaluate_queue(q, str(tmp_path / "exp"), str(tmp_path / "data"), 0, None, False, True, False, False, False, False, "obman")
 
 
 def test_chamfer_abi_errors(native_lib):

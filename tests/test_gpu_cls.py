@@ -75,7 +75,7 @@ def test_label_pass_files_match_reference(tmp_path, golden_dir):
     g = np.load(golden_dir + "/ref_cls_combcls3.npz")
     specs, dec, lat, mano, obj = _module("combcls3")
     prefix = str(tmp_path / "s0")
-    stats = create_mesh_combined_decoder(True, True, True, dec, lat, mano, obj, None, specs, prefix, N=32, max_batch=2 ** 18,
+    stats = create_mesh_combined_decoder(True, True, True, dec, lat, mano, obj, None, specs, prefix, N=32, max_batch=2 ** 18, return_stats=True,
                                          label_out=True, viz=True)
     z = np.load(prefix + "_hand_label.npz")
     assert z["points"].shape == g["lab_points"].shape and stats["hand"][0] == len(g["lab_points"])

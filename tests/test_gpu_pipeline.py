@@ -51,7 +51,7 @@ def test_create_mesh_combined_decoder_files(tag, tmp_path, golden_dir):
     gd = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
     specs, dec, lat, mano, obj = _module(tag)
     prefix = str(tmp_path / "sample0")
-    stats = create_mesh_combined_decoder(True, True, False, dec, lat, mano, obj, None, specs, prefix, N=32, max_batch=2 ** 18)
+    stats = create_mesh_combined_decoder(True, True, False, dec, lat, mano, obj, None, specs, prefix, N=32, max_batch=2 ** 18, return_stats=True)
     for part in ("hand", "obj"):
         v, f = read_ply("%s_%s.ply" % (prefix, part))
         ref_v, ref_f = gm["dec_%s_%s32.verts" % (tag, part)], gm["dec_%s_%s32.faces" % (tag, part)]

@@ -70,7 +70,7 @@ def test_variant_through_the_sample_pipeline_and_files(tmp_path):
     from alignsdf_amd.reconstruct import pipelined_two_pass
     from alignsdf_amd.utils.mesh import create_mesh_combined_decoder
     specs, dec, mano, obj, cam, latent = _module("tanh")
-    stats = create_mesh_combined_decoder(True, True, False, dec, latent.cuda(), None, None, None, specs, str(tmp_path / "s"), N=32)
+    stats = create_mesh_combined_decoder(True, True, False, dec, latent.cuda(), None, None, None, specs, str(tmp_path / "s"), N=32, return_stats=True)
     assert stats["hand"][1] > 100 and stats["obj"][1] > 100 and (tmp_path / "s_hand.ply").exists() and (tmp_path / "s_obj.ply").exists()
     out = list(pipelined_two_pass(dec, specs, [(k, latent.cuda(), None, None) for k in range(2)], 32))
     assert [k for k, _ in out] == [0, 1] and all(r["F_hand"] == stats["hand"][1] and r["F_obj"] == stats["obj"][1] for _, r in out)
