@@ -39,6 +39,10 @@ PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
 # features stay on the fp32 MFMA
 EXEC_F16_FLOP_PER_POINT_HEAD = 3 * 2 * (512 * 256 + 256 * 512 + 512 * 512)
 EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD = 2 * (4 * 512 + 4 * 512 + 512)
+# one-plane kernel: ONE fp16 MFMA per product sum of the hidden GEMMs, + layer 0's point features and bias row as one K = 16 fp16
+# MFMA per output tile; layer 2's point features stay on the fp32 MFMA
+EXEC_P1_FLOP_PER_POINT_HEAD = 2 * (512 * 256 + 256 * 512 + 512 * 512) + 2 * 16 * 512
+EXEC_P1_SIDE_F32_FLOP_PER_POINT_HEAD = 2 * (4 * 512 + 512)
 CHUNK = 2 ** 18                      # reconstruct.py:93
 
 
@@ -415,7 +419,7 @@ def main():
     split = dec.math == "f16x3"
     if one_plane_main:
         kernel_name, peak, launch_ms_all = "sdf_mlp_f16p1_kernel", PEAK_F16_MFMA_TFLOPS, p1_ms
-        exec_flop = N ** 3 * meshes_per_sample * EXEC_F16_FLOP_PER_POINT_HEAD // 3
+        exec_flop = N ** 3 * meshes_per_sample * EXEC_P1_FLOP_PER_POINT_HEAD
     else:
         kernel_name = "sdf_mlp_f16_kernel" if split else "sdf_mlp_kernel"
         peak, launch_ms_all = (PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS), k1_ms
@@ -552,8 +556,9 @@ def main():
                        "decides, against the peak of the MFMA instruction that is issued; ")
         if one_plane_main:
             note = note_common + ("the one-plane kernel issues ONE v_mfma_f32_32x32x16_f16 per product sum (%d MFMA FLOPs per point per "
-                                  "head, plus %d on the fp32 MFMA for the point features): frac_executed is the matrix-pipe utilisation "
-                                  "against the 2.5 PFLOP/s spec" % (EXEC_F16_FLOP_PER_POINT_HEAD // 3, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD))
+                                  "head incl. layer 0's point features, plus %d on the fp32 MFMA for layer 2's): frac_executed is the "
+                                  "matrix-pipe utilisation against the 2.5 PFLOP/s spec; the part lowers its clock under this kernel "
+                                  "(profiles/r03_k1s_segments.txt)" % (EXEC_P1_FLOP_PER_POINT_HEAD, EXEC_P1_SIDE_F32_FLOP_PER_POINT_HEAD))
         elif split:
             note = note_common + ("each fp32 product sum is carried as two fp16 planes per operand and costs three v_mfma_f32_32x32x16_f16 "
                                   "(%d MFMA FLOPs per point per head, plus %d on the fp32 MFMA); the part is power-limited under this kernel "
