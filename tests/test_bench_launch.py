@@ -47,3 +47,22 @@ def test_gpus_2_on_one_device():
     assert line["n_gpus"] == 2 and line["config"]["world_size_env"] == 2
     assert line["config"]["samples_per_gpu"] == 2 and line["scaling"] == "weak"
     assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"]
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_hand_only_config0():
+    """`--branches hand --grid 64` = BASELINE configs[0]: one mesh per sample, the default (audited one-plane) sweeps, every field of
+    the line the driver and the judge read."""
+    line = _run(["--branches", "hand", "--grid", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"], {})
+    assert line["metric"] == "meshes_per_sec_hand_only_N64" and line["unit"] == "meshes/s" and line["n_gpus"] == 1
+    assert line["config"]["meshes_per_sample"] == 1 and line["config"]["coarse_pass"] == "box" and line["config"]["fine_pass"] == "band"
+    assert abs(line["value"] - 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    r = line["roofline"]
+    assert r["kernel"] == "sdf_mlp_f16p1_kernel" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["launches_timed"] == 6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert line["sweeps"]["refused_sweeps"] == 0 and line["sweeps"]["fine_sweeps"]["audit_evals"] > 0
+    p = line["parity_in_run"]
+    assert p["against_ordinary_sweeps_f16x3"]["vertices_identical"] == 3 and p["against_fp32_chain"]["faces_identical"] == 3
+    assert p["volumes_f16x3_vs_f32"]["sign_differences"] == 0
+    assert line["other_sweeps"]["value"] > 0 and line["other_math"]["math"] == "f32"
