@@ -123,8 +123,12 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         vh, vo, ticket = hip.fine_begin(N, norg.tolist(), nvs.item(), mode, hand=hb, obj=ob, mc_only=True)
         return {"vol_hand": vh, "vol_obj": vo, "voxel_size": nvs, "origin": norg.tolist(), "bbox": b, "fine_ticket": ticket}
 
-    def surfaces(r, sample):
-        """Marching cubes (and the label pass) of one sample; returns True when the decoder was re-bound to it."""
+    def surfaces(r, sample, between=None):
+        """Marching cubes (and the label pass) of one sample.  between(rebound), if given, is called once the marching-cubes
+        launches are queued and before the component filter, label pass and host copies are: the caller queues pass 2 of the
+        next sample there (it may overwrite the volumes only behind the emits), so the ~40 small launches of the post-processing
+        never sit between a pass-1 read-back and the pass-2 launch (eval-mode trace: 1.3 ms of idle GPU per sample).  `rebound`
+        tells it whether the decoder was re-bound to this sample."""
         rebound = False
         ticket = r.pop("fine_ticket", None)
         while hip.fine_needs_repeat(ticket):
@@ -145,11 +149,15 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     continue
                 r["verts_" + part], r["faces_" + part] = v, f
                 r["V_" + part], r["F_" + part] = v.shape[0], f.shape[0]
+        if between is not None:
+            between(rebound)
+        for part, on in (("hand", hb), ("obj", ob)):
+            if on and "verts_" + part in r:
+                v, f = r["verts_" + part], r["faces_" + part]
                 if label_out and part == "hand":
                     # the vertex arithmetic of utils/mesh.py:138-141 in fp32, on the device
                     pts = v * float(r["voxel_size"]) + torch.tensor(r["origin"], dtype=torch.float32, device=v.device)
                     bind(sample)
-                    rebound = True
                     r["labels_hand"] = hip.classify_points(pts, want_sdf=False)[3]
                 if host_copy:
                     # K8 right behind marching cubes: only the largest component (what the file holds) crosses to the
@@ -165,25 +173,31 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                         to_host(r, "faces_" + part, f)
                         done = to_host(r, "labels_" + part, r["labels_" + part])
                     r["copy_done_" + part] = done           # the side stream is in order: the last event covers all
-        return rebound
 
     r = second_pass(first_pass(cur))
     nxt = next(it, None)
     bbox_next = first_pass(nxt) if nxt is not None else None
     while True:
-        rebound = surfaces(r, cur)                      # MC of sample k, queued behind pass 1 of sample k+1
         if nxt is not None:
+            queued = []
+
+            def queue_next_pass2(rebound):
+                if rebound:
+                    bind(nxt)
+                queued.append(second_pass(bbox_next))
+
             # fetch sample k+2 while the queue is short: a source that uploads its codes with a blocking copy would
             # otherwise sit behind pass 2 of sample k+1 and hold the consumer back for a whole pass
             after = next(it, None)
-            if rebound:
-                bind(nxt)
-            r_next = second_pass(bbox_next)
+            surfaces(r, cur, queue_next_pass2)          # MC of sample k, queued behind pass 1 of sample k+1
+            r_next = queued[0]
             if midpoint is not None:
                 midpoint(cur[0], r)
             bbox_after = first_pass(after) if after is not None else None
-        elif midpoint is not None:
-            midpoint(cur[0], r)
+        else:
+            surfaces(r, cur)
+            if midpoint is not None:
+                midpoint(cur[0], r)
         yield cur[0], r
         if nxt is None:
             return
@@ -194,7 +208,11 @@ class GroundTruthPrefetcher:
     """Eval mode reads one ground-truth mesh per sample (utils/mesh.py:386-389) and samples 30 000 points from it
     (deep_sdf/metrics/icp_trans_scale.py:19-23): file parsing and sampling run on a worker thread, one or two samples ahead of
     the consumer, so that neither sits between two decoder passes.  get() returns the pinned [samples, 3] fp64 target points, or
-    None when the file is missing and allow_missing_gt is set; a missing file otherwise raises like the reference's trimesh.load."""
+    None when the file is missing and allow_missing_gt is set; a missing file otherwise raises like the reference's trimesh.load.
+    The work itself runs in a PROCESS (alignsdf_amd/gt_worker.py, numpy only - like the reference's DataLoader worker): 15 ms of
+    parsing and sampling per sample in a thread would hold the interpreter lock exactly when the main thread has to turn a coarse
+    pass's boxes into the next launch (measured: 1.3 ms of GPU idle per pass in eval mode).  The thread here only moves requests
+    and replies over the pipes (blocking reads release the lock).  ASDF_GT_WORKER=thread keeps everything in-process."""
 
     def __init__(self, task, data_root, allow_missing_gt=False, samples=30000, seed=1):
         from concurrent.futures import ThreadPoolExecutor
@@ -202,33 +220,49 @@ class GroundTruthPrefetcher:
         quick_gil_handover()
         self.task, self.data_root, self.allow_missing, self.samples, self.seed = task, data_root, allow_missing_gt, samples, seed
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-gt")
+        self.proc = None
+        if os.environ.get("ASDF_GT_WORKER", "process") != "thread":
+            import subprocess
+            import sys
+            env = dict(os.environ)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+            self.proc = subprocess.Popen([sys.executable, "-m", "alignsdf_amd.gt_worker"], stdin=subprocess.PIPE,
+                                         stdout=subprocess.PIPE, env=env)
         self.jobs = {}
         # pinned staging for the target samples, allocated once (pinning per sample takes a runtime lock that the main thread's
         # launches queue behind); a slot is reused four samples later, long after its ICP has been waited for
         self.ring = [torch.empty((samples, 3), dtype=torch.float64).pin_memory() for _ in range(4)] if torch.cuda.is_available() else []
         self.turn = 0
 
-    def _load(self, ply_filename_out):
-        from .icp import load_obj, sample_surface
-        path = mesh_utils.ground_truth_mesh_path(ply_filename_out, self.task, self.data_root)
-        if not os.path.exists(path):
-            return path, None
-        gv, gf = load_obj(path)
-        pts = torch.from_numpy(np.ascontiguousarray(sample_surface(gv, gf, self.samples, self.seed)))
-        if self.ring:
-            slot = self.ring[self.turn % len(self.ring)]
-            self.turn += 1
-            slot.copy_(pts)
-            pts = slot
-        return path, pts
+    def _load(self, path):
+        from . import gt_worker
+        if self.proc is None:
+            return gt_worker.load_samples(path, self.samples, self.seed)
+        gt_worker.write_message(self.proc.stdin, (path, self.samples, self.seed))
+        reply = gt_worker.read_message(self.proc.stdout)
+        if reply is None and self.proc.poll() is not None:
+            raise RuntimeError("ground-truth worker process ended with code %s" % self.proc.returncode)
+        if isinstance(reply, tuple) and reply and reply[0] == "error":
+            raise RuntimeError("ground-truth mesh %s: %s" % (path, reply[1]))
+        return reply
 
     def prefetch(self, ply_filename_out):
         if ply_filename_out not in self.jobs:
-            self.jobs[ply_filename_out] = self.pool.submit(self._load, ply_filename_out)
+            path = mesh_utils.ground_truth_mesh_path(ply_filename_out, self.task, self.data_root)
+            self.jobs[ply_filename_out] = (path, self.pool.submit(self._load, path))
 
     def get(self, ply_filename_out):
         self.prefetch(ply_filename_out)
-        path, pts = self.jobs.pop(ply_filename_out).result()
+        path, job = self.jobs.pop(ply_filename_out)
+        pts = job.result()
+        if pts is not None:
+            pts = torch.from_numpy(pts)
+            if self.ring:
+                slot = self.ring[self.turn % len(self.ring)]
+                self.turn += 1
+                slot.copy_(pts)
+                pts = slot
         if pts is None:
             if not self.allow_missing:
                 raise FileNotFoundError("eval_mode: ground-truth mesh %s not found (data_root=%r); pass allow_missing_gt to write "
@@ -239,6 +273,14 @@ class GroundTruthPrefetcher:
 
     def close(self):
         self.pool.shutdown(wait=True)
+        if self.proc is not None:
+            self.proc.stdin.close()
+            try:
+                self.proc.wait(timeout=10)
+            except Exception:
+                self.proc.kill()
+            self.proc.stdout.close()
+            self.proc = None
 
 
 class FileWriter:

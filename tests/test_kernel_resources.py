@@ -90,4 +90,5 @@ def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
     body = body[:body.index("s_endpgm")].splitlines()
     mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16" in l]
     scratch = [i for i, l in enumerate(body) if "scratch_" in l and not l.strip().startswith(";")]
-    assert len(mfma) == 2048 and len([i for i in scratch if mfma[0] < i < mfma[-1]]) <= 8
+    # (2048 of the three 512-wide layers + 32 of layer 0, whose point features are an fp16 operand since round 3)
+    assert len(mfma) == 2048 + 32 and len([i for i in scratch if mfma[0] < i < mfma[-1]]) <= 8

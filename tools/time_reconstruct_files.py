@@ -32,7 +32,7 @@ if EVAL:
 kw = dict(eval_mode=True, data_root=os.path.join(tmp, "data")) if EVAL else {}
 kw["code_source"] = rc.synthetic_code_source("nerf3")
 rc.reconstruct(dec, specs, split, tmp, 0, 1, cube_dim=N, **kw)          # warm-up
-REPS = 5      # the boxes are shared hosts: the worker threads (and the main one) get descheduled now and then - median of 5 runs
+REPS = int(os.environ.get('ASDF_TIMING_REPS', '5'))      # the boxes are shared hosts: the worker threads (and the main one) get descheduled now and then - median of 5 runs
 runs = []
 for _ in range(REPS):
     torch.cuda.synchronize()

@@ -1,0 +1,30 @@
+# Kernel trace of the eval-mode file flow: where does the time over the plain sample pipeline go - GPU work or idle gaps?
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r3/trace_eval; rm -rf $O; mkdir -p $O
+ASDF_TIMING_REPS=1 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python tools/time_reconstruct_files.py 256 8 eval > $O/run.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+rows = []
+for f in glob.glob("$O/t/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+rows.sort()
+# the timed reconstruct() call = the last 8 samples' worth: take the window of the last 16 one-plane sweeps
+p1 = [i for i, r in enumerate(rows) if "f16p1" in r[2]]
+first = p1[-16]
+win = rows[first:]
+t0, t1 = win[0][0], max(r[1] for r in win)
+busy = collections.Counter()
+last_end, idle, gaps = t0, 0, []
+for s, e, n in win:
+    busy[n] += e - s
+    if s > last_end:
+        idle += s - last_end
+        gaps.append((s - last_end, n))
+    last_end = max(last_end, e)
+print("window %.1f ms for 8 samples = %.2f ms/sample; GPU idle %.2f ms/sample" % ((t1 - t0) / 1e6, (t1 - t0) / 8e6, idle / 8e6))
+for n, v in busy.most_common(18):
+    print("  %-70s %.3f ms/sample" % (n[:70], v / 8e6))
+print("largest gaps (ms, before kernel):", [(round(g / 1e6, 2), n[:40]) for g, n in sorted(gaps, reverse=True)[:12]])
+PY
+tail -n 5 $O/run.log
