@@ -31,7 +31,7 @@ def write_message(stream, obj):
 
 def load_samples(path, samples, seed):
     import numpy as np
-    from .icp import load_obj, sample_surface
+    from .surface_sampling import load_obj, sample_surface
     if not os.path.exists(path):
         return None
     gv, gf = load_obj(path)

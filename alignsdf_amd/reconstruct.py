@@ -12,6 +12,7 @@ is the HIP path.
 import argparse
 import json
 import os
+import threading
 import time
 
 import numpy as np
@@ -204,6 +205,41 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         cur, r, nxt, bbox_next = nxt, r_next, after, bbox_after
 
 
+_gt_proc = None
+_gt_lock = threading.Lock()
+
+
+def _ground_truth_process():
+    """The ground-truth worker process (gt_worker.py), started on first use and shared by every reconstruct() call of this
+    process: its start (interpreter + numpy, ~0.2 s) is paid once, not per call.  A worker that has died is replaced."""
+    global _gt_proc
+    with _gt_lock:
+        if _gt_proc is None or _gt_proc.poll() is not None:
+            import atexit
+            import subprocess
+            import sys
+            env = dict(os.environ)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+            first = _gt_proc is None
+            _gt_proc = subprocess.Popen([sys.executable, "-m", "alignsdf_amd.gt_worker"], stdin=subprocess.PIPE,
+                                        stdout=subprocess.PIPE, env=env)
+            if first:
+                atexit.register(_stop_ground_truth_process)
+        return _gt_proc
+
+
+def _stop_ground_truth_process():
+    global _gt_proc
+    proc, _gt_proc = _gt_proc, None
+    if proc is not None and proc.poll() is None:
+        try:
+            proc.stdin.close()
+            proc.wait(timeout=5)
+        except Exception:
+            proc.kill()
+
+
 class GroundTruthPrefetcher:
     """Eval mode reads one ground-truth mesh per sample (utils/mesh.py:386-389) and samples 30 000 points from it
     (deep_sdf/metrics/icp_trans_scale.py:19-23): file parsing and sampling run on a worker thread, one or two samples ahead of
@@ -220,15 +256,7 @@ class GroundTruthPrefetcher:
         quick_gil_handover()
         self.task, self.data_root, self.allow_missing, self.samples, self.seed = task, data_root, allow_missing_gt, samples, seed
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-gt")
-        self.proc = None
-        if os.environ.get("ASDF_GT_WORKER", "process") != "thread":
-            import subprocess
-            import sys
-            env = dict(os.environ)
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-            self.proc = subprocess.Popen([sys.executable, "-m", "alignsdf_amd.gt_worker"], stdin=subprocess.PIPE,
-                                         stdout=subprocess.PIPE, env=env)
+        self.proc = None if os.environ.get("ASDF_GT_WORKER", "process") == "thread" else _ground_truth_process()
         self.jobs = {}
         # pinned staging for the target samples, allocated once (pinning per sample takes a runtime lock that the main thread's
         # launches queue behind); a slot is reused four samples later, long after its ICP has been waited for
@@ -239,8 +267,9 @@ class GroundTruthPrefetcher:
         from . import gt_worker
         if self.proc is None:
             return gt_worker.load_samples(path, self.samples, self.seed)
-        gt_worker.write_message(self.proc.stdin, (path, self.samples, self.seed))
-        reply = gt_worker.read_message(self.proc.stdout)
+        with _gt_lock:                                  # (one request / reply pair at a time on the shared pipes)
+            gt_worker.write_message(self.proc.stdin, (path, self.samples, self.seed))
+            reply = gt_worker.read_message(self.proc.stdout)
         if reply is None and self.proc.poll() is not None:
             raise RuntimeError("ground-truth worker process ended with code %s" % self.proc.returncode)
         if isinstance(reply, tuple) and reply and reply[0] == "error":
@@ -272,15 +301,7 @@ class GroundTruthPrefetcher:
         return pts
 
     def close(self):
-        self.pool.shutdown(wait=True)
-        if self.proc is not None:
-            self.proc.stdin.close()
-            try:
-                self.proc.wait(timeout=10)
-            except Exception:
-                self.proc.kill()
-            self.proc.stdout.close()
-            self.proc = None
+        self.pool.shutdown(wait=True)               # (the worker process is shared by later calls and ends with the interpreter)
 
 
 class FileWriter:

@@ -50,11 +50,14 @@ if EVAL:
     gv, gf = icp.load_obj(os.path.join(gt_dir, "%08d.obj" % 1))
     hv, hf = read_ply(os.path.join(tmp, "meshes", "%08d_obj.ply" % 1))
     src, tgt = icp.sample_surface(np.asarray(hv, np.float64), hf, 30000, 0), icp.sample_surface(gv, gf, 30000, 1)
-    for _ in range(2):
+    ts = []
+    for _ in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = icp.icp_trans_scale(src, tgt, src)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("stand-alone ICP 30k x 30k: %d iterations, %.1f ms total, %.2f ms / iteration" % (out["iterations"], 1e3 * (t1 - t0), 1e3 * (t1 - t0) / out["iterations"]))
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    print("stand-alone ICP 30k x 30k: %d iterations, %.1f ms total, %.2f ms / iteration (median of 5: %s)" % (
+        out["iterations"], 1e3 * t, 1e3 * t / out["iterations"], " ".join("%.1f" % (1e3 * x) for x in ts)))
 # the GPU-side reference of the same configuration: the product's sample pipeline without files (what bench.py times)
 def pipeline_ms(n):
     src = rc.synthetic_code_source("nerf3")
