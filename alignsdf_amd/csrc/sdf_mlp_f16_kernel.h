@@ -43,35 +43,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
 // v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
 // v_pack per register on top)
-template <int PL>
-__device__ __forceinline__ float amax_value(float amax) {      // the running range maximum as a float (the one-plane kernel under PK_RELU keeps two packed halves)
-#if ASDF16_PK_RELU
-  if (PL == 1) {
-    const h2 m = __builtin_bit_cast(h2, amax);
-    return fmaxf((float)m[0], (float)m[1]);
-  }
-#endif
-  return amax;
-}
 __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
-#if ASDF16_PK_RELU
-  // mul, convert, then ReLU and the running maximum on the packed pair: negative values become +0 either way, positive ones
-  // are converted exactly as before (same rounding of the same product), an overflow is an infinity that the maximum keeps
-  f32x2 u;
-  u[0] = a0; u[1] = a1;
-  u = u * mul;
-  h2 q = __builtin_convertvector(u, h2);
-  const h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
-  q = __builtin_elementwise_max(q, zero);
-  h2 m = __builtin_bit_cast(h2, amax);
-  m = __builtin_elementwise_max(m, q);
-  amax = __builtin_bit_cast(float, m);
-  asm volatile("" : "+v"(amax));
-  u32x4 dd = __builtin_bit_cast(u32x4, dst);
-  dd[w] = __builtin_bit_cast(unsigned, q);
-  dst = __builtin_bit_cast(h8, dd);
-  return;
-#endif
   f32x2 t;
   t[0] = __int_as_float(max(__float_as_int(a0), 0));
   t[1] = __int_as_float(max(__float_as_int(a1), 0));
@@ -129,12 +101,6 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 // split-half kernel does not hide here:
 #ifndef ASDF16_P1_FP16PT
 #define ASDF16_P1_FP16PT 1       // point features and bias rows of layers 0 / 2 on ONE fp16 MFMA per tile (sdf_layout.h: kA16Floats)
-#endif
-#ifndef ASDF16_P1_FP16PT_L2
-#define ASDF16_P1_FP16PT_L2 0    // ... layer 2 as well: measured SLOWER (its two point operands are 8 more live registers in the part of the
-#endif                           // kernel that sits at the 512-register limit: layers 2 / 3 lose 6 k cycles to spills, layer 0 gains 2.6 k)
-#ifndef ASDF16_PK_RELU
-#define ASDF16_PK_RELU 0         // ReLU and the range maximum on the PACKED fp16 pair (v_pk_max_f16) behind the conversion: 4 VALU per pair, not 6
 #endif
 #ifndef ASDF16_W4_TILE
 #define ASDF16_W4_TILE 1         // the 16 last-layer weights of a tile's deferred epilogue read at once, half a tile ahead (not pair by pair one K-block ahead)
@@ -264,25 +230,6 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
   lds_dma16_off<(P & 3) * 1024>(src + (P >> 2) * 1024, dst + (P >> 2) * 4096);
 }
 
-// All four pieces of a wave's share of a 16 KiB stage behind ONE M0 set-up (one asm statement: M0 is saved and restored inside it)
-__device__ __forceinline__ void dma_burst4(const float* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-#ifndef ASDF16_DMA_BURST
-#define ASDF16_DMA_BURST 0       // one-plane kernel (4 pieces per stage): 1 = all four in one sequence behind the barrier
-#endif
 
 // One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
@@ -340,9 +287,7 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
       acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
 #endif
       const int m = (kb - BKB) * SG::kMfmas + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
-      if (ASDF16_DMA_BURST && SG::kPieces == 4 && !(ABL & 1) && !(ABL & 32)) {
-        if (m == 0) { dma_burst4(src, dst); __builtin_amdgcn_sched_barrier(0); }
-      } else if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
+      if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
         else if (m == 2) dma_piece<2>(src, dst);
@@ -425,13 +370,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     }
     // (one-plane kernels: the fp16 point-feature / bias operands of layers 0 and 2, behind the per-wave records)
     constexpr bool kPt16 = pt16(KP, PL);
-    constexpr bool kPt16L2 = kPt16 && ASDF16_P1_FP16PT_L2;
     static_assert(!kPt16 || ASDF16_L0_PIPE, "the fp16 point operands are wired into the pipelined layer 0");
     float* a16s = cst + CL::kFloats + kWaves * kWrecInts;
     if (kPt16) {
       const f32x4* src4 = reinterpret_cast<const f32x4*>(p.a16 + (size_t)head * kA16Floats);
       for (int i = tid; i < kA16Floats / 4; i += 256)
-        if (kPt16L2 || i < kA16LayerFloats / 4 || i >= 2 * kA16LayerFloats / 4) reinterpret_cast<f32x4*>(a16s)[i] = src4[i];
+        if (i < kA16LayerFloats / 4 || i >= 2 * kA16LayerFloats / 4) reinterpret_cast<f32x4*>(a16s)[i] = src4[i];      // (layer 2's operands are not used: see the tuning log)
     }
     const float* sbase0 = p.stream + (size_t)head * kS16Head * SG::kFloats;
 #pragma unroll
@@ -517,7 +461,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         return r;
       };
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      h8 bq0, bq0b, bq2, bq2b;
+      h8 bq0, bq0b;
       if (kPt16) {
         bq0 = point_operand(x0, x1, x2, a16s[2 * kA16LayerFloats]);
         if (G == 2) bq0b = point_operand(y0, y1, y2, a16s[2 * kA16LayerFloats]);
@@ -537,7 +481,6 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       f32x16 acc1[2], acc2[2], acc3[2];
       f32x16 acc1b[2], acc2b[2], acc3b[2];      // G == 2: the accumulators of the second point group
       float pf2[KP];                            // A fragments (fp32 MFMA) of the next layer-2 tile
-      h8 pq2;                                   // ... one-plane kernels: its fp16 point / bias operand
       float w4c[2], w4n[2], w4bc[2], w4bn[2];   // last-layer weights of the current / next part of the layer-3 epilogue
       // one-plane kernel: all 16 of a tile's, read half a tile ahead (a K-block of 64 cycles is shorter than the LDS latency)
       constexpr bool kW4Tile = ASDF16_W4_TILE && PL == 1 && !TWO_OUT;
@@ -679,7 +622,6 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
-          else if (kPt16L2) pq2 = a16_frag(1, 0);
           else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
 #if ASDF16_STAGE_KB == 8
@@ -699,10 +641,6 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
       ASDF16_MARK(2);
-      if (kPt16L2) {
-        bq2 = point_operand(x0, x1, x2, a16s[2 * kA16LayerFloats + 1]);
-        if (G == 2) bq2b = point_operand(y0, y1, y2, a16s[2 * kA16LayerFloats + 1]);
-      }
       // ---- layer 2: [h1 (256) | xyz (4, fp32 MFMA, pre-scaled A fragments)] -> 512
       h8 h2h[2 * kTilesHidden], h2l[2 * kTilesHidden];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesHidden; ++t) { h2h[t] = h0h[t]; h2l[t] = h0l[t]; }
@@ -711,18 +649,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
         f32x16& accb = (G == 2 ? acc2b : acc2)[t & 1];
-        if (kPt16L2) {
-          if (!ASDF16_PRELOAD) pq2 = a16_frag(1, t);
-          acc = ASDF_MFMA16(pq2, bq2, zero16);
-          if (G == 2) accb = ASDF_MFMA16(pq2, bq2b, zero16);
-        } else {
         if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
 #pragma unroll
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
           acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
-        }
         }
         auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
@@ -742,9 +674,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         };
         auto pre_last = [&](int c) {
           if (!ASDF16_PRELOAD || c != kPreKb) return;
-          if (t + 1 < kTilesHidden && kPt16L2) {
-            pq2 = a16_frag(1, t + 1);
-          } else if (t + 1 < kTilesHidden) {
+          if (t + 1 < kTilesHidden) {
             acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
             if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
             load_pf2(t + 1);
@@ -914,7 +844,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
-      amax = amax_value<PL>(amax); amax1 = amax_value<PL>(amax1); amax2 = amax_value<PL>(amax2);
+      amax = amax; amax1 = amax1; amax2 = amax2;
       const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
       const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)) ||
                                             (G == 2 && !(fabsf(sdfg) <= 1.0f)))) ? 1 : 0;
