@@ -1,8 +1,9 @@
 # Kernel trace of the eval-mode file flow: where does the time over the plain sample pipeline go - GPU work or idle gaps?
+#   gpurun -- 'bash tools/trace_eval_flow.sh'    -> gpurun_out/r3/trace_eval/summary.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3/trace_eval; rm -rf $O; mkdir -p $O
 ASDF_TIMING_REPS=1 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python tools/time_reconstruct_files.py 256 8 eval > $O/run.log 2>&1
-python3 - <<PY
+python3 - <<PY | tee $O/summary.txt
 import csv, glob, collections
 rows = []
 for f in glob.glob("$O/t/**/*kernel_trace.csv", recursive=True):
