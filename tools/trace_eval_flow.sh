@@ -2,7 +2,7 @@
 #   gpurun -- 'bash tools/trace_eval_flow.sh'    -> gpurun_out/r3/trace_eval/summary.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3/trace_eval; rm -rf $O; mkdir -p $O
-ASDF_TIMING_REPS=1 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python tools/time_reconstruct_files.py 256 8 eval > $O/run.log 2>&1
+ASDF_TIMING_REPS=1 ASDF_TIMING_FLOW_ONLY=1 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python tools/time_reconstruct_files.py 256 8 eval > $O/run.log 2>&1
 python3 - <<PY | tee $O/summary.txt
 import csv, glob, collections
 rows = []
@@ -28,4 +28,4 @@ for n, v in busy.most_common(18):
     print("  %-70s %.3f ms/sample" % (n[:70], v / 8e6))
 print("largest gaps (ms, before kernel):", [(round(g / 1e6, 2), n[:40]) for g, n in sorted(gaps, reverse=True)[:12]])
 PY
-tail -n 5 $O/run.log
+grep -v '^[WE]2026' $O/run.log | tail -n 3 | tee -a $O/summary.txt
