@@ -1,7 +1,7 @@
 """deep_sdf.utils.decode_sdf counterpart (deep_sdf/utils.py:64-75)."""
 import torch
 
-from ..utils.utils import decoder_for, hip_decoder_for
+from ..utils.utils import hip_decoder_for
 
 
 def legacy_evaluator(decoder, latent_vector, query_width=3):

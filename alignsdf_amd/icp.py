@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _native, synthetic
+from . import _native
 
 
 from .surface_sampling import _AREA_QUANTUM, _uniforms, load_obj, sample_surface  # noqa: E402,F401  (torch-free host part)
