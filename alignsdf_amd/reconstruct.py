@@ -242,7 +242,7 @@ def _stop_ground_truth_process():
 
 class GroundTruthPrefetcher:
     """Eval mode reads one ground-truth mesh per sample (utils/mesh.py:386-389) and samples 30 000 points from it
-    (deep_sdf/metrics/icp_trans_scale.py:19-23): file parsing and sampling run on a worker thread, one or two samples ahead of
+    (deep_sdf/metrics/icp_trans_scale.py:19-23): file parsing and sampling run in a worker process, one or two samples ahead of
     the consumer, so that neither sits between two decoder passes.  get() returns the pinned [samples, 3] fp64 target points, or
     None when the file is missing and allow_missing_gt is set; a missing file otherwise raises like the reference's trimesh.load.
     The work itself runs in a PROCESS (alignsdf_amd/gt_worker.py, numpy only - like the reference's DataLoader worker): 15 ms of
@@ -409,7 +409,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
             def begin_hand(key, r):
                 """Eval mode: the ICP of the hand mesh, slotted between two decoder passes (see pipelined_two_pass).  Everything
                 it needs is on the device already - the largest component straight from K8, sampled there (bit-identical to the
-                host sampler), normalised there - and the ground truth's samples come from the prefetch thread: the hook only
+                host sampler), normalised there - and the ground truth's samples come from the prefetch worker: the hook only
                 enqueues, the consumer below only waits for the result."""
                 if "verts_hand" in r:
                     from .icp import start_alignment_device
