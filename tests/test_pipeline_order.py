@@ -1,0 +1,120 @@
+"""Order of the launches pipelined_two_pass issues (alignsdf_amd/reconstruct.py), checked on the CPU with a recording stand-in for
+the decoder: per sample  pass 1 -> [box read-back] -> pass 2 -> marching cubes (utils/mesh.py:27-121, 351-369), with pass 1 of the
+next sample queued ahead of this sample's marching cubes, pass 2 of the next sample ahead of this sample's post-processing (label
+pass), the eval hook between pass 2 of k+1 and pass 1 of k+2 - and a refused fine sweep repeated before marching cubes reads it."""
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import reconstruct as rc
+
+
+class RecordingDecoder:
+    device = torch.device("cpu")
+
+    def __init__(self, log, refuse_fine_of=()):
+        self.log, self.bound, self.refuse = log, None, set(refuse_fine_of)
+        self.fine_count = {}
+
+    def coarse_begin(self, N, origin, voxel, mode, hand=True, obj=True):
+        self.log.append(("pass1", self.bound))
+        return {"key": self.bound}
+
+    def coarse_finish(self, ticket):
+        self.log.append(("boxes", ticket["key"]))
+        b = np.zeros(16, dtype=np.int64)
+        b[0:3], b[3:6], b[6] = (3, 4, 5), (9, 11, 12), 100
+        b[8:11], b[11:14], b[14] = (2, 6, 5), (8, 10, 13), 50
+        return b
+
+    def fine_begin(self, N, origin, voxel, mode, hand=True, obj=True, mc_only=False):
+        assert mc_only
+        k = self.bound
+        self.fine_count[k] = self.fine_count.get(k, 0) + 1
+        self.log.append(("pass2", k))
+        return ("vol_hand", k), ("vol_obj", k), {"key": k, "nth": self.fine_count[k]}
+
+    def fine_needs_repeat(self, ticket):
+        return ticket is not None and ticket["key"] in self.refuse and ticket["nth"] == 1
+
+    def classify_points(self, pts, want_sdf=False):
+        self.log.append(("labels", self.bound))
+        return None, None, None, torch.zeros(pts.shape[0], dtype=torch.int64)
+
+
+@pytest.fixture()
+def harness(monkeypatch):
+    log = []
+    state = {}
+
+    def install(refuse=()):
+        dec = RecordingDecoder(log, refuse)
+        state["dec"] = dec
+        import alignsdf_amd.marching_cubes as mc
+        import alignsdf_amd.utils.utils as uu
+        monkeypatch.setattr(uu, "decoder_for", lambda decoder, specs, mano: dec)
+        monkeypatch.setattr(uu, "bind_sample", lambda hip, specs, latent, mano, obj: setattr(hip, "bound", int(latent)))
+        monkeypatch.setattr(mc, "marching_cubes_begin", lambda vol, level, slot: (log.append(("mc_count", vol[1], vol[0])), vol)[1])
+        monkeypatch.setattr(mc, "marching_cubes_finish", lambda t: (log.append(("mc_emit", t[1], t[0])),
+                                                                   (torch.zeros(6, 3), torch.zeros(8, 3, dtype=torch.int32)))[1])
+        return dec
+    return log, install
+
+
+def samples(n):
+    return [(k, k, None, None) for k in range(n)]          # (key, latent stand-in, mano, obj)
+
+
+SPECS = {"HandBranch": True, "ObjectBranch": True}
+
+
+def first(log, event):
+    return log.index(event)
+
+
+def test_order_of_the_launches(harness):
+    log, install = harness
+    install()
+    hooks = []
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(4), 16, label_out=True,
+                                     midpoint=lambda key, r: (hooks.append(key), log.append(("hook", key)))))
+    assert [k for k, _ in out] == [0, 1, 2, 3] and hooks == [0, 1, 2, 3]
+    for k in range(4):
+        # the reference's order within a sample
+        assert first(log, ("pass1", k)) < first(log, ("boxes", k)) < first(log, ("pass2", k)) < first(log, ("mc_count", k, "vol_hand"))
+        assert first(log, ("mc_count", k, "vol_obj")) < first(log, ("mc_emit", k, "vol_hand")) < first(log, ("mc_emit", k, "vol_obj"))
+        assert first(log, ("mc_emit", k, "vol_obj")) < first(log, ("labels", k)) < first(log, ("hook", k))
+    for k in range(3):
+        # pass 1 of k+1 ahead of the marching cubes of k; pass 2 of k+1 behind its emits and AHEAD of k's post-processing
+        assert first(log, ("pass1", k + 1)) < first(log, ("mc_count", k, "vol_hand"))
+        assert first(log, ("mc_emit", k, "vol_obj")) < first(log, ("pass2", k + 1)) < first(log, ("labels", k))
+    for k in range(2):
+        # the hook of k sits between pass 2 of k+1 and pass 1 of k+2
+        assert first(log, ("pass2", k + 1)) < first(log, ("hook", k)) < first(log, ("pass1", k + 2))
+    # every result carries the zoom cube of its boxes (union of the two branches' boxes: utils/mesh.py:239-254)
+    from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
+    nvs, norg = zoom_cube_from_bboxes([((3, 4, 5), (9, 11, 12), 100), ((2, 6, 5), (8, 10, 13), 50)], 16, 2.0 / 15)
+    for _, r in out:
+        assert float(r["voxel_size"]) == float(nvs) and r["origin"] == norg.tolist()
+        assert r["V_hand"] == 6 and r["F_obj"] == 8 and r["labels_hand"].shape[0] == 6
+
+
+def test_refused_fine_sweep_is_repeated_before_marching_cubes(harness):
+    log, install = harness
+    dec = install(refuse=(1,))
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(3), 16))
+    assert [k for k, _ in out] == [0, 1, 2]
+    assert dec.fine_count == {0: 1, 1: 2, 2: 1}
+    second = [i for i, e in enumerate(log) if e == ("pass2", 1)][1]
+    assert second < first(log, ("mc_count", 1, "vol_hand"))
+    # the decoder was re-bound to sample 1 for the repeat, and to sample 2 again before ITS pass 2
+    assert first(log, ("pass2", 2)) > second and log[first(log, ("pass2", 2))] == ("pass2", 2)
+
+
+def test_single_sample_and_empty_stream(harness):
+    log, install = harness
+    install()
+    assert list(rc.pipelined_two_pass(object(), SPECS, [], 16)) == []
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(1), 16, midpoint=lambda key, r: log.append(("hook", key))))
+    assert [k for k, _ in out] == [0]
+    assert [e[0] for e in log] == ["pass1", "boxes", "pass2", "mc_count", "mc_count", "mc_emit", "mc_emit", "hook"]
