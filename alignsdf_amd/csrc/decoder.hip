@@ -125,6 +125,21 @@ __global__ void bbox_init_kernel(int* bbox) {   // 16 ints: two records of {min[
   }
 }
 
+// Start of a one-plane sweep: the box record plus every small counter / flag word the sweep's kernels accumulate into, in ONE
+// launch (they were a bbox_init launch and four memsets: seven launches per sample that the small lattices notice).
+struct ClearRange { int* p; int n; };
+__global__ void sweep_init_kernel(int* bbox, ClearRange a, ClearRange b, ClearRange c, ClearRange e) {
+  const int i = threadIdx.x;
+  if (i < 16) {
+    const int j = i & 7;
+    bbox[i] = j < 3 ? 0x7fffffff : (j < 6 ? -1 : 0);
+  }
+  if (i < a.n) a.p[i] = 0;
+  if (i < b.n) b.p[i] = 0;
+  if (i < c.n) c.p[i] = 0;
+  if (i < e.n) e.p[i] = 0;
+}
+
 // K2 (standalone form; K1 fuses the same reduction into its epilogue): bounding box of the voxels with
 // sdf < 0 - torch.nonzero + per-axis min/max of get_higher_res_cube (utils/mesh.py:208-237).
 // One wave per (i0, i1) row: the row index is wave-uniform (no per-voxel division), lanes stride over axis 2 with float4
@@ -831,17 +846,16 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
     else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
   }
   p.neg_thr = -tau;                                                   // the fused box takes the CERTAINLY negative voxels
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+  // the box record, the candidate count, status [1] candidates beyond the list / [2] contradiction flag / [3] largest
+  // |exact - one-plane|, the audit record and the audit pick count (none of them is touched by the sweep kernel itself)
+  hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, st, p.bbox, ClearRange{d->near_count, 1}, ClearRange{d->status + 1, 3},
+                     ClearRange{d->audit_rec, 8}, ClearRange{d->audit_count, 1});
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
   k1h_box_launch(two_out, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
-  ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
-  ASDF_HIP(hipMemsetAsync(d->status + 1, 0, 3 * sizeof(int), st));    // [1] candidates beyond the list, [2] contradiction flag, [3] largest |exact - one-plane|
-  ASDF_HIP(hipMemsetAsync(d->audit_rec, 0, 8 * sizeof(int), st));
-  ASDF_HIP(hipMemsetAsync(d->audit_count, 0, sizeof(int), st));
   // audit: voxels both heads decided by sign alone, drawn at random, through the split-half kernel (the arithmetic of the
   // ordinary sweep) - they report the error of the one-plane values where nothing else looks
   if (d->audit_n > 0) {
@@ -896,16 +910,16 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   p.first_mlp = 0; p.num_mlps = 2; p.pf = d->spec.point_feats[0];
   if (!p.sdf1) p.num_mlps = 1;
   else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, p.bbox);
+  // the record, the two band counts, status [1] near-level voxels beyond the list / [3] largest |exact - one-plane| of this call,
+  // the audit record and the near-level count
+  hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, st, p.bbox, ClearRange{d->band_count, 2}, ClearRange{d->status + 1, 3},
+                     ClearRange{d->audit_rec, 8}, ClearRange{d->near_count, 1});
   const long long ntiles = (P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
   k1h_box_launch(false, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
-  ASDF_HIP(hipMemsetAsync(d->band_count, 0, 2 * sizeof(int), st));
-  ASDF_HIP(hipMemsetAsync(d->status + 1, 0, 3 * sizeof(int), st));    // [1] near-level voxels beyond the list, [3] largest |exact - one-plane| of this call
-  ASDF_HIP(hipMemsetAsync(d->audit_rec, 0, 8 * sizeof(int), st));
   float* vols[2] = {sdf_hand_dev, sdf_obj_dev};
   for (int h = 0; h < 2; ++h) {
     if (!vols[h]) continue;
@@ -934,7 +948,6 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   if (d->refine_tau > 0.0f) {
     // ... and, as behind every split-half sweep, the fp32 chain where those values lie within refine_tau of the level (both
     // MLPs over the union of the two near-level lists: an extra exact value is harmless)
-    ASDF_HIP(hipMemsetAsync(d->near_count, 0, sizeof(int), st));
     for (int h = 0; h < 2; ++h)
       if (vols[h])
         hipLaunchKernelGGL(collect_near_level_list_kernel, dim3(256), dim3(256), 0, st, vols[h], d->band_idx + (size_t)h * kBandCap,

@@ -224,10 +224,10 @@ static CcLayout cc_layout(int V, int F) {
   l.size = take((size_t)F * 4); l.open_comp = take((size_t)F * 4); l.keep = take((size_t)F * 4); l.fpos = take((size_t)F * 4);
   l.used = take((size_t)V * 4); l.vpos = take((size_t)V * 4);
   size_t sort_bytes = 0, scan_f = 0, scan_v = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                      (const int*)nullptr, (int*)nullptr, (int)E, 0, 64, (hipStream_t)0);
-  hipcub::DeviceScan::ExclusiveSum(nullptr, scan_f, (const int*)nullptr, (int*)nullptr, F, (hipStream_t)0);
-  hipcub::DeviceScan::ExclusiveSum(nullptr, scan_v, (const int*)nullptr, (int*)nullptr, V, (hipStream_t)0);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_f, (const int*)nullptr, (int*)nullptr, F, (hipStream_t)0);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_v, (const int*)nullptr, (int*)nullptr, V, (hipStream_t)0);
   l.cub_bytes = sort_bytes > scan_f ? sort_bytes : scan_f;
   if (scan_v > l.cub_bytes) l.cub_bytes = scan_v;
   l.cub = take(l.cub_bytes + 256);
