@@ -5,8 +5,8 @@ Rounds 1 / 2 pinned one sample (latent 0) per configuration at N = 128 / 256; on
 counts, so one sample is thin evidence for "identical triangle counts".  This script runs the reference's
 create_mesh_combined_decoder (utils/mesh.py:17-195) on
 
-    nerf3 (ObMan decoder)              N = 128: synthetic samples 1..8,   N = 256: samples 1, 2
-    both9 (DexYCB MANO-aligned)        N = 128: samples 1..8 (each with its own pose_inputs(s)),   N = 256: samples 1, 2
+    nerf3 (ObMan decoder)              N = 128: synthetic samples 1..8,   N = 256: samples 1..6
+    both9 (DexYCB MANO-aligned)        N = 128: samples 1..8 (each with its own pose_inputs(s)),   N = 256: samples 1..6
 
 and records, per (tag, N, sample): the negative-voxel boxes and counts of pass 1, the zoom cube (new_voxel_size, new_origin),
 8192 probes per head and pass, the number of voxels within 1e-6 of the level, and - step 2, skimage 0.18.3 under
@@ -29,7 +29,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 TMP = "/tmp/asdf_r3_%s_%d_s%d_%s.npy"
-PLAN = ((128, tuple(range(1, 9))), (256, (1, 2)))
+PLAN = ((128, tuple(range(1, 9))), (256, (1, 2, 3, 4, 5, 6)))
 
 
 def out_path(tag):
