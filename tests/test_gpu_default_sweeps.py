@@ -177,3 +177,55 @@ def test_allowance_follows_the_samples():
     assert len(set(taus)) > 1 and all(1e-5 < t < 0.05 for t in taus)
     assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     hip.close()
+
+
+@pytest.mark.parametrize("name", ["spread1e4", "huge", "tiny", "heavy_tails", "gain30", "latent_x10"])
+def test_default_sweeps_on_adversarial_decoders_give_the_ordinary_sweeps_meshes(name):
+    """The decoders built to break the fp16 arithmetic (tests/test_gpu_split_half_adversarial.py: magnitude spreads of 1e4,
+    activations far outside the default scale's range, heavy-tailed weights, weight_g = 30, latent x 10) under the DEFAULT sweeps:
+    whatever the one-plane error is there - small, large enough to widen the lists to their capacity, or too large for the
+    allowance so that the mode switches itself off - boxes, zoom cube and both meshes are those of ordinary sweeps, bit for bit."""
+    from alignsdf_amd import _native
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
+    from tests.test_gpu_split_half_adversarial import variant
+    sd, lat = variant(name)
+    N, G = 48, _native.GRID_REFERENCE
+    voxel = 2.0 / (N - 1)
+
+    def run(hip, latent):
+        hip.set_sample(torch.from_numpy(latent).cuda())
+        b = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], voxel, G))
+        nvs, norg = zoom_cube_from_bboxes([(b[0:3], b[3:6], int(b[6])), (b[8:11], b[11:14], int(b[14]))], N, voxel)
+        vh, vo, t = hip.fine_begin(N, norg.tolist(), nvs.item(), G, mc_only=True)
+        while hip.fine_needs_repeat(t):
+            vh, vo, t = hip.fine_begin(N, norg.tolist(), nvs.item(), G, mc_only=True)
+        # (words 6 / 14 are the negative-voxel COUNT of an ordinary sweep and merely non-zero iff there is one after a box-only sweep)
+        out = [[int(x) for x in b[0:6]] + [int(b[6]) != 0], [int(x) for x in b[8:14]] + [int(b[14]) != 0], float(nvs), norg.tolist()]
+        for vol in (vh, vo):
+            try:
+                out.append(marching_cubes_device(vol, 0.0))
+            except (ValueError, RuntimeError) as e:          # no surface in this volume: the same message either way
+                out.append(str(e))
+        return out
+
+    ordinary, default = HipSdfDecoder(sd, 256, 3, "nerf"), HipSdfDecoder(sd, 256, 3, "nerf")
+    ordinary.coarse_mode = ordinary.fine_mode = "exact"
+    assert (default.coarse_mode, default.fine_mode) == ("box", "band")
+    surfaces = 0
+    for k in range(6):
+        latent = (lat * np.float32(1.0 - 0.07 * k)).astype(np.float32)
+        want, got = run(ordinary, latent), run(default, latent)
+        assert want[:4] == got[:4], (name, k, want[:4], got[:4])
+        for a, b in zip(want[4:], got[4:]):
+            if isinstance(a, str) or isinstance(b, str):
+                assert a == b, (name, k, a, b)
+            else:
+                surfaces += 1
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (name, k)
+    print(name, "surfaces compared", surfaces, "modes now", default.coarse_mode, default.fine_mode, "math", default.math,
+          "box", {k: default.box_stats[k] for k in ("box", "exact", "fallback", "max_err", "tau_max")},
+          "band", {k: default.band_stats[k] for k in ("band", "exact", "fallback", "max_err", "max_marked")})
+    assert default.box_stats["audit_flips"] == 0 and default.band_stats["audit_flips"] == 0
+    ordinary.close(); default.close()
