@@ -241,28 +241,101 @@ __global__ __launch_bounds__(256) void collect_box_candidates_kernel(const float
     return box[h][6] == 0 || i0 < box[h][0] || i0 > box[h][3] || i1 < box[h][1] || i1 > box[h][4] || i2 < box[h][2] || i2 > box[h][5];
   };
   auto open = [&](float v) { return v >= -tau && v < tau; };
-  auto hit = [&](long long i) {
-    const int k = atomicAdd(count, 1);
-    if (k < cap) idx[k] = (int)i;
-    else if (status) atomicAdd(status + 1, 1);
+  // one reservation per wave and step (a pose-aligned decoder lists up to 1e6 voxels: one atomic per voxel was 0.3 ms)
+  const int lane = threadIdx.x & 63;
+  auto append = [&](bool h, long long i) {
+    const unsigned long long m = __ballot(h);
+    if (!m) return;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (h) {
+      const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (k < cap) idx[k] = (int)i;
+      else if (status) atomicAdd(status + 1, 1);
+    }
   };
   const bool vec = (N & 3) == 0;
   const long long items = vec ? n / 4 : n;
-  for (long long q = t0; q < items; q += stride) {
+  const long long rounds = (items + stride - 1) / stride;              // (every lane takes every step: the appends are wave-wide)
+  for (long long r = 0; r < rounds; ++r) {
+    const long long q = t0 + r * stride;
+    const bool live = q < items;
     const long long i = vec ? 4 * q : q;
     const int i2 = (int)(i % N), i1 = (int)((i / N) % N), i0 = (int)((i / N) / N);
     float va[4] = {1.f, 1.f, 1.f, 1.f}, vb[4] = {1.f, 1.f, 1.f, 1.f};
-    if (vec) {
-      if (a) { const float4 t = reinterpret_cast<const float4*>(a)[q]; va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; }
-      if (b) { const float4 t = reinterpret_cast<const float4*>(b)[q]; vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w; }
-    } else {
-      if (a) va[0] = a[i];
-      if (b) vb[0] = b[i];
+    if (live) {
+      if (vec) {
+        if (a) { const float4 t = reinterpret_cast<const float4*>(a)[q]; va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; }
+        if (b) { const float4 t = reinterpret_cast<const float4*>(b)[q]; vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w; }
+      } else {
+        if (a) va[0] = a[i];
+        if (b) vb[0] = b[i];
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!vec && k > 0) break;
-      if ((a && open(va[k]) && outside(0, i0, i1, i2 + k)) || (b && open(vb[k]) && outside(1, i0, i1, i2 + k))) hit(i + k);
+      append(live && ((a && open(va[k]) && outside(0, i0, i1, i2 + k)) || (b && open(vb[k]) && outside(1, i0, i1, i2 + k))), i + k);
+    }
+  }
+}
+
+// The candidate count decides how the candidates are re-evaluated (the host cannot know it without a wait, so both forms are
+// enqueued and the one whose count word is zero returns at once): up to `direct` voxels straight on the fp32 chain - one round of
+// 128-point tiles over the CUs is the latency floor of that chain anyway; more than that (pose-aligned decoders list up to 1e6)
+// through the split-half kernel first, 3 x the fp32 chain's rate, and the fp32 chain only where those values lie within refine_tau
+// of the level - the rule of every split-half sweep.  out[0] / out[1]: the count as the direct / the two-step form sees it,
+// out[2] = 0: the near-level count of the two-step form.
+__global__ void split_candidate_count_kernel(const int* __restrict__ count, int cap, int direct, int* out) {
+  if (threadIdx.x == 0) {
+    int c = *count;
+    if (c > cap) c = cap;
+    out[0] = c <= direct ? c : 0;
+    out[1] = c > direct ? c : 0;
+    out[2] = 0;
+  }
+}
+
+// ... and the two-step form's last step: every listed voxel whose exact value is negative extends its head's box (a voxel the
+// sweep kernel had counted already changes nothing: min / max; words 6 / 14 only have to be non-zero iff there is a negative voxel)
+__global__ __launch_bounds__(256) void extend_box_from_list_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                   const int* __restrict__ list, const int* __restrict__ count, int N, int* bbox) {
+  const int n = *count;
+  const float* vols[2] = {a, b};
+  int lo[2][3], hi[2][3], cnt[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[h][k] = 0x7fffffff; hi[h][k] = -1; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int po = list[i];
+    const int i2 = po % N, i1 = (po / N) % N, i0 = (po / N) / N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (vols[h] && vols[h][po] < 0.0f) {
+        lo[h][0] = min(lo[h][0], i0); lo[h][1] = min(lo[h][1], i1); lo[h][2] = min(lo[h][2], i2);
+        hi[h][0] = max(hi[h][0], i0); hi[h][1] = max(hi[h][1], i1); hi[h][2] = max(hi[h][2], i2);
+        ++cnt[h];
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (!vols[h]) continue;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[h][k] = min(lo[h][k], __shfl_xor(lo[h][k], off));
+        hi[h][k] = max(hi[h][k], __shfl_xor(hi[h][k], off));
+      }
+      cnt[h] += __shfl_xor(cnt[h], off);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt[h] > 0) {
+      int* rec = bbox + 8 * h;
+      atomicMin(rec + 0, lo[h][0]); atomicMin(rec + 1, lo[h][1]); atomicMin(rec + 2, lo[h][2]);
+      atomicMax(rec + 3, hi[h][0]); atomicMax(rec + 4, hi[h][1]); atomicMax(rec + 5, hi[h][2]);
+      atomicAdd(rec + 6, cnt[h]);
     }
   }
 }
@@ -447,6 +520,7 @@ struct asdf_decoder {
   // narrow-band fine sweep (asdf_decode_grid_band): voxel marks and the per-head re-evaluation lists, allocated on first use
   unsigned char* band_mark;
   size_t band_mark_bytes;
+  int* box_aux;     // box-only sweep, large candidate lists: [0..2] count words, [4 ..] near-level voxels among the candidates (kNearCap)
   int* band_idx;    // [2][kBandCap]
   int* band_count;  // [2] device words
   // the exact re-evaluation of a short voxel list is latency-bound (one 128-point tile of one MLP on the fp32 chain takes
@@ -472,6 +546,7 @@ namespace asdf {
 // decoder's side stream, joined back into `st`), everything else as one launch
 static int launch_subset(asdf_decoder* d, const DecodeParams& q, bool two_out, int grid, hipStream_t st);
 }
+static constexpr int kCandDirect = 1 << 15;  // candidates of a box-only sweep that go straight to the fp32 chain (more: split-half kernel first)
 static constexpr int kBandCap = 1 << 22;     // voxels per head the narrow-band sweep re-evaluates at most (25 % of 256^3)
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
@@ -526,6 +601,7 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
   if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   if (d->band_mark) (void)hipFree(d->band_mark);
+  if (d->box_aux) (void)hipFree(d->box_aux);
   if (d->band_idx) (void)hipFree(d->band_idx);
   if (d->band_count) (void)hipFree(d->band_count);
   for (float* b : bufs) (void)hipFree(b);
@@ -872,11 +948,40 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
   hipLaunchKernelGGL(collect_box_candidates_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, N, tau, p.bbox, d->near_idx,
                      d->near_count, kCandCap, d->status);
-  DecodeParams q = p;
-  q.stream = d->stream; q.cst = d->cst; q.fixup_flag = d->status + 2;
-  q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kCandCap;
+  if (!d->box_aux) ASDF_HIP(hipMalloc((void**)&d->box_aux, (4 + (size_t)kNearCap) * sizeof(int)));
+  int* direct_count = d->box_aux, *twostep_count = d->box_aux + 1, *twostep_near = d->box_aux + 2, *twostep_idx = d->box_aux + 4;
+  hipLaunchKernelGGL(split_candidate_count_kernel, dim3(1), dim3(64), 0, st, d->near_count, kCandCap, kCandDirect, d->box_aux);
   const int rgrid = kCandCap / kWgPts < d->num_cus ? kCandCap / kWgPts : d->num_cus;
-  { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
+  {
+    // up to kCandDirect candidates: the fp32 chain patches values and boxes in one step
+    DecodeParams q = p;
+    q.stream = d->stream; q.cst = d->cst; q.fixup_flag = d->status + 2;
+    q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = direct_count; q.P = kCandCap;
+    { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
+  }
+  {
+    // more: the values of the ordinary sweep (split-half kernel; it reports the largest |exact - one-plane| to status[3]) ...
+    DecodeParams e = p;
+    e.stream = d->stream16; e.cst = d->cst16; e.bbox = nullptr; e.neg_thr = 0.0f;
+    e.mode = kGridSubset; e.grid_mode = p.mode; e.idx = d->near_idx; e.count_dev = twostep_count; e.P = kCandCap;
+    e.audit = nullptr; e.audit_from = nullptr;
+    k1h_subset_launch(two_out, e, rgrid, st);
+    if (d->refine_tau > 0.0f) {
+      // ... the fp32 chain where they lie within refine_tau of the level ...
+      const float* vols[2] = {p.sdf0, p.sdf1};
+      for (int h = 0; h < 2; ++h)
+        if (vols[h])
+          hipLaunchKernelGGL(collect_near_level_list_kernel, dim3(256), dim3(256), 0, st, vols[h], d->near_idx, twostep_count, kCandCap,
+                             d->refine_tau, twostep_idx, twostep_near, kNearCap, d->status);
+      DecodeParams f = p;
+      f.stream = d->stream; f.cst = d->cst; f.bbox = nullptr; f.neg_thr = 0.0f; f.status = nullptr;
+      f.mode = kGridSubset; f.grid_mode = p.mode; f.idx = twostep_idx; f.count_dev = twostep_near; f.P = kNearCap;
+      const int ngrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
+      { const int rc = launch_subset(d, f, two_out, ngrid, st); if (rc != ASDF_OK) return rc; }
+    }
+    // ... and the boxes take every candidate that is negative
+    hipLaunchKernelGGL(extend_box_from_list_kernel, dim3(256), dim3(256), 0, st, p.sdf0, p.sdf1, d->near_idx, twostep_count, N, p.bbox);
+  }
   // the record of this call travels with the boxes: one read-back for the caller
   hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, bbox_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());

@@ -377,3 +377,35 @@ def test_one_plane_sweeps_on_lattices_that_are_not_multiples_of_four(N):
             assert torch.equal(vb, ve) and torch.equal(fb, fe)
     assert hip.box_stats["box"] == 2 and hip.band_stats["band"] == 3 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     hip.close()
+
+
+@pytest.mark.parametrize("tag,N,hand,obj", [("nerf3", 96, True, True), ("both9", 96, True, True), ("comb3", 64, True, True),
+                                            ("nerf3", 64, True, False), ("nerf3", 70, False, True)])
+def test_large_candidate_lists_take_the_two_step_form(tag, N, hand, obj):
+    """Up to 2^15 candidates go straight to the fp32 chain; more than that (pose-aligned decoders list up to 1e6 at N = 256) are
+    evaluated by the split-half kernel first and only the near-level ones among them by the fp32 chain, with the boxes extended
+    from the list afterwards (csrc/decoder.hip: split_candidate_count_kernel).  A large allowance forces the second form on small
+    lattices: both forms must deliver the ordinary sweep's boxes, and the record the same error measure."""
+    hip, specs = _decoder(tag)
+    hip.coarse_mode = "box"
+    vs = 2.0 / (N - 1)
+    forms = set()
+    for sample in range(3):
+        _bind(hip, specs, sample)
+        want = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs, hand=hand, obj=obj)[2].cpu().numpy()
+        hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs, hand=hand, obj=obj))      # (calibrates on the first sample)
+        errs = {}
+        for tau in (hip._box_tau, 0.02, 0.045):
+            rec, _, _ = hip._box_launch(N, [-1.0, -1.0, -1.0], vs, 0, hand, obj, tau)
+            r = rec.cpu().numpy()
+            listed = int(r[32])
+            forms.add(listed > (1 << 15))
+            assert _boxes(r) == _boxes(want), (tag, sample, tau, listed)
+            assert int(r[16]) == 0 and int(r[18]) == 0 and int(r[36]) == 0          # no range violation, no contradiction, no audit flip
+            errs[tau] = float(np.int32(r[19]).view(np.float32))
+        # the larger lists contain the smaller ones: the largest |exact - one-plane| over the re-evaluated voxels cannot shrink
+        taus = sorted(errs)
+        assert errs[taus[0]] <= errs[taus[1]] + 1e-9 <= errs[taus[2]] + 2e-9, errs
+        assert 0.0 < errs[taus[2]] < 0.01
+    assert forms == {False, True}, "both forms of re-evaluation should have run (%s)" % forms
+    hip.close()
