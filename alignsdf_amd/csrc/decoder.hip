@@ -241,23 +241,40 @@ __global__ __launch_bounds__(256) void collect_box_candidates_kernel(const float
     return box[h][6] == 0 || i0 < box[h][0] || i0 > box[h][3] || i1 < box[h][1] || i1 > box[h][4] || i2 < box[h][2] || i2 > box[h][5];
   };
   auto open = [&](float v) { return v >= -tau && v < tau; };
-  // one reservation per wave and step (a pose-aligned decoder lists up to 1e6 voxels: one atomic per voxel was 0.3 ms)
+  // The list is gathered per workgroup in LDS and handed over with ONE reservation per 8 steps: a pose-aligned decoder lists up
+  // to 1e6 voxels, and one atomic per wave and step on the single count word was 0.3 ms of same-address atomics.
+  constexpr int kSteps = 8, kLocal = kSteps * 256 * 4;
+  __shared__ int s_list[kLocal];
+  __shared__ int s_n, s_base;
   const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
   auto append = [&](bool h, long long i) {
     const unsigned long long m = __ballot(h);
     if (!m) return;
+    const int leader = __ffsll((long long)m) - 1;
     int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (h) {
-      const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (k < cap) idx[k] = (int)i;
+    if (lane == leader) base = atomicAdd(&s_n, __popcll(m));
+    base = __shfl(base, leader);
+    if (h) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;      // (at most kLocal voxels between two flushes)
+  };
+  auto flush = [&]() {
+    __syncthreads();
+    const int m = s_n;
+    if (threadIdx.x == 0 && m > 0) s_base = atomicAdd(count, m);
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+      const int k = s_base + j;
+      if (k < cap) idx[k] = s_list[j];
       else if (status) atomicAdd(status + 1, 1);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
   };
   const bool vec = (N & 3) == 0;
   const long long items = vec ? n / 4 : n;
-  const long long rounds = (items + stride - 1) / stride;              // (every lane takes every step: the appends are wave-wide)
+  const long long rounds = (items + stride - 1) / stride;              // (every thread takes every step: appends and flushes are collective)
   for (long long r = 0; r < rounds; ++r) {
     const long long q = t0 + r * stride;
     const bool live = q < items;
@@ -278,7 +295,9 @@ __global__ __launch_bounds__(256) void collect_box_candidates_kernel(const float
       if (!vec && k > 0) break;
       append(live && ((a && open(va[k]) && outside(0, i0, i1, i2 + k)) || (b && open(vb[k]) && outside(1, i0, i1, i2 + k))), i + k);
     }
+    if ((r + 1) % kSteps == 0) flush();
   }
+  flush();
 }
 
 // The candidate count decides how the candidates are re-evaluated (the host cannot know it without a wait, so both forms are
