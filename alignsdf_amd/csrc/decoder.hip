@@ -481,6 +481,61 @@ __global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict
   if (ok && at < cap) list[at] = (int)v;
 }
 
+// The AT-RISK SHELL of a one-plane sweep (round 4): of the voxels a sweep decides by sign alone, only those whose one-plane value
+// lies close to the decision threshold can be decided wrongly by an error of the allowance's order - tau <= |v| < 2 tau.  A uniform
+// draw spends a fraction of a percent of its picks there; half of the audit is therefore drawn FROM the shell: it is counted
+// (shell_count_kernel) and then listed - every shell voxel while the shell is smaller than the budget (an exhaustive check), a
+// hash-thinned uniform subset of expected size `budget` otherwise (shell_pick_kernel).  Band sweep: unmarked voxels of one head's
+// volume (unmarked implies |v| >= tau); box sweep: voxels every evaluated head leaves outside [-tau, tau), some head inside 2 tau.
+__device__ __forceinline__ bool in_audit_shell(const float* __restrict__ a, const float* __restrict__ b,
+                                               const unsigned char* __restrict__ mark, long long v, float tau) {
+  if (mark) return mark[v] == 0 && fabsf(a[v]) < 2.0f * tau;
+  bool decided = true, close = false;
+  if (a) { const float t = a[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
+  if (b) { const float t = b[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
+  return decided && close;
+}
+__global__ __launch_bounds__(256) void shell_count_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const unsigned char* __restrict__ mark, long long P, float tau, int* shell_n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int c = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P; v += stride) c += in_audit_shell(a, b, mark, v, tau) ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+  __shared__ int s_c[4];
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int t = s_c[0] + s_c[1] + s_c[2] + s_c[3]; if (t) atomicAdd(shell_n, t); }
+}
+__global__ __launch_bounds__(256) void shell_pick_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const unsigned char* __restrict__ mark, long long P, float tau,
+                                                         unsigned long long seed, int budget, const int* __restrict__ shell_n,
+                                                         int* list, int* count, int cap, int* audit_rec) {
+  const int population = *shell_n;
+  // keep every shell voxel while they fit the budget, else each with probability budget / population (a hash of the voxel index)
+  const unsigned long long thr = population <= budget ? (1ull << 32) : (unsigned long long)(((double)budget / (double)population) * 4294967296.0);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  const long long rounds = (P + stride - 1) / stride;
+  int kept = 0;
+  for (long long r = 0; r < rounds; ++r) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x + r * stride;
+    const bool ok = v < P && in_audit_shell(a, b, mark, v, tau) &&
+                    (splitmix64_dev(seed ^ ((unsigned long long)v * 0x9E3779B97F4A7C15ull)) >> 32) < thr;
+    const unsigned long long m = __ballot(ok);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    const int at = base + __popcll(m & ((1ull << lane) - 1));
+    if (ok && at < cap) { list[at] = (int)v; ++kept; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) kept += __shfl_xor(kept, m);
+  if (lane == 0 && kept) atomicAdd(audit_rec + 6, kept);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(audit_rec + 7, population);
+}
+
 // more voxels lay within the refinement threshold of the level than the list holds (status[1] != 0): bit 30 of the range word of
 // the bbox record tells the caller, who reads that record anyway
 __global__ void near_overflow_to_bbox_kernel(const int* status, int* bbox) {
@@ -554,6 +609,7 @@ struct asdf_decoder {
   int* audit_rec;   // [8]
   int* audit_idx;   // [kAuditCap]
   int* audit_count;
+  int* shell_count; // device word: population of the at-risk shell of the sweep being audited
 };
 static constexpr int kNearCap = 1 << 16;      // near-level refinement list of a split-half sweep
 static constexpr int kCandCap = 1 << 21;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
@@ -584,7 +640,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 118; }
+int asdf_version(void) { return 119; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -630,6 +686,7 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   (void)hipFree(d->audit_rec);
   (void)hipFree(d->audit_idx);
   (void)hipFree(d->audit_count);
+  (void)hipFree(d->shell_count);
   std::free(d->cst_host);
   std::free(d->cst16_host);
   delete d;
@@ -705,6 +762,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) e = hipMalloc((void**)&d->audit_rec, 8 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->audit_idx, kAuditCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->audit_count, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->shell_count, sizeof(int));
   d->audit_n = 1 << 16;
   d->audit_seed = 0x5DF5A11D00000000ull;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
@@ -894,19 +952,34 @@ int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float 
   return launch_decode(d, p, (hipStream_t)stream);
 }
 
-// the audit of a one-plane sweep (see audit_pick_kernel): draws d->audit_n decided voxels into list[*count ..] and advances the seed
+// the audit of a one-plane sweep: min(d->audit_n, P / 16) voxels the sweep decided by sign alone are appended to list[*count ..] -
+// half of them drawn uniformly (audit_pick_kernel), half from the at-risk shell (shell_count_kernel / shell_pick_kernel) - and the
+// seed advances.  The small lattices pay a sixteenth of their own size, not a sample sized for 256^3.
+static int audit_size(const asdf_decoder* d, long long P) {
+  if (d->audit_n <= 0) return 0;
+  const long long cap = P / 16 > 64 ? P / 16 : 64;
+  return (long long)d->audit_n < cap ? d->audit_n : (int)cap;
+}
 static int enqueue_audit_picks(asdf_decoder* d, const float* a, const float* b, const unsigned char* mark, long long P, float tau,
                                int* list, int* count, int cap, hipStream_t st) {
-  if (d->audit_n <= 0) return ASDF_OK;
-  const int n = (long long)d->audit_n < P / 2 ? d->audit_n : (int)(P / 2 > 0 ? P / 2 : 1);      // (a lattice smaller than the sample: half of it)
-  hipLaunchKernelGGL(audit_pick_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed, n,
+  const int n = audit_size(d, P);
+  if (n <= 0) return ASDF_OK;
+  const int uniform = n - n / 2, budget = n / 2;
+  hipLaunchKernelGGL(audit_pick_kernel, dim3((uniform + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed, uniform,
                      list, count, cap);
+  if (budget > 0) {
+    ASDF_HIP(hipMemsetAsync(d->shell_count, 0, sizeof(int), st));
+    const int sgrid = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+    hipLaunchKernelGGL(shell_count_kernel, dim3(sgrid), dim3(256), 0, st, a, b, mark, P, tau, d->shell_count);
+    hipLaunchKernelGGL(shell_pick_kernel, dim3(sgrid), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed ^ 0xA5A5A5A55A5A5A5Aull, budget,
+                       d->shell_count, list, count, cap, d->audit_rec);
+  }
   ASDF_HIP(hipGetLastError());
   d->audit_seed = d->audit_seed * 6364136223846793005ull + 1442695040888963407ull;
   return ASDF_OK;
 }
 
-// words 32..39 of the record of a one-plane sweep, gathered on the device behind the call
+// words 32..41 of the record of a one-plane sweep, gathered on the device behind the call
 __global__ void sweep_record_kernel(int* rec, const int* status, const int* near_count, const int* audit_rec) {
   const int i = threadIdx.x;
   if (i < 16) rec[16 + i] = status[i];
@@ -916,8 +989,10 @@ __global__ void sweep_record_kernel(int* rec, const int* status, const int* near
     rec[34] = audit_rec[5];
     rec[35] = audit_rec[0]; rec[36] = audit_rec[1]; rec[37] = audit_rec[2];
     rec[38] = status[1];
-    rec[39] = 0;
-    for (int k = 40; k < 48; ++k) rec[k] = 0;
+    rec[39] = audit_rec[6];          // audit picks drawn from the at-risk shell (tau <= |one-plane| < 2 tau)
+    rec[40] = audit_rec[7];          // population of that shell (summed over the heads of a band sweep)
+    rec[41] = audit_rec[3];          // sum of squared audit errors (float bits): sigma of the one-plane error = sqrt([41] / [37])
+    for (int k = 42; k < 48; ++k) rec[k] = 0;
   }
 }
 
@@ -1058,7 +1133,7 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     // the audit picks of this head - unmarked voxels, i.e. voxels marching cubes will read the SIGN of and nothing else - ride
     // behind the marked ones in the same list (positions >= audit_rec[4 + h])
     ASDF_HIP(hipMemcpyAsync(d->audit_rec + 4 + h, d->band_count + h, sizeof(int), hipMemcpyDeviceToDevice, st));
-    { const int rc = enqueue_audit_picks(d, nullptr, nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
+    { const int rc = enqueue_audit_picks(d, vols[h], nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
     // the values of the ordinary sweep at the listed voxels of this head: the split-half kernel over the list ...
     DecodeParams q = p;
     q.stream = d->stream16; q.cst = d->cst16; q.bbox = nullptr; q.neg_thr = 0.0f;

@@ -352,6 +352,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   if ((long long)blockIdx.x >= ntiles) return;
 
   const unsigned lds_ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+  // shader-clock stamps of workgroup 0 around a whole-lattice sweep (status words 12..13 begin, 14..15 end; s_memtime counts shader
+  // clocks on gfx950): ticks / the launch's HIP-event time = the clock the part actually held under this kernel, which bench.py
+  // reports next to the matrix-pipe utilisation.  Stored at once, so nothing stays live across the kernel.
+  if (!SUB && p.status && p.mode != kPointList && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(p.status + 12)[0] = clock64();
 
 #pragma unroll 1
   for (int slot = 0; slot < p.num_mlps; ++slot) {
@@ -809,12 +813,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         // with the number of picks whose sign the exact value contradicts.  Reduced over the wave on the float BITS (a NaN
         // is a huge pattern and must survive the reduction), then one set of atomics per wave.
         int dm = 0, da = 0, flips = 0, na = 0;
+        float sq = 0.0f;           // sum of squared audit errors: sigma of the one-plane error, next to its maximum
         if (valid && half == 0) {
           const bool aud = p.audit && pi >= (long long)audit_from;
           auto replace = [&](float* vol, float now) {
             const float before = vol[po];
             const int d = __float_as_int(fabsf(now - before));
-            if (aud) { da = max(da, d); flips += ((before < 0.0f) != (now < 0.0f)) ? 1 : 0; ++na; }
+            if (aud) { da = max(da, d); flips += ((before < 0.0f) != (now < 0.0f)) ? 1 : 0; ++na; sq += (now - before) * (now - before); }
             else dm = max(dm, d);
             vol[po] = now;
           };
@@ -826,10 +831,14 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         for (int m = 32; m >= 1; m >>= 1) {
           dm = max(dm, __shfl_xor(dm, m)); da = max(da, __shfl_xor(da, m));
           flips += __shfl_xor(flips, m); na += __shfl_xor(na, m);
+          if (p.audit) sq += __shfl_xor(sq, m);
         }
         if (lane == 0) {
           if (p.status && dm) atomicMax(p.status + 3, dm);
-          if (p.audit && na) { atomicMax(p.audit + 0, da); if (flips) atomicAdd(p.audit + 1, flips); atomicAdd(p.audit + 2, na); }
+          if (p.audit && na) {
+            atomicMax(p.audit + 0, da); if (flips) atomicAdd(p.audit + 1, flips); atomicAdd(p.audit + 2, na);
+            atomicAdd(reinterpret_cast<float*>(p.audit + 3), sq);
+          }
         }
       } else if (valid && half == 0) {
         float* out = is_hand ? p.sdf0 : p.sdf1;
@@ -914,6 +923,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     }
   }   // MLPs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!SUB && p.status && p.mode != kPointList && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(p.status + 12)[1] = clock64();
 }
 
 // The __global__ instantiations live in k1h_kernels.hip; tools/k1h_ablate.hip instantiates its own.

@@ -51,13 +51,66 @@ def physical_cores():
     return len(cores) or len(allowed) or 1
 
 
-def limit_host_threads(world_size, reserve=0):
-    """One rank's share of the host: torch's intra-op pool (and OMP / MKL for anything started later) is capped at
-    physical_cores // world_size.  The host tail of a sample (surface sampling, OBJ parsing, PLY export) is numpy / torch CPU work
-    that defaults to one thread per LOGICAL CPU in every process - eight ranks with 256 threads each on a 128-core box fight over
-    the cores and each other's caches.  ASDF_HOST_THREADS overrides.  Returns the thread count set."""
+def core_blocks(world_size):
+    """The CPUs this process may run on, grouped by physical core and cut into `world_size` CONTIGUOUS blocks of cores (package-
+    major order, so a block stays inside one socket / NUMA node wherever the division allows): block r = the logical CPUs of the
+    cores rank r owns.  Falls back to blocks of logical CPUs when /proc/cpuinfo has no topology."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores, cpu, pkg = {}, None, 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key = key.strip()
+                if key == "processor":
+                    cpu, pkg = int(val), 0
+                elif key == "physical id":
+                    pkg = int(val)
+                elif key == "core id" and cpu in allowed:
+                    cores.setdefault((pkg, int(val)), []).append(cpu)
+    except (OSError, ValueError):
+        cores = {}
+    units = [sorted(v) for _, v in sorted(cores.items())] if cores else [[c] for c in allowed]
+    world_size = max(1, int(world_size))
+    per = len(units) // world_size
+    if per < 1:                                    # more ranks than cores: round-robin single cores (oversubscribed whatever is done)
+        return [list(units[r % len(units)]) for r in range(world_size)]
+    blocks = []
+    for r in range(world_size):
+        hi = (r + 1) * per if r != world_size - 1 else len(units)
+        blocks.append(sorted(c for u in units[r * per:hi] for c in u))
+    return blocks
+
+
+def bind_host_cores(world_size, local_rank):
+    """Pin this rank - and every thread and child process it starts afterwards: the intra-op pools, the PLY writer thread, the
+    ground-truth worker process (alignsdf_amd/gt_worker.py), which inherit the mask - to ITS block of cores (core_blocks).  Eight
+    ranks on one host then never migrate onto each other's cores or caches.  A no-op for a single rank, when ASDF_NO_CORE_BINDING
+    is set, or where the platform has no sched_setaffinity.  Returns the CPU list bound to (None when nothing was bound)."""
+    if int(world_size) <= 1 or os.environ.get("ASDF_NO_CORE_BINDING") or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = core_blocks(world_size)[int(local_rank) % int(world_size)]
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return cpus
+
+
+def limit_host_threads(world_size, reserve=2, local_rank=None):
+    """One rank's share of the host: with `local_rank` given the rank is first BOUND to its block of cores (bind_host_cores); then
+    torch's intra-op pool (and OMP / MKL for anything started later) is capped at the cores of the share minus `reserve` - two cores
+    stay free for the rank's ground-truth worker process and its writer / loader threads, which run next to the pool.  The host tail
+    of a sample (surface sampling, OBJ parsing, PLY export) is numpy / torch CPU work that defaults to one thread per LOGICAL CPU in
+    every process - eight ranks with 256 threads each on a 128-core box fight over the cores and each other's caches.
+    ASDF_HOST_THREADS overrides the count.  Returns the thread count set."""
+    bound = bind_host_cores(world_size, local_rank) if local_rank is not None else None
+    share = physical_cores() if bound else physical_cores() // max(1, int(world_size))      # (bound: the cores of the mask just set)
     n = os.environ.get("ASDF_HOST_THREADS")
-    n = int(n) if n else max(1, physical_cores() // max(1, int(world_size)) - reserve)
+    n = int(n) if n else max(1, share - int(reserve))
     torch.set_num_threads(n)
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ[var] = str(n)
@@ -100,7 +153,7 @@ def run_sharded(num_items, process_range, backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         backend = os.environ.get("ASDF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
-    limit_host_threads(world)
+    limit_host_threads(world, local_rank=local_rank)
     if torch.cuda.is_available():
         # explicit rank -> device binding (the reference's thread race on the GPU index, dist_reconstruct.py:21, cannot
         # happen); ASDF_SHARE_DEVICE=1 folds the ranks onto the available devices for single-GPU testing over gloo

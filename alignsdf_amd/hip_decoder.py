@@ -34,6 +34,13 @@ REC_WORDS = 48                # record of a one-plane sweep (include/alignsdf_hi
 # between the tail-corrected estimate and the bound that must hold for every voxel
 TAU_FACTOR = 5.0
 TAU_ACCEPT = 0.6
+# The whole-lattice comparison that calibrates the allowance (one ordinary + one plain one-plane sweep of the coarse lattice, all
+# 2 N^3 values compared) is REPEATED every RECAL_EVERY coarse passes of a decoder - the tail ratio (lattice maximum / maximum of a
+# sample of the audit's size), i.e. how far the largest error can hide from a sample, is a measured quantity that is never older
+# than that - and on the coarse pass that follows any sweep refused for its error.  A tail ratio above TAIL_MAX means the error has
+# rare large outliers a sample cannot see: the one-plane sweeps are switched off for that decoder.
+RECAL_EVERY = 64
+TAIL_MAX = 3.0
 
 
 def _effective(module_sd, name):
@@ -216,6 +223,11 @@ class HipSdfDecoder:
                               "asdf_decoder_set_classifier")
             self.num_class = int(cw.shape[0])
         self._pf = pf
+        self._init_sweep_state()
+
+    def _init_sweep_state(self):
+        """Everything the sweep state machine keeps on the host (arithmetic in use, calibration of the activation scales, modes,
+        allowance, counters): no device involved beyond set_math, so tests/test_sweep_state_machine.py can drive it on the CPU."""
         # arithmetic of the hidden GEMMs: "f32" (fp32 MFMA chain) or "f16x3" (split-half fp16 MFMA, fp32-class results);
         # ASDF_MATH overrides the default
         self.math = "f32"
@@ -257,10 +269,18 @@ class HipSdfDecoder:
         self._box_epoch = -1
         self._box_failures = 0
         self._tail = 1.0
+        self._tail_by_n = {}         # tail ratio per uniform sample size (a ladder of powers of two), from the last calibration
+        self._cal_points = 0         # lattice size of the last calibration: a much larger lattice needs its own
+        self._coarse_since_cal = 0
         self._err_window = collections.deque(maxlen=16)
         self.audit_voxels = AUDIT_VOXELS
+        # what the certificate of the one-plane sweeps rests on, as measured (bench.py prints it as the `certificate` block)
+        self.cert = {"calibrations": 0, "tail_ratio": None, "tail_ratio_max": None, "lattice_max_error": None, "lattice_sigma": None,
+                     "lattice_max_over_sigma": None, "neighbour_correlation": None, "audited_sweeps": 0, "shell_picks": 0,
+                     "shell_population_max": 0, "uniform_picks": 0, "min_margin_tau_over_estimate": None, "min_tau_over_sigma": None,
+                     "audit_sigma_max": None, "refusals_for_error": 0}
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
-        self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps
+        self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps, plus the sweep's record tensor
 
     @staticmethod
     def _new_stats(kind):
@@ -538,20 +558,43 @@ class HipSdfDecoder:
                              ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
                              so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()), name)
             if ev is not None:
-                self.box_event_log.append(ev)
+                self.box_event_log.append(ev + (rec,))      # (words 28..31 of the record: shader-clock stamps of the sweep kernel)
         return rec, sh, so
 
-    def _judge(self, r, tau, stats, cap_word, cap):
+    @staticmethod
+    def audit_sizes(audit_voxels, points):
+        """(uniform picks, shell budget) per sweep and head on a lattice of `points` voxels - csrc/decoder.hip: audit_size."""
+        if audit_voxels <= 0:
+            return 0, 0
+        n = int(min(audit_voxels, max(points // 16, 64)))
+        return n - n // 2, n // 2
+
+    def _tail_for(self, points):
+        """Tail ratio for the uniform half of an audit on a lattice of `points` voxels: the calibration's entry for the largest
+        sample size not above it (a smaller sample sees less of the tail: conservative)."""
+        uniform, _ = self.audit_sizes(self.audit_voxels, points)
+        best = None
+        for n, t in self._tail_by_n.items():
+            if n <= max(uniform, 1) and (best is None or n > best[0]):
+                best = (n, t)
+        return best[1] if best is not None else self._tail
+
+    def _judge(self, r, tau, stats, cap_word, cap, points=None):
         """Verdict on the record of one one-plane sweep launched with allowance tau: (accepted, range violations, reason).
         Accepted = no fp16 range violation, every list within its capacity, no contradiction, the largest |exact - one-plane| over
         the re-evaluated voxels AND the audit's estimate of the lattice maximum within TAU_ACCEPT x tau, and no audit voxel whose sign the
-        exact value contradicts.  The audit's estimate enters the allowance of the sweeps that follow."""
+        exact value contradicts.  The estimate of an ACCEPTED sweep enters the allowance of the sweeps that follow; a sweep refused for
+        its error invalidates the allowance instead: the next coarse pass measures the whole lattice again (a refusal
+        must not inflate the allowance by itself)."""
         bad, near_over = self._range_words(r)
         f = lambda w: float(np.int32(r[w]).view(np.float32))
         err, audit = f(19), f(35)
         flips, evals = int(r[36]), int(r[37])
+        shell_picks, shell_pop, sumsq = int(r[39]), int(r[40]), f(41)
         listed = max(int(r[w]) for w in cap_word)
-        est = audit * self._tail
+        tail = self._tail_for(points) if points else self._tail
+        est = audit * tail
+        sigma = float(np.sqrt(sumsq / evals)) if evals > 0 and np.isfinite(sumsq) and sumsq >= 0 else float("nan")
         stats["max_err"] = max(stats["max_err"], err)
         stats["audit_max_err"] = max(stats["audit_max_err"], audit)
         stats["audit_evals"] += evals
@@ -560,7 +603,7 @@ class HipSdfDecoder:
         stats[key] = max(stats[key], listed)
         stats["tau_min"] = tau if stats["tau_min"] is None else min(stats["tau_min"], tau)
         stats["tau_max"] = tau if stats["tau_max"] is None else max(stats["tau_max"], tau)
-        reason = None
+        reason, for_error = None, False
         if bad:
             reason = "%d activations left the fp16 range" % bad
         elif listed > cap:
@@ -568,19 +611,33 @@ class HipSdfDecoder:
         elif near_over or int(r[38]):
             reason = "near-level list overflowed"
         elif int(r[18]):
-            reason = "a voxel taken as certainly negative was not"
+            reason, for_error = "a voxel taken as certainly negative was not", True
         elif flips:
-            reason = "%d of %d audit voxels have the other sign" % (flips, evals)
+            reason, for_error = "%d of %d audit voxels have the other sign" % (flips, evals), True
         elif not (err <= TAU_ACCEPT * tau):
-            reason = "error %.3g on the re-evaluated voxels against allowance %.3g" % (err, tau)
+            reason, for_error = "error %.3g on the re-evaluated voxels against allowance %.3g" % (err, tau), True
         elif not (est <= TAU_ACCEPT * tau):
-            reason = "audit error %.3g (x tail %.2f) against allowance %.3g" % (audit, self._tail, tau)
+            reason, for_error = "audit error %.3g (x tail %.2f) against allowance %.3g" % (audit, tail, tau), True
         elif self.audit_voxels and evals == 0:
             reason = "the audit evaluated nothing"
-        if not bad and np.isfinite(est) and np.isfinite(err):
-            # per-sweep re-estimate of the lattice maximum: the next sweeps' allowance follows the samples
-            self._err_window.append(max(est, err, 2.5e-7))
-            self._box_tau = self._tau_current()
+        c = self.cert
+        if reason is None:
+            if np.isfinite(est) and np.isfinite(err):
+                # per-sweep re-estimate of the lattice maximum: the next sweeps' allowance follows the samples
+                self._err_window.append(max(est, err, 2.5e-7))
+                self._box_tau = self._tau_current()
+            c["audited_sweeps"] += 1
+            c["shell_picks"] += shell_picks
+            c["shell_population_max"] = max(c["shell_population_max"], shell_pop)
+            c["uniform_picks"] += max(evals - shell_picks, 0)
+            worst = max(est, err, 2.5e-7)
+            c["min_margin_tau_over_estimate"] = tau / worst if c["min_margin_tau_over_estimate"] is None else min(c["min_margin_tau_over_estimate"], tau / worst)
+            if np.isfinite(sigma) and sigma > 0:
+                c["min_tau_over_sigma"] = tau / sigma if c["min_tau_over_sigma"] is None else min(c["min_tau_over_sigma"], tau / sigma)
+                c["audit_sigma_max"] = sigma if c["audit_sigma_max"] is None else max(c["audit_sigma_max"], sigma)
+        elif for_error:
+            c["refusals_for_error"] += 1
+            self._box_epoch = -1          # the allowance is void until the next coarse pass has measured the whole lattice again
         return reason is None, bad, near_over, reason
 
     # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
@@ -592,17 +649,22 @@ class HipSdfDecoder:
     def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
         return self._one_plane_launch(self._L.asdf_decode_grid_box, "asdf_decode_grid_box", N, origin3, voxel_size, grid_mode, hand, obj, tau)
 
-    def _allowance_valid(self):
-        return self._box_tau is not None and self._box_epoch == self._recalibrations
+    def _allowance_valid(self, N=None):
+        """The allowance was measured under the current activation scales, no sweep has been refused for its error since, and the
+        lattice it was measured on is not much smaller than the one to be swept (the largest of 64 x as many errors is larger)."""
+        return (self._box_tau is not None and self._box_epoch == self._recalibrations and
+                (N is None or int(N) ** 3 <= 8 * self._cal_points))
 
     def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
         """Enqueue the coarse pass of one sample; returns a ticket for coarse_finish."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
-        if self._box_usable() and self._allowance_valid() and not self._force_f32_once:
+        self._coarse_since_cal += 1
+        due = self._coarse_since_cal > RECAL_EVERY          # the periodic whole-lattice re-measurement: this pass runs both ways
+        if self._box_usable() and self._allowance_valid(N) and not self._force_f32_once and not due:
             rec, sh, so = self._box_launch(*args, self._box_tau)
             return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": self._box_tau, "epoch": self._recalibrations}
         h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
-        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
+        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations, "recalibrate": due}
 
     def coarse_finish(self, ticket):
         """int32[16] host record of the coarse pass (words 0..5 / 8..13: boxes of the negative voxels; 6 / 14: non-zero
@@ -616,7 +678,7 @@ class HipSdfDecoder:
             if ticket["epoch"] != self._recalibrations:
                 ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
             else:
-                ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP)
+                ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP, points=int(N) ** 3)
             if ok:
                 self.box_stats["box"] += 1
                 self._box_failures = 0              # (three refusals IN A ROW switch the mode off)
@@ -628,7 +690,9 @@ class HipSdfDecoder:
                 logging.warning("box-only coarse sweep not accepted (%s): repeated as an ordinary sweep", reason)
                 if ticket["epoch"] == self._recalibrations:
                     self._box_failures += 1
-                    calibrate_allowance = False
+                    # refused for its error: the allowance is void (_judge) and is measured again below, on this very lattice;
+                    # refused for a capacity / list overflow: the allowance stands
+                    calibrate_allowance = not self._allowance_valid(N)
                 if self._box_failures >= 3:
                     logging.warning("box-only coarse sweep switched off for this decoder")
                     self.coarse_mode = "exact"
@@ -642,7 +706,7 @@ class HipSdfDecoder:
         self.box_stats["exact"] += 1
         # the error allowance of the one-plane kernel (shared by the box-only coarse sweep and the narrow-band fine sweep) is
         # calibrated here, on the coarse lattice, while the decoder is bound to this sample
-        if (self._box_usable() or self._band_usable()) and calibrate_allowance and not self._allowance_valid():
+        if (self._box_usable() or self._band_usable()) and calibrate_allowance and (not self._allowance_valid(N) or ticket.get("recalibrate")):
             self._calibrate_box(ticket["args"], keep)
         b = b.copy()
         b[7] &= NEAR_OVERFLOW_BIT - 1
@@ -659,7 +723,7 @@ class HipSdfDecoder:
         mc_only=True declares that the volumes go to marching cubes at level 0 and nowhere else: only then may a decoder
         set to fine_mode "band" deliver them exact next to the surface and sign-correct elsewhere."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
-        if mc_only and self._band_usable() and not self._band_skip and self._allowance_valid() and not self._force_f32_once:
+        if mc_only and self._band_usable() and not self._band_skip and self._allowance_valid(N) and not self._force_f32_once:
             rec, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band, "asdf_decode_grid_band", N, origin3, voxel_size,
                                                  grid_mode, hand, obj, self._box_tau)
             return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau, "epoch": self._recalibrations}
@@ -676,9 +740,11 @@ class HipSdfDecoder:
             import logging
             r = ticket["rec"].cpu().numpy()
             if ticket["epoch"] != self._recalibrations:
-                ok, bad, near_over, reason = False, 0, False, "launched under activation scales that have been re-calibrated since"
+                # not judged: its error says nothing about the current scales.  (A near-level list that overflowed is a property of
+                # the SAMPLE - refine_tau is absolute - and is honoured: the repeat runs on the fp32 chain.)
+                ok, bad, near_over, reason = False, 0, self._range_words(r)[1], "launched under activation scales that have been re-calibrated since"
             else:
-                ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP)
+                ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP, points=int(ticket["args"][0]) ** 3)
             if ok:
                 self.band_stats["band"] += 1
                 self._band_failures = 0
@@ -704,38 +770,79 @@ class HipSdfDecoder:
         return False
 
     def _calibrate_box(self, args, exact_vols):
-        """Error allowance of the one-plane sweep for this decoder and scale set, from one whole coarse sweep run both ways:
-        TAU_FACTOR x the largest |one-plane - split-half| over every voxel (2 x N^3 values).  A random sample of the audit's size from the
-        same differences gives the tail ratio (lattice maximum / sample maximum) with which the audits of later sweeps estimate
-        THEIR lattice maximum."""
+        """Error allowance of the one-plane sweep for this decoder and scale set, from one whole coarse sweep run both ways: every one
+        of the 2 x N^3 one-plane values against the ordinary sweep's.  Measured: the lattice maximum of |one-plane - split-half|, its
+        rms (sigma), the correlation of the signed error between x-neighbours (noise-like = near 0), and the TAIL RATIO - lattice
+        maximum / maximum of a uniform sample - for a ladder of sample sizes, with which the audits of later sweeps estimate THEIR
+        lattice maximum.  Runs on the first coarse pass of a decoder and scale epoch, on the coarse pass after a sweep refused for
+        its error, and every RECAL_EVERY coarse passes (tail regularity is re-measured, not assumed)."""
         import logging
         audit = self.audit_voxels
+        N = int(args[0])
         self.set_audit(0)                                      # (the audit would overwrite its picks with exact values)
         rec, sh, so = self._box_launch(*args, 1e-7)            # (a tiny allowance: next to no candidates, plain one-plane values)
         self._audit_restarts = getattr(self, "_audit_restarts", 0) + 1
         self.set_audit(audit, seed=0x5DF5A11D00000000 + 0x9E3779B9 * self._audit_restarts)
-        err, sample = 0.0, 0.0
+        err, sumsq, count, corr = 0.0, 0.0, 0, 0.0
+        ladder = [1 << k for k in range(5, 18)]
+        sample_max = np.zeros(len(ladder))
         gen = torch.Generator(device=self.device)
-        gen.manual_seed(12345)
+        gen.manual_seed(12345 + self._audit_restarts)
         for fast, exact in zip((sh, so), exact_vols):
             if fast is not None and exact is not None:
-                diff = (fast - exact).abs().reshape(-1)
+                signed = (fast - exact).reshape(-1)
+                diff = signed.abs()
                 err = max(err, float(diff.max().item()))
-                n = min(max(audit, 1), max(diff.numel() // 2, 1))
-                pick = torch.randint(0, diff.numel(), (n,), device=self.device, generator=gen)
-                sample = max(sample, float(diff[pick].max().item()))
+                sumsq += float((signed.double() ** 2).sum().item())
+                count += diff.numel()
+                e3 = signed.reshape(N, N, N)
+                a, b = e3[:, :, :-1].reshape(-1).double(), e3[:, :, 1:].reshape(-1).double()
+                va, vb = a - a.mean(), b - b.mean()
+                den = float((va.norm() * vb.norm()).item())
+                corr = max(corr, abs(float((va * vb).sum().item()) / den) if den > 0 else 0.0)
+                pick = torch.randint(0, diff.numel(), (ladder[-1],), device=self.device, generator=gen)
+                running = torch.cummax(diff[pick], 0).values
+                sample_max = np.maximum(sample_max, running[torch.tensor([n - 1 for n in ladder], device=self.device)].cpu().numpy())
+        self._coarse_since_cal = 0
         self._box_epoch = self._recalibrations
-        self._err_window.clear()
+        self._cal_points = N ** 3
+        fresh = self.cert["calibrations"] == 0 or not self._err_window
+        if fresh:
+            self._err_window.clear()
         if not np.isfinite(err) or TAU_FACTOR * err > 0.05:
             logging.warning("one-plane sweeps: error %.3g too large, switched off for this decoder", err)
             self.coarse_mode = self.fine_mode = "exact"
             self._box_tau = None
             return
-        self._tail = float(np.clip(err / sample, 1.0, 4.0)) if sample > 0 and np.isfinite(sample) else 2.0
+        tails = {n: float(np.clip(err / m, 1.0, 1e3)) if m > 0 and np.isfinite(m) else 2.0 for n, m in zip(ladder, sample_max)}
+        uniform, _ = self.audit_sizes(audit, N ** 3)
+        self._tail_by_n = tails
+        self._tail = self._tail_for(N ** 3) if uniform else 1.0
+        sigma = float(np.sqrt(sumsq / max(count, 1)))
+        c = self.cert
+        c["calibrations"] += 1
+        c["tail_ratio"] = self._tail
+        c["tail_ratio_max"] = self._tail if c["tail_ratio_max"] is None else max(c["tail_ratio_max"], self._tail)
+        c["lattice_max_error"], c["lattice_sigma"] = err, sigma
+        c["lattice_max_over_sigma"] = err / sigma if sigma > 0 else None
+        c["neighbour_correlation"] = corr
+        if self._tail > TAIL_MAX:
+            logging.warning("one-plane sweeps: the lattice maximum %.3g is %.1f x what a sample of %d sees - rare large errors a sample "
+                            "cannot certify; switched off for this decoder", err, self._tail, uniform)
+            self.coarse_mode = self.fine_mode = "exact"
+            self._box_tau = None
+            return
         self._err_window.append(max(err, 2.5e-7))
         self._box_tau = self._tau_current()
-        logging.info("one-plane sweeps: lattice error %.3g, sample of %d per head %.3g (tail ratio %.2f), allowance %.3g", err, audit,
-                     sample, self._tail, self._box_tau)
+        logging.info("one-plane sweeps: lattice error max %.3g sigma %.3g (max / sigma %.1f, x-neighbour correlation %.3f), sample of %d "
+                     "per head: tail ratio %.2f, allowance %.3g", err, sigma, err / max(sigma, 1e-30), corr, uniform, self._tail, self._box_tau)
+
+    def certificate(self):
+        """What the default sweeps' certificate rests on, as measured so far on this decoder."""
+        out = dict(self.cert)
+        out.update(tau_factor=TAU_FACTOR, tau_accept=TAU_ACCEPT, recalibrate_every=RECAL_EVERY, tail_max=TAIL_MAX,
+                   allowance_now=self._box_tau, audit_voxels=self.audit_voxels)
+        return out
 
     def decode_points(self, xyz):
         """Both heads on explicit normalised points [M,3]. Returns (hand [M], obj [M]) device tensors."""

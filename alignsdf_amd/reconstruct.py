@@ -24,13 +24,13 @@ from .utils import mesh as mesh_utils
 
 
 def synthetic_code_source(tag="nerf3", device="cuda"):
-    """Deterministic per-sample codes (64 distinct samples, cycled)."""
+    """Deterministic per-sample codes (64 distinct samples, cycled; the grasp family: its 16 trained scenes)."""
     def source(name, index):
-        s = index % 64
-        lat = torch.from_numpy(synthetic.latent_code(s)).to(device)
-        if tag == "nerf3":
+        s = index % (synthetic.GRASP_SAMPLES if tag in synthetic.GRASP_TAGS else 64)
+        lat, m, o = synthetic.sample_inputs(tag, s)
+        lat = torch.from_numpy(lat).to(device)
+        if m is None:
             return lat, None, None
-        m, o = synthetic.pose_inputs(s)
         return lat, {k: torch.from_numpy(v).to(device) for k, v in m.items()}, {k: torch.from_numpy(v).to(device) for k, v in o.items()}
     return source
 

@@ -75,8 +75,9 @@ def test_host_thread_share():
         cores = physical_cores()
         assert 1 <= cores <= (os.cpu_count() or 1)
         for world in (1, 2, 8, 1024):
-            n = limit_host_threads(world)
-            assert n == max(1, cores // world) == torch.get_num_threads() and os.environ["OMP_NUM_THREADS"] == str(n)
+            n = limit_host_threads(world)              # (two cores of the share stay free for the worker process / writer thread)
+            assert n == max(1, cores // world - 2) == torch.get_num_threads() and os.environ["OMP_NUM_THREADS"] == str(n)
+            assert limit_host_threads(world, reserve=0) == max(1, cores // world)
         os.environ["ASDF_HOST_THREADS"] = "3"
         assert limit_host_threads(8) == 3
     finally:
@@ -105,6 +106,10 @@ def host_tail(i):
         m = torch.tanh(m @ m * 1e-3)
     return float(m.sum())
 def process(start, end, rank):
+    # the core set run_sharded bound this rank to - and what a child process started now (the ground-truth worker's position) gets
+    import subprocess
+    child = subprocess.run([sys.executable, "-c", "import os; print(sorted(os.sched_getaffinity(0)))"], capture_output=True, text=True).stdout
+    json.dump({"self": sorted(os.sched_getaffinity(0)), "child": json.loads(child)}, open(sys.argv[2] + ".aff%%d" %% rank, "w"))
     host_tail(10 ** 6)                              # warm up the pools
     t0 = time.perf_counter()
     for i in range(start, end):
@@ -128,7 +133,7 @@ def test_eight_ranks_do_not_oversubscribe_the_host(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(HOST_TAIL_WORKER % {"root": ROOT})
     per_rank = 6
-    share = max(1, physical_cores() // 8)
+    share = max(1, physical_cores() // 8 - 2)          # two cores of a rank's block stay free for its worker process and writer thread
 
     def run(world, extra_env):
         out = tmp_path / ("merged_%d.json" % world)
@@ -139,10 +144,16 @@ def test_eight_ranks_do_not_oversubscribe_the_host(tmp_path):
         subprocess.run(cmd, check=True, timeout=600, env=env, cwd=ROOT)
         merged = json.load(open(out))
         assert len(merged) == per_rank * world
-        return max(m["milliseconds"] for m in merged), {m["V_hand"] for m in merged}
+        masks = [json.load(open(str(out) + ".aff%d" % r)) for r in range(world)]
+        return max(m["milliseconds"] for m in merged), {m["V_hand"] for m in merged}, masks
 
-    single, threads1 = run(1, {"ASDF_HOST_THREADS": str(share)})       # one rank on the share a rank of eight gets
-    eight, threads8 = run(8, {})
+    single, threads1, _ = run(1, {"ASDF_HOST_THREADS": str(share)})    # one rank on the share a rank of eight gets
+    eight, threads8, masks = run(8, {})
     assert threads1 == {share} and threads8 == {share}                 # run_sharded set every rank's pool to its share
+    # every rank - and a child process it starts, like its ground-truth worker - is bound to its OWN contiguous block of cores
+    from alignsdf_amd.dist_reconstruct import core_blocks
+    assert [m["self"] for m in masks] == core_blocks(8) and all(m["child"] == m["self"] for m in masks)
+    seen = [c for m in masks for c in m["self"]]
+    assert len(seen) == len(set(seen))                                  # disjoint
     print("host tail: 1 rank %.0f ms, slowest of 8 ranks %.0f ms" % (single, eight))
     assert eight <= 1.5 * single + 50.0, (single, eight)

@@ -40,11 +40,12 @@ def _meshes(tag, N, samples, monkeypatch, coarse=None, fine=None, math=None):
     return out, hip
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "grasp3", "grasp9"])
 def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, monkeypatch):
-    """N = 256 (BASELINE configs[2] / configs[4]'s decoder), all 64 synthetic samples: torch.equal on vertices and faces."""
+    """N = 256 (BASELINE configs[2] / configs[4]'s decoder), all 64 synthetic samples - and all 16 scenes of the GRASP family
+    (decoders with every layer trained, hands closing on objects in contact): torch.equal on vertices and faces."""
     N = 256
-    samples = list(range(64))
+    samples = list(range(syn.GRASP_SAMPLES if tag in syn.GRASP_TAGS else 64))
     want, _ = _meshes(tag, N, samples, monkeypatch, coarse="exact", fine="exact")
     got, hip = _meshes(tag, N, samples, monkeypatch)                     # the defaults
     assert (hip.coarse_mode, hip.fine_mode) == ("box", "band") and hip.math == "f16x3"
@@ -54,13 +55,18 @@ def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, 
         for k in (2, 3, 4, 5):
             assert torch.equal(a[k], b[k]), (s, k)
     # sample 0's coarse pass calibrated the allowance on an ordinary sweep; everything else ran on the one-plane kernel
-    assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 64, (hip.box_stats, hip.band_stats)
+    n = len(samples)
+    assert hip.box_stats["box"] == n - 1 and hip.band_stats["band"] == n, (hip.box_stats, hip.band_stats)
     assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     # the audit ran in every sweep (voxels x heads), found no sign contradiction, and its error stayed inside the allowance
-    assert hip.box_stats["audit_evals"] >= 63 * 2 * 60000 and hip.band_stats["audit_evals"] >= 64 * 2 * 60000
+    # (half of the 65 536 picks per head are uniform, half come from the at-risk shell - as many as it holds)
+    assert hip.box_stats["audit_evals"] >= (n - 1) * 2 * 30000 and hip.band_stats["audit_evals"] >= n * 2 * 30000
+    cert = hip.certificate()
+    assert cert["shell_picks"] > 0 and cert["calibrations"] == 1 and cert["refusals_for_error"] == 0
+    assert cert["min_margin_tau_over_estimate"] >= 1.0 / 0.6 and cert["tail_ratio"] <= 3.0
     assert hip.box_stats["audit_flips"] == 0 and hip.band_stats["audit_flips"] == 0
     assert 0.0 < hip.band_stats["audit_max_err"] * hip._tail <= 0.6 * hip.band_stats["tau_max"]
-    print(tag, "box", hip.box_stats, "band", hip.band_stats, "tail", hip._tail)
+    print(tag, "box", hip.box_stats, "band", hip.band_stats, "certificate", cert)
 
 
 def test_default_meshes_have_the_faces_of_the_fp32_chain(monkeypatch):
@@ -116,8 +122,16 @@ def test_audit_record_of_the_c_abi():
     marked = (int(r1[33]), int(r1[34]))
     assert all(0 < m < N ** 3 // 2 for m in marked)
     assert int(r1[36]) == 0                                         # no audited voxel has the other sign
-    assert 2 * 65536 * 0.75 <= int(r1[37]) <= 2 * 65536             # picks that fell on marked voxels are dropped
+    # the audit of a 96^3 lattice: 96^3 / 16 = 55 296 voxels per head - half drawn uniformly (picks that fell on marked voxels are
+    # dropped), half from the at-risk shell (unmarked, tau <= |one-plane| < 2 tau: all of it while it is smaller than the budget)
+    uniform, budget = HipSdfDecoder.audit_sizes(1 << 16, N ** 3)
+    assert (uniform, budget) == (27648, 27648)
+    shell_picks, shell_population = int(r1[39]), int(r1[40])
+    assert 0 < shell_picks <= 2 * budget + 64 and shell_population >= shell_picks
+    assert 2 * uniform * 0.75 + shell_picks <= int(r1[37]) <= 2 * uniform + shell_picks
     assert 0.2 * lattice_max <= f(r1[35]) <= lattice_max + 1e-6
+    sigma = (f(r1[41]) / int(r1[37])) ** 0.5                        # rms of the audit's errors next to their maximum
+    assert 0.0 < sigma < f(r1[35]) and f(r1[35]) / sigma < 12.0
     assert f(r1[19]) <= lattice_max + 1e-6
     hip.set_audit(1 << 16, seed=1234)
     _, _, r2 = _raw_band(hip, N, origin, vs, tau)
@@ -144,10 +158,10 @@ def test_python_layer_refuses_on_the_audit_alone():
     hip.set_sample(lat(1))
     real_judge = hip._judge
 
-    def judge_without_marked_error(r, tau, stats, cap_word, cap):
+    def judge_without_marked_error(r, tau, stats, cap_word, cap, **kw):
         r = r.copy()
         r[19] = 0                              # pretend the re-evaluated voxels showed no error at all
-        return real_judge(r, tau, stats, cap_word, cap)
+        return real_judge(r, tau, stats, cap_word, cap, **kw)
 
     hip._judge = judge_without_marked_error
     hip._box_tau = honest / 32.0
@@ -156,7 +170,40 @@ def test_python_layer_refuses_on_the_audit_alone():
     assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * hip._tail > 0.6 * honest / 32.0
     bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
     assert ticket["kind"] == "exact" and not hip.fine_needs_repeat(ticket)
-    assert hip._box_tau > honest / 32.0        # the refused sweep's audit went into the allowance
+    # a sweep refused for its error does not inflate the allowance by itself: the allowance is VOID until the next
+    # coarse pass has compared the whole lattice again
+    assert not hip._allowance_valid() and hip.certificate()["refusals_for_error"] == 1
+    _, _, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "exact"
+    hip._judge = real_judge
+    t = hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+    assert t["kind"] == "exact"
+    hip.coarse_finish(t)
+    assert hip._allowance_valid() and hip.certificate()["calibrations"] == 2 and 0.25 * honest <= hip._box_tau <= 4.0 * honest
+    _, _, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+    assert ticket["kind"] == "band" and not hip.fine_needs_repeat(ticket)
+    hip.close()
+
+
+def test_whole_lattice_recalibration_is_periodic(monkeypatch):
+    """the tail ratio is re-measured every RECAL_EVERY coarse passes (here 5), not once per decoder - that pass
+    runs an ordinary sweep next to a plain one-plane one and compares all 2 N^3 values; its boxes are the ordinary sweep's."""
+    from alignsdf_amd import hip_decoder as hd
+    monkeypatch.setattr(hd, "RECAL_EVERY", 5)
+    hip = hd.HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
+    N = 64
+    kinds = []
+    for s in range(13):
+        hip.set_sample(torch.from_numpy(syn.latent_code(s)).cuda())
+        t = hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+        kinds.append(t["kind"])
+        hip.coarse_finish(t)
+    assert kinds == ["exact"] + ["box"] * 5 + ["exact"] + ["box"] * 5 + ["exact"]
+    cert = hip.certificate()
+    assert cert["calibrations"] == 3 and 1.0 <= cert["tail_ratio"] <= cert["tail_ratio_max"] <= 3.0
+    assert cert["lattice_max_over_sigma"] > 1.0 and 0.0 <= cert["neighbour_correlation"] < 1.0
+    assert hip.box_stats["fallback"] == 0
+    print("certificate after 3 whole-lattice comparisons:", cert)
     hip.close()
 
 

@@ -1,0 +1,325 @@
+"""The sweep state machine of alignsdf_amd.hip_decoder.HipSdfDecoder as a TABLE, on the CPU.
+
+Which kernels evaluate a lattice is decided on the host from 48-word records the sweeps leave behind: coarse_begin / coarse_finish,
+fine_begin / fine_needs_repeat, _judge, fall_back_if_overflowed, decode_grid's one-sweep-on-the-fp32-chain switch - 250 lines of
+interacting flags (_band_skip, _force_f32_once, scale epochs, allowance epochs, failure counters).  Here the REAL methods run
+against a stand-in for libalignsdf_hip.so that logs every launch (entry point, arithmetic in force) and hands back scripted
+records: every refusal reason of _judge x {fresh ticket, ticket launched under activation scales re-calibrated since}, for the
+coarse and the fine pass, and what must come out whatever path ran - the reference's flow needs boxes from pass 1 and two volumes
+from pass 2 (utils/mesh.py:46-63, :98-115) - i.e. which launch comes NEXT."""
+import contextlib
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import hip_decoder as hd
+
+N = 32
+ARGS = (N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+F = lambda x: int(np.float32(x).view(np.int32))
+
+
+def good_record(tau):
+    """Record of an accepted one-plane sweep: boxes present, error on the re-evaluated voxels and audit error a tenth of tau."""
+    r = np.zeros(48, dtype=np.int32)
+    r[0:3], r[3:6], r[6] = (3, 4, 5), (20, 21, 22), 1
+    r[8:11], r[11:14], r[14] = (6, 7, 8), (17, 18, 19), 1
+    r[19], r[35] = F(0.1 * tau), F(0.1 * tau)
+    r[32], r[33], r[34] = 900, 5000, 4000
+    r[37], r[39], r[40], r[41] = 2000, 600, 700, F(2000 * (0.03 * tau) ** 2)
+    return r
+
+
+# reason -> (mutation of the good record, refused for its ERROR (allowance void)?, counts as a failure of the mode?)
+def _range(r, tau): r[7] = 5
+def _listed_box(r, tau): r[32] = hd.CAND_CAP + 1
+def _listed_band(r, tau): r[33] = hd.BAND_CAP + 1
+def _near(r, tau): r[38] = 3
+def _near_bit(r, tau): r[15] |= hd.NEAR_OVERFLOW_BIT
+def _contradiction(r, tau): r[18] = 1
+def _flips(r, tau): r[36] = 2
+def _err(r, tau): r[19] = F(0.7 * tau)
+def _audit(r, tau): r[35] = F(0.7 * tau)
+def _no_audit(r, tau): r[37] = 0
+
+
+REASONS = {"range": (_range, False), "near": (_near, False), "near_bit": (_near_bit, False), "contradiction": (_contradiction, True),
+           "flips": (_flips, True), "error": (_err, True), "audit": (_audit, True), "no_audit": (_no_audit, False)}
+
+
+class FakeLib:
+    """Logs (entry point, arithmetic in force) and writes the next scripted record into the caller's buffer."""
+
+    def __init__(self, dec):
+        self.dec, self.log, self.script = dec, [], []
+
+    def _write(self, ptr, words):
+        buf = (ctypes.c_int32 * len(words)).from_address(ptr)
+        buf[:] = [int(w) for w in words]
+
+    def asdf_decode_grid(self, h, n, org, vs, mode, hand, obj, bbox, stream):
+        self.log.append(("grid", self.dec.math))
+        if bbox:
+            self._write(bbox, good_record(1.0)[:16])
+        return 0
+
+    def _one_plane(self, name, rec):
+        self.log.append((name, self.dec.math))
+        self._write(rec, self.script.pop(0))
+        return 0
+
+    def asdf_decode_grid_box(self, h, n, org, vs, mode, tau, sh, so, rec, stream):
+        return self._one_plane("box", rec)
+
+    def asdf_decode_grid_band(self, h, n, org, vs, mode, tau, sh, so, rec, stream):
+        return self._one_plane("band", rec)
+
+    def asdf_decoder_set_math(self, h, code):
+        return 0
+
+    def asdf_decoder_set_audit(self, h, n, seed):
+        return 0
+
+
+@pytest.fixture()
+def machine(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE"):
+        monkeypatch.delenv(k, raising=False)
+    dec = hd.HipSdfDecoder.__new__(hd.HipSdfDecoder)
+    dec.combined, dec.nerf_features, dec.point_feat_size = False, False, 3
+    dec.device, dec._h = torch.device("cpu"), None
+    dec._L = FakeLib(dec)
+    dec._stream = lambda: None
+    dec._init_sweep_state()
+    dec._calibrated = True                          # the activation scales: not under test here
+    calls = []
+
+    def fake_calibrate(args, vols):                 # the whole-lattice comparison: sets the allowance, as the real one does
+        calls.append("calibrate")
+        dec._coarse_since_cal, dec._box_epoch, dec._cal_points = 0, dec._recalibrations, int(args[0]) ** 3
+        dec._err_window.append(2e-4)
+        dec._box_tau = dec._tau_current()
+        dec.cert["calibrations"] += 1
+
+    def fake_recover(bad, status=None):             # fp16 range violation -> new activation scales -> a new scale epoch
+        calls.append("recover")
+        dec._recalibrations += 1
+
+    dec._calibrate_box, dec._recover = fake_calibrate, fake_recover
+    dec._status = lambda clear: np.zeros(16, dtype=np.int32)
+    dec.close = lambda: None
+    # first coarse pass: ordinary sweep + calibration
+    t = dec.coarse_begin(*ARGS)
+    assert t["kind"] == "exact"
+    dec.coarse_finish(t)
+    assert calls == ["calibrate"] and dec._allowance_valid(N) and dec._L.log == [("grid", "f16x3")]
+    dec._L.log.clear()
+    calls.clear()
+    return dec, calls
+
+
+def test_accepted_sweeps_stay_on_the_one_plane_kernel(machine):
+    dec, calls = machine
+    tau = dec._box_tau
+    dec._L.script = [good_record(tau), good_record(tau)]
+    t = dec.coarse_begin(*ARGS)
+    b = dec.coarse_finish(t)
+    assert t["kind"] == "box" and b[:16].tolist() == good_record(tau)[:16].tolist()
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "band" and not dec.fine_needs_repeat(t)
+    assert dec._L.log == [("box", "f16x3"), ("band", "f16x3")] and calls == []
+    c = dec.certificate()
+    assert c["audited_sweeps"] == 2 and c["shell_picks"] == 1200 and c["shell_population_max"] == 700
+    assert abs(c["min_margin_tau_over_estimate"] - 10.0) < 1e-3 and abs(c["min_tau_over_sigma"] - 1 / 0.03) < 0.1
+    # a fine pass whose caller wants VOLUMES is an ordinary sweep whatever the mode
+    _, _, t = dec.fine_begin(*ARGS)
+    assert t["kind"] == "exact" and dec._L.log[-1] == ("grid", "f16x3")
+
+
+@pytest.mark.parametrize("stale", [False, True])
+@pytest.mark.parametrize("reason", sorted(REASONS) + ["listed"])
+def test_coarse_pass_refusals(machine, reason, stale):
+    """A refused box-only sweep is answered by an ordinary sweep IN coarse_finish (the zoom cube needs boxes now); what the next
+    coarse pass launches depends on why."""
+    dec, calls = machine
+    tau = dec._box_tau
+    r = good_record(tau)
+    (REASONS[reason][0] if reason != "listed" else _listed_box)(r, tau)
+    dec._L.script = [r, good_record(tau), good_record(tau)]
+    t = dec.coarse_begin(*ARGS)
+    assert t["kind"] == "box"
+    if stale:
+        dec._recalibrations += 1                     # the activation scales were re-calibrated while the sweep was in flight
+    b = dec.coarse_finish(t)
+    assert b[:6].tolist() == [3, 4, 5, 20, 21, 22]                       # boxes come out whatever path ran
+    assert dec._L.log[:2] == [("box", "f16x3"), ("grid", "f16x3")]       # ... from an ordinary sweep
+    assert dec.box_stats["fallback"] == 1
+    for_error = reason != "listed" and REASONS[reason][1]
+    if stale:
+        # not judged at all: nothing is learnt from a sweep under scales that no longer exist; the new epoch needs its own allowance
+        assert dec._box_failures == 0 and dec.cert["refusals_for_error"] == 0 and calls == ["calibrate"]
+    elif reason == "range":
+        assert calls == ["recover", "calibrate"]     # new scales, then the allowance for them, on this very lattice
+        assert dec._box_failures == 0
+    elif for_error:
+        assert calls == ["calibrate"] and dec.cert["refusals_for_error"] == 1 and dec._box_failures == 1
+    else:
+        assert calls == [] and dec._box_failures == 1 and dec._allowance_valid(N)
+    if reason in ("near", "near_bit") and not stale:
+        pass                                         # (the box sweep's near-level overflow is answered by the ordinary repeat itself)
+    # the next coarse pass is a box-only sweep again (one refusal does not switch the mode off)
+    dec._L.log.clear()
+    t = dec.coarse_begin(*ARGS)
+    assert t["kind"] == "box", (reason, stale)
+    dec.coarse_finish(t)
+    assert dec._box_failures == 0
+
+
+@pytest.mark.parametrize("stale", [False, True])
+@pytest.mark.parametrize("reason", sorted(REASONS) + ["listed"])
+def test_fine_pass_refusals(machine, reason, stale):
+    """A refused narrow-band sweep makes fine_needs_repeat return True; the repeat is an ordinary sweep - on the fp32 chain, once,
+    when the near-level list overflowed - and the pass after that is a band sweep again unless the allowance was voided."""
+    dec, calls = machine
+    tau = dec._box_tau
+    r = good_record(tau)
+    (REASONS[reason][0] if reason != "listed" else _listed_band)(r, tau)
+    dec._L.script = [r, good_record(tau), good_record(tau)]
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "band"
+    if stale:
+        dec._recalibrations += 1
+    assert dec.fine_needs_repeat(t)
+    assert dec.band_stats["fallback"] == 1
+    dec._L.log.clear()
+    _, _, t2 = dec.fine_begin(*ARGS, mc_only=True)                        # the repeat
+    assert t2["kind"] == "exact"
+    near = reason in ("near", "near_bit")           # (a property of the sample, honoured for a stale ticket too)
+    assert dec._L.log == [("grid", "f32" if near else "f16x3")], (reason, stale, dec._L.log)
+    assert dec.math == "f16x3" and not dec._force_f32_once               # ... for that one sweep only
+    assert not dec.fine_needs_repeat(t2)
+    for_error = reason != "listed" and REASONS[reason][1]
+    if stale:
+        assert dec._band_failures == 0 and calls == []
+    elif reason == "range":
+        assert calls == ["recover"] and dec._band_failures == 0
+    elif near:
+        assert dec._band_failures == 0               # a capacity of the fp32 refinement, not a failure of the band sweep
+    else:
+        assert dec._band_failures == 1
+    # the pass after the repeat
+    dec._L.log.clear()
+    _, _, t3 = dec.fine_begin(*ARGS, mc_only=True)
+    if stale or reason == "range" or (for_error and not stale):
+        # no valid allowance (new scale epoch, or voided by the refusal): ordinary sweeps until a coarse pass has calibrated again
+        assert t3["kind"] == "exact" and not dec._allowance_valid(N)
+        t = dec.coarse_begin(*ARGS)
+        assert t["kind"] == "exact"
+        dec.coarse_finish(t)
+        assert calls[-1] == "calibrate" and dec._allowance_valid(N)
+        _, _, t3 = dec.fine_begin(*ARGS, mc_only=True)
+    assert t3["kind"] == "band" and not dec.fine_needs_repeat(t3)
+    assert dec._band_failures == 0
+
+
+def test_three_refusals_in_a_row_switch_the_mode_off(machine):
+    dec, calls = machine
+    tau = dec._box_tau
+    bad = good_record(tau)
+    _listed_band(bad, tau)
+    dec._L.script = [bad.copy(), bad.copy(), bad.copy()]
+    for k in range(3):
+        _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+        assert t["kind"] == "band" and dec.fine_needs_repeat(t)
+        _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+        assert t["kind"] == "exact" and not dec.fine_needs_repeat(t)
+    assert dec.fine_mode == "exact" and dec._band_failures == 3
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "exact"
+    # an accepted sweep in between resets the count: refusals must be CONSECUTIVE
+    dec.fine_mode, dec._band_failures = "band", 0
+    dec._L.script = [bad.copy(), bad.copy(), good_record(tau), bad.copy()]
+    for k, refused in enumerate((True, True, False, True)):
+        _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+        assert t["kind"] == "band" and dec.fine_needs_repeat(t) == refused
+        if refused:
+            _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+            assert not dec.fine_needs_repeat(t)
+    assert dec.fine_mode == "band" and dec._band_failures == 1
+    # the coarse mode the same way
+    badc = good_record(tau)
+    _listed_box(badc, tau)
+    dec._L.script = [badc.copy(), badc.copy(), badc.copy()]
+    for k in range(3):
+        t = dec.coarse_begin(*ARGS)
+        assert t["kind"] == "box"
+        dec.coarse_finish(t)
+    assert dec.coarse_mode == "exact"
+    assert dec.coarse_begin(*ARGS)["kind"] == "exact"
+
+
+def test_ordinary_sweep_reports(machine):
+    """An ORDINARY split-half sweep answers for itself through words 7 / 15 of its box record: range violations -> new scales and
+    a repeat; bit 30 (near-level list overflowed) -> one repeat on the fp32 chain."""
+    dec, calls = machine
+    dec.coarse_mode = dec.fine_mode = "exact"
+    real = dec._L.asdf_decode_grid
+    state = {"n": 0}
+
+    def overflow_once(h, n, org, vs, mode, hand, obj, bbox, stream):
+        rc = real(h, n, org, vs, mode, hand, obj, bbox, stream)
+        if state["n"] == 0 and bbox:
+            (ctypes.c_int32 * 16).from_address(bbox)[7] = hd.NEAR_OVERFLOW_BIT
+        state["n"] += 1
+        return rc
+
+    dec._L.asdf_decode_grid = overflow_once
+    t = dec.coarse_begin(*ARGS)
+    b = dec.coarse_finish(t)
+    assert dec._L.log == [("grid", "f16x3"), ("grid", "f32")] and dec.math == "f16x3"
+    assert int(b[7]) == 0 and int(b[15]) == 0
+    # the same in the fine pass: fine_needs_repeat says so, the repeat runs on the fp32 chain
+    dec._L.log.clear()
+    state["n"] = 0
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "exact" and dec.fine_needs_repeat(t)
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert not dec.fine_needs_repeat(t)
+    assert dec._L.log == [("grid", "f16x3"), ("grid", "f32")] and dec.math == "f16x3"
+    # range violations: re-calibrated and repeated under the new scales
+    dec._L.log.clear()
+    state["n"] = 1
+
+    def range_once(h, n, org, vs, mode, hand, obj, bbox, stream):
+        rc = real(h, n, org, vs, mode, hand, obj, bbox, stream)
+        if state["n"] == 1 and bbox:
+            (ctypes.c_int32 * 16).from_address(bbox)[15] = 7
+        state["n"] += 1
+        return rc
+
+    dec._L.asdf_decode_grid = range_once
+    t = dec.coarse_begin(*ARGS)
+    dec.coarse_finish(t)
+    assert calls[-1] == "recover" and dec._L.log == [("grid", "f16x3"), ("grid", "f16x3")]
+
+
+def test_periodic_recalibration_and_lattice_growth(machine, monkeypatch):
+    dec, calls = machine
+    monkeypatch.setattr(hd, "RECAL_EVERY", 3)
+    tau = dec._box_tau
+    dec._L.script = [good_record(tau) for _ in range(8)]
+    kinds = []
+    for _ in range(8):
+        t = dec.coarse_begin(*ARGS)
+        kinds.append(t["kind"])
+        dec.coarse_finish(t)
+    assert kinds == ["box", "box", "box", "exact", "box", "box", "box", "exact"] and calls == ["calibrate", "calibrate"]
+    # a lattice more than 8 x the calibrated one needs its own whole-lattice comparison
+    big = (2 * N + 8,) + ARGS[1:]
+    t = dec.coarse_begin(*big)
+    assert t["kind"] == "exact"
+    dec.coarse_finish(t)
+    assert calls[-1] == "calibrate" and dec._allowance_valid(2 * N + 8) and dec._allowance_valid(N)
