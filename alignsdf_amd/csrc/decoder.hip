@@ -610,6 +610,7 @@ struct asdf_decoder {
   int* audit_idx;   // [kAuditCap]
   int* audit_count;
   int* shell_count; // device word: population of the at-risk shell of the sweep being audited
+  int short_max;    // voxel lists of up to this many points are re-evaluated by the short-list form of the fp32 chain (0 = never)
 };
 static constexpr int kNearCap = 1 << 16;      // near-level refinement list of a split-half sweep
 static constexpr int kCandCap = 1 << 21;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
@@ -640,7 +641,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 119; }
+int asdf_version(void) { return 120; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -765,6 +766,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) e = hipMalloc((void**)&d->shell_count, sizeof(int));
   d->audit_n = 1 << 16;
   d->audit_seed = 0x5DF5A11D00000000ull;
+  d->short_max = 8192;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
@@ -838,7 +840,14 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
 }
 
 namespace asdf {
-static int launch_subset(asdf_decoder* d, const DecodeParams& q, bool two_out, int grid, hipStream_t st) {
+static int launch_subset(asdf_decoder* d, const DecodeParams& q_in, bool two_out, int grid, hipStream_t st) {
+  DecodeParams q = q_in;
+  if (d->kp == 2 && d->short_max > 0 && q.mode == kGridSubset) {
+    // short lists (the usual case of a near-level refinement: a few dozen to a few hundred voxels) take the short-list form - a
+    // quarter of the tile form's latency; both are enqueued, the device-side count decides which one runs (bit-identical results)
+    q.short_max = d->short_max;
+    k1_short_launch(two_out, q, st);
+  }
   if (two_out || q.num_mlps != 2 || !q.sdf0 || !q.sdf1 || !d->side) {
     k1_launch(d->kp, two_out, q, grid, st);
     return ASDF_OK;
@@ -1159,6 +1168,12 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   }
   hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, rec_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_short_list(asdf_decoder_t* d, int32_t max_points) {
+  if (!d || max_points < 0 || max_points > (1 << 16)) return ASDF_EINVAL;
+  d->short_max = max_points;
   return ASDF_OK;
 }
 

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/alignsdf_hip.h"
@@ -444,7 +446,18 @@ struct IcpLayout {
 };
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 bool use_grid(int ns, int nt) { return g_icp_search == 2 || (g_icp_search == 0 && ns >= 1024 && nt >= 1024); }
-IcpLayout icp_layout(int ns, int nt) {
+// The search mode of a run is fixed when the run BEGINS and remembered per workspace on the host: a continuation
+// (asdf_icp_ts_enqueue_range with first_iter > 0) attaches with the layout and the kernels its run was begun with, whatever
+// asdf_icp_set_search has been told in between (the process-wide setting used to be re-read on every attach).
+std::mutex g_run_mu;
+std::unordered_map<const void*, bool> g_run_grid;
+void remember_run(const void* ws, bool grid) { std::lock_guard<std::mutex> g(g_run_mu); g_run_grid[ws] = grid; }
+bool run_uses_grid(const void* ws, int ns, int nt) {
+  std::lock_guard<std::mutex> g(g_run_mu);
+  auto it = g_run_grid.find(ws);
+  return it != g_run_grid.end() ? it->second : use_grid(ns, nt);
+}
+IcpLayout icp_layout(int ns, int nt, bool grid) {
   IcpLayout l;
   const size_t total = (size_t)ns + nt;
   l.update_blocks = (int)((total + kIcpThreads - 1) / kIcpThreads);
@@ -454,7 +467,7 @@ IcpLayout icp_layout(int ns, int nt) {
   l.cand_d = l.partials + (size_t)l.update_blocks * kIcpSums * sizeof(double);
   l.cand_i = l.cand_d + (size_t)kIcpSplits * total * sizeof(double);
   size_t at = align256(l.cand_i + (size_t)kIcpSplits * total * sizeof(int));
-  for (int k = 0; k < 2 && use_grid(ns, nt); ++k) {
+  for (int k = 0; k < 2 && grid; ++k) {
     const size_t n = k == 0 ? nt : ns;
     IcpGridLayout& g = l.grid[k];
     g.hdr = at; at = align256(at + sizeof(IcpGrid));
@@ -482,7 +495,7 @@ int asdf_icp_set_search(int32_t mode) {
 
 int asdf_icp_workspace_bytes(int32_t ns, int32_t nt, size_t* bytes) {
   if (!bytes || ns < 1 || nt < 1) return ASDF_EINVAL;
-  *bytes = icp_layout(ns, nt).bytes;
+  *bytes = icp_layout(ns, nt, use_grid(ns, nt)).bytes;
   return ASDF_OK;
 }
 
@@ -516,23 +529,25 @@ void grid_ref(char* ws, const IcpGridLayout& g, IcpGridRef& ref) {
   ref.sorted_idx = (const int*)(ws + g.sorted_idx);
 }
 // the pointers of a run inside its workspace (no device work): a run begun earlier is continued through this
-int icp_attach(int32_t ns, int32_t nt, void* workspace_dev, size_t workspace_bytes, IcpRun& r) {
+int icp_attach(int32_t ns, int32_t nt, void* workspace_dev, size_t workspace_bytes, IcpRun& r, bool grid) {
   if (!workspace_dev || ns < 1 || nt < 1) return ASDF_EINVAL;
-  r.l = icp_layout(ns, nt);
+  r.l = icp_layout(ns, nt, grid);
   if (workspace_bytes < r.l.bytes) return ASDF_ENOSPC;
   char* ws = (char*)workspace_dev;
   r.state = (IcpState*)(ws + r.l.state);
   r.partials = (double*)(ws + r.l.partials);
   r.cand_d = (double*)(ws + r.l.cand_d);
   r.cand_i = (int*)(ws + r.l.cand_i);
-  r.grid = use_grid(ns, nt);
+  r.grid = grid;
   if (r.grid) { grid_ref(ws, r.l.grid[0], r.gt); grid_ref(ws, r.l.grid[1], r.gs); }
   return ASDF_OK;
 }
 int icp_begin(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, int32_t max_iter, void* workspace_dev,
               size_t workspace_bytes, hipStream_t st, IcpRun& r) {
   if (!src_dev || !tgt_dev || !workspace_dev || ns < 1 || nt < 1 || max_iter < 1) return ASDF_EINVAL;
-  { const int rc = icp_attach(ns, nt, workspace_dev, workspace_bytes, r); if (rc != ASDF_OK) return rc; }
+  const bool grid = use_grid(ns, nt);            // the setting in force NOW belongs to this run until its workspace begins another
+  { const int rc = icp_attach(ns, nt, workspace_dev, workspace_bytes, r, grid); if (rc != ASDF_OK) return rc; }
+  remember_run(workspace_dev, grid);
   char* ws = (char*)workspace_dev;
   // the initial state is a kernel argument of a fill, not a host buffer: nothing the caller must keep alive
   IcpState h;
@@ -541,7 +556,6 @@ int icp_begin(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t 
   h.iters = 0; h.done = 0; h.ticket = 0; h.pad = 0;
   hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, st, r.state, h);
   ASDF_HIP(hipGetLastError());
-  r.grid = use_grid(ns, nt);
   if (r.grid) {
     int rc = build_grid(ws, r.l.grid[0], tgt_dev, nt, st, r.gt);
     if (rc == ASDF_OK) rc = build_grid(ws, r.l.grid[1], src_dev, ns, st, r.gs);
@@ -612,7 +626,7 @@ int asdf_icp_ts_enqueue_range(const double* src_dev, int32_t ns, const double* t
   IcpRun r;
   int rc;
   if (first_iter == 0) rc = icp_begin(src_dev, ns, tgt_dev, nt, last_iter, workspace_dev, workspace_bytes, st, r);
-  else rc = (!src_dev || !tgt_dev) ? ASDF_EINVAL : icp_attach(ns, nt, workspace_dev, workspace_bytes, r);
+  else rc = (!src_dev || !tgt_dev) ? ASDF_EINVAL : icp_attach(ns, nt, workspace_dev, workspace_bytes, r, run_uses_grid(workspace_dev, ns, nt));
   if (rc != ASDF_OK) return rc;
   icp_iterations(r, src_dev, ns, tgt_dev, nt, first_iter, last_iter, stop_error, stop_improvement, st);
   if (result_mapped) hipLaunchKernelGGL(icp_publish_kernel, dim3(1), dim3(1), 0, st, r.state, result_mapped);

@@ -1,6 +1,7 @@
 // K1 on the fp32 MFMA: SeparateDecoder / CombinedDecoder, affine xyz features or the in-kernel NeRF encoding (PointFeatSize 9 / 15, utils/mesh.py:53-55).
 #include "k1_launch.h"
 #include "sdf_mlp_kernel.h"
+#include "sdf_mlp_short_kernel.h"
 
 namespace asdf {
 
@@ -11,8 +12,13 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodePara
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
 
+__global__ __launch_bounds__(256, 1) void sdf_mlp_short_kernel(const DecodeParams p) { sdf_mlp_short_body<false>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_short_combined_kernel(const DecodeParams p) { sdf_mlp_short_body<true>(p); }
+
 hipError_t k1_prepare() {
   hipError_t e = hipSuccess;
+  for (const void* k : {(const void*)sdf_mlp_short_kernel, (const void*)sdf_mlp_short_combined_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesShort);
   for (const void* k : {(const void*)sdf_mlp_kernel, (const void*)sdf_mlp_combined_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   for (const void* k : {(const void*)sdf_mlp_nerf9_kernel, (const void*)sdf_mlp_nerf15_kernel,
@@ -32,6 +38,13 @@ void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_
     if (two_out) hipLaunchKernelGGL(sdf_mlp_combined_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
     else hipLaunchKernelGGL(sdf_mlp_nerf15_kernel, dim3(grid), dim3(256), lds_bytes(8), st, p);
   }
+}
+
+// the short-list form: one workgroup per 32 listed points and MLP, p.short_max / 32 of them per MLP (those beyond the list return)
+void k1_short_launch(bool two_out, const DecodeParams& p, hipStream_t st) {
+  const dim3 grid((p.short_max + kWavePts - 1) / kWavePts, p.num_mlps);
+  if (two_out) hipLaunchKernelGGL(sdf_mlp_short_combined_kernel, grid, dim3(256), kLdsBytesShort, st, p);
+  else hipLaunchKernelGGL(sdf_mlp_short_kernel, grid, dim3(256), kLdsBytesShort, st, p);
 }
 
 }  // namespace asdf

@@ -15,6 +15,9 @@ hipError_t k1h_nerf_prepare();
 
 // kp = point-feature K-steps (2 affine xyz, 5 / 8 NeRF encoding of 9 / 15 features); two_out = CombinedDecoder
 void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
+// the fp32 chain over a SHORT voxel list (kGridSubset, kp == 2): one workgroup per 32 points and MLP, output tiles spread over its
+// waves (sdf_mlp_short_kernel.h); returns at once for lists longer than p.short_max
+void k1_short_launch(bool two_out, const DecodeParams& p, hipStream_t st);
 void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel, kp == 2 only; p.stream = high planes

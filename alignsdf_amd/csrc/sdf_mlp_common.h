@@ -58,6 +58,8 @@ struct DecodeParams {
   int* bbox;                // [kHeads][8]: min0,min1,min2,max0,max1,max2,count,pad (or null)
   const int* idx;           // kGridSubset: [<= P] linear lattice indices
   const int* count_dev;     // kGridSubset: number of listed points (device word; P is the capacity)
+  int short_max;            // kGridSubset, fp32 chain: lists of up to this many points belong to the short-list form
+                            // (sdf_mlp_short_kernel.h) - it returns for longer ones, the tile form for these; 0 = no such split
   int grid_mode;            // kGridSubset: kGridReference / kGridInteger of the lattice
   int* fixup_flag;          // kGridSubset with bbox: the outputs REPLACE earlier values - the box is patched in place (a voxel
                             // that turns negative extends it) and *fixup_flag is raised when one turns non-negative

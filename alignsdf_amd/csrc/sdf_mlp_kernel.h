@@ -98,7 +98,11 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
 
   // kGridSubset: the point count lives on the device (the list was compacted by a kernel just in front of this launch)
   long long npts = p.P;
-  if (p.mode == kGridSubset) { const long long c = *p.count_dev; npts = c < npts ? c : npts; }
+  if (p.mode == kGridSubset) {
+    const long long c = *p.count_dev;
+    npts = c < npts ? c : npts;
+    if (KP == 2 && !CLS && p.short_max > 0 && npts <= (long long)p.short_max) return;      // the short-list form's (sdf_mlp_short_kernel.h)
+  }
   const long long ntiles = (npts + kWgPts - 1) / kWgPts;
   if ((long long)blockIdx.x >= ntiles) return;
 

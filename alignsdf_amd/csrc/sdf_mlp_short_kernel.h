@@ -1,0 +1,188 @@
+// K1n: the fp32 MFMA chain for SHORT voxel lists - the near-level refinement of every split-half sweep (a few dozen to a few hundred
+// voxels), the candidates of a box-only coarse sweep - with the output tiles of a layer spread over the four waves of a workgroup.
+//
+// The tile form (sdf_mlp_kernel.h) gives each wave 32 points through ALL 16 output tiles of every layer: 8 256 dependent MFMAs,
+// 0.23 ms, however few points the list holds - at N = 64 two such launches were a quarter of a sample.  Here a
+// workgroup owns ONE block of 32 points of one MLP and its four waves take a quarter of the output tiles each (2 064 MFMAs per
+// wave); between layers the activations cross through LDS in the accumulator's own register layout, [tile][lane][register], so
+// that K-step s of the next layer reads, per lane, exactly the value the tile form holds in register s & 15 of tile s >> 4.  Every
+// output is therefore accumulated by the SAME instruction sequence as in the tile form - bias, then the K-steps in stream order on
+// v_mfma_f32_32x32x2_f32, the last layer's fmaf chain over tiles 0..15, registers 0..15, one cross-half add, tanhf - and the
+// results are bit-identical (tests/test_gpu_short_list.py compares the two forms on the same lists).
+//
+// Weights: each A fragment is used by one wave once, so it goes straight from L2 into registers (the packed stream's stage image
+// [group][lane][4] is one coalesced 1 KiB load per wave and 4 K-steps), two input tiles (32 K-steps) ahead.  kGridSubset only,
+// affine point features (KP = 2); lists longer than p.short_max are left to the tile form, which skips the short ones.
+#pragma once
+#include "sdf_mlp_kernel.h"
+
+namespace asdf {
+
+constexpr int kShortBufFloats = kTilesHidden * 64 * 16;                       // one 512-wide activation of 32 points: 64 KiB
+constexpr int kLdsBytesShort = (2 * kShortBufFloats + kCstFloats) * 4;
+static_assert(kLdsBytesShort <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void short_store16(float* buf, int t, int lane, const f32x16& a) {
+  f32x4* d = reinterpret_cast<f32x4*>(buf + (t * 64 + lane) * 16);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { f32x4 v; v[0] = a[4 * c]; v[1] = a[4 * c + 1]; v[2] = a[4 * c + 2]; v[3] = a[4 * c + 3]; d[c] = v; }
+}
+
+// acc += sum over K-steps 0 .. 16 IN_TILES - 1, in order: A from the packed stream of one output tile (global), B from the
+// previous layer's activations in LDS
+template <int IN_TILES>
+__device__ __forceinline__ void short_chain(f32x16& acc, const float* __restrict__ wsrc, const float* hin, int lane) {
+  const f32x4* w = reinterpret_cast<const f32x4*>(wsrc) + lane;               // group g of the tile's stream: w[g * 64]
+  f32x4 abuf[IN_TILES + 2][4];
+#pragma unroll
+  for (int i = 0; i < 2 && i < IN_TILES; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) abuf[i][g] = w[(i * 4 + g) * 64];
+#pragma unroll
+  for (int it = 0; it < IN_TILES; ++it) {
+    if (it + 2 < IN_TILES) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) abuf[it + 2][g] = w[((it + 2) * 4 + g) * 64];
+    }
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(hin + (it * 64 + lane) * 16);
+    f32x4 b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = b4[c];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = ASDF_MFMA(abuf[it][g][j], b[g][j], acc);        // K-step 16 it + 4 g + j
+  }
+}
+
+template <bool TWO_OUT>
+__device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p) {
+  using CL = CstLayout<2>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufX = smem;                          // h0, then h2
+  float* bufY = smem + kShortBufFloats;        // h1, then the raw layer-3 accumulators
+  float* cst = smem + 2 * kShortBufFloats;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+
+  long long npts = *p.count_dev;
+  if (npts > p.P) npts = p.P;
+  if (npts > (long long)p.short_max) return;                   // the tile form's list
+  const long long pb = (long long)blockIdx.x * kWavePts;
+  if (pb >= npts) return;
+  const int head = p.first_mlp + blockIdx.y;
+  {
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(p.cst + (size_t)head * CL::kFloats);
+    for (int i = tid; i < CL::kFloats / 4; i += 256) reinterpret_cast<f32x4*>(cst)[i] = src4[i];
+  }
+  __syncthreads();
+  const float* hc = cst;
+  const float* sbase = p.stream + (size_t)head * kStagesHead * kStageFloats;
+  const long long pi = pb + (lane & 31);
+  const bool valid = pi < npts;
+  const long long po = valid ? (long long)p.idx[pi] : 0;
+  float x0, x1, x2;
+  grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+  const float bp0 = half ? x1 : x0, bp1 = half ? 0.0f : x2;
+
+  // ---- layer 0: tiles 4 wave .. 4 wave + 3
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = wave * 4 + k;
+    f32x16 acc = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+    acc = ASDF_MFMA(hc[CL::kA0 + (t * 2 + 0) * 64 + lane], bp0, acc);
+    acc = ASDF_MFMA(hc[CL::kA0 + (t * 2 + 1) * 64 + lane], bp1, acc);
+    short_store16(bufX, t, lane, relu16i(acc));
+  }
+  __syncthreads();
+  // ---- layer 1 (512 -> 256): tiles 2 wave, 2 wave + 1; four stages (K = 512) per tile
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int t = wave * 2 + k;
+    f32x16 acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
+    short_chain<16>(acc, sbase + (size_t)(t * 4) * kStageFloats, bufX, lane);
+    short_store16(bufY, t, lane, relu16i(acc));
+  }
+  __syncthreads();
+  // ---- layer 2 ([h1 (256) | xyz] -> 512): the point-feature K-steps first, then two stages per tile
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int t = wave * 4 + k;
+    f32x16 acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16);
+    acc = ASDF_MFMA(hc[CL::kA2 + (t * 2 + 0) * 64 + lane], bp0, acc);
+    acc = ASDF_MFMA(hc[CL::kA2 + (t * 2 + 1) * 64 + lane], bp1, acc);
+    short_chain<8>(acc, sbase + (size_t)(kStagesL1 + t * 2) * kStageFloats, bufY, lane);
+    short_store16(bufX, t, lane, relu16i(acc));
+  }
+  __syncthreads();
+  // ---- layer 3 (512 -> 512): raw accumulators to LDS; the last layer applies the ReLU as it reads them
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int t = wave * 4 + k;
+    f32x16 acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
+    short_chain<16>(acc, sbase + (size_t)(kStagesL1 + kStagesL2 + t * 4) * kStageFloats, bufX, lane);
+    short_store16(bufY, t, lane, acc);
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- layer 4 + tanh, in the tile form's order: tiles 0..15, registers 0..15, then the cross-half add
+  float part = 0.0f, partb = 0.0f;
+#pragma unroll 1
+  for (int t = 0; t < kTilesHidden; ++t) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(bufY + (t * 64 + lane) * 16);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(hc + CL::kW4 + (t * 2 + half) * 16);
+    const f32x4* w4b = reinterpret_cast<const f32x4*>(hc + CL::kW4b + (t * 2 + half) * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 a = a4[c], w = w4[c];
+      f32x4 wb = w;
+      if (TWO_OUT) wb = w4b[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __int_as_float(max(__float_as_int(a[r]), 0));
+        part = fmaf(v, w[r], part);
+        if (TWO_OUT) partb = fmaf(v, wb[r], partb);
+      }
+    }
+  }
+  part += __shfl_xor(part, 32);
+  const float sdf = tanhf(part + hc[CL::kB4]);
+  float sdfb = 1.0f;
+  if (TWO_OUT) {
+    partb += __shfl_xor(partb, 32);
+    sdfb = tanhf(partb + hc[CL::kB4 + 1]);
+  }
+  const bool is_hand = head == 0;
+  if (valid && half == 0) {
+    // what the tile form does with a kGridSubset result (sdf_mlp_kernel.h): measured change, box patch, value in place
+    float* out = is_hand ? p.sdf0 : p.sdf1;
+    if (p.status && !p.bbox) {
+      if (out) atomicMax(p.status + 3, __float_as_int(fabsf(sdf - out[po])));
+      if (TWO_OUT && p.sdf1) atomicMax(p.status + 3, __float_as_int(fabsf(sdfb - p.sdf1[po])));
+    }
+    if (p.bbox) {
+      auto patch = [&](float* vol, float now, int* rec) {
+        const float before = vol[po];
+        const bool was = before < p.neg_thr, is = now < 0.0f;
+        if (p.status) atomicMax(p.status + 3, __float_as_int(fabsf(now - before)));
+        if (was == is) return;
+        if (is) {
+          const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
+          atomicMin(rec + 0, i0); atomicMin(rec + 1, i1); atomicMin(rec + 2, i2);
+          atomicMax(rec + 3, i0); atomicMax(rec + 4, i1); atomicMax(rec + 5, i2);
+          atomicAdd(rec + 6, 1);
+        } else {
+          atomicExch(p.fixup_flag, 1);
+        }
+      };
+      if (out) patch(out, sdf, p.bbox + (is_hand ? 0 : 8));
+      if (TWO_OUT && p.sdf1) patch(p.sdf1, sdfb, p.bbox + 8);
+    }
+    if (out) out[po] = sdf;
+    if (TWO_OUT && p.sdf1) p.sdf1[po] = sdfb;
+  }
+}
+
+}  // namespace asdf

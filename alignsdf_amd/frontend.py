@@ -87,8 +87,18 @@ def quick_gil_handover(interval=5e-4):
     CPython's default 5 ms switch interval the main thread - whose job is to keep the GPU's queue full - can wait that long
     for it every time.  0.5 ms makes a worker hand it back promptly."""
     import sys
-    if sys.getswitchinterval() > interval:
+    previous = sys.getswitchinterval()
+    if previous > interval:
         sys.setswitchinterval(interval)
+    return previous
+
+
+def restore_gil_handover(previous):
+    """Undo quick_gil_handover (the switch interval is a PROCESS-wide setting: whoever shortened it for its worker threads puts the
+    caller's value back when the threads are gone)."""
+    import sys
+    if previous is not None and previous > sys.getswitchinterval():
+        sys.setswitchinterval(previous)
 
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # transforms.Normalize of utils/data.py:220

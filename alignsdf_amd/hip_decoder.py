@@ -640,6 +640,33 @@ class HipSdfDecoder:
             self._box_epoch = -1          # the allowance is void until the next coarse pass has measured the whole lattice again
         return reason is None, bad, near_over, reason
 
+    # ---- records travel to the host behind their own sweep: an asynchronous copy into pinned memory + an event recorded right behind
+    # it.  The reader waits for THAT event - a `.cpu()` would wait for everything queued on the stream since (the next sample's
+    # pass 1, marching cubes ...), which at N = 64 was a tenth of a sample of idle GPU (profiles/r04_small_lattice_traces.txt).
+    def _record_to_host(self, rec):
+        if rec is None or rec.device.type != "cuda":
+            return None
+        if not hasattr(self, "_rec_ring"):
+            self._rec_ring = [torch.zeros(REC_WORDS, dtype=torch.int32).pin_memory() for _ in range(32)]
+            self._rec_turn = 0
+        slot = self._rec_ring[self._rec_turn % len(self._rec_ring)]
+        self._rec_turn += 1
+        n = rec.numel()
+        slot[:n].copy_(rec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return slot, n, ev
+
+    @staticmethod
+    def _record_of(ticket):
+        """The ticket's record as a host array (waits for the sweep it belongs to, and for nothing queued behind it)."""
+        host = ticket.get("host")
+        if host is not None:
+            slot, n, ev = host
+            ev.synchronize()
+            return slot[:n].numpy().copy()
+        return ticket["rec"].cpu().numpy()
+
     # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
     # per-head boxes of its negative voxels.  begin() enqueues, finish() reads the record back (the one host
     # synchronisation the zoom cube needs anyway) and repeats the sweep where a guard asks for it.
@@ -662,9 +689,11 @@ class HipSdfDecoder:
         due = self._coarse_since_cal > RECAL_EVERY          # the periodic whole-lattice re-measurement: this pass runs both ways
         if self._box_usable() and self._allowance_valid(N) and not self._force_f32_once and not due:
             rec, sh, so = self._box_launch(*args, self._box_tau)
-            return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": self._box_tau, "epoch": self._recalibrations}
+            return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": self._box_tau, "epoch": self._recalibrations,
+                    "host": self._record_to_host(rec)}
         h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
-        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations, "recalibrate": due}
+        return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations, "recalibrate": due,
+                "host": self._record_to_host(bbox)}
 
     def coarse_finish(self, ticket):
         """int32[16] host record of the coarse pass (words 0..5 / 8..13: boxes of the negative voxels; 6 / 14: non-zero
@@ -674,7 +703,7 @@ class HipSdfDecoder:
         N, origin3, voxel_size, grid_mode, hand, obj = ticket["args"]
         calibrate_allowance = True
         if ticket["kind"] == "box":
-            r = ticket["rec"].cpu().numpy()
+            r = self._record_of(ticket)
             if ticket["epoch"] != self._recalibrations:
                 ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
             else:
@@ -698,7 +727,7 @@ class HipSdfDecoder:
                     self.coarse_mode = "exact"
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
             ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
-        b = ticket["rec"].cpu().numpy()
+        b = self._record_of(ticket)
         keep, epoch = ticket["keep"], ticket["epoch"]
         while self.fall_back_if_overflowed(b, epoch):      # split-half planes out of fp16 range: re-calibrated, or at last fp32
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
@@ -726,10 +755,11 @@ class HipSdfDecoder:
         if mc_only and self._band_usable() and not self._band_skip and self._allowance_valid(N) and not self._force_f32_once:
             rec, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band, "asdf_decode_grid_band", N, origin3, voxel_size,
                                                  grid_mode, hand, obj, self._box_tau)
-            return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau, "epoch": self._recalibrations}
+            return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau, "epoch": self._recalibrations,
+                            "host": self._record_to_host(rec)}
         self._band_skip = False
         vh, vo, bbox2 = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj)
-        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations}
+        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations, "host": self._record_to_host(bbox2)}
 
     def fine_needs_repeat(self, ticket):
         """True when the fine pass has to be repeated (the decoder must be bound to its sample again first): its range or
@@ -738,7 +768,7 @@ class HipSdfDecoder:
             return False
         if ticket["kind"] == "band":
             import logging
-            r = ticket["rec"].cpu().numpy()
+            r = self._record_of(ticket)
             if ticket["epoch"] != self._recalibrations:
                 # not judged: its error says nothing about the current scales.  (A near-level list that overflowed is a property of
                 # the SAMPLE - refine_tau is absolute - and is honoured: the repeat runs on the fp32 chain.)
@@ -763,8 +793,7 @@ class HipSdfDecoder:
                     self.fine_mode = "exact"
             self._band_skip = True
             return True
-        rec = ticket["rec"]
-        if rec is not None and self.fall_back_if_overflowed(rec.cpu().numpy(), ticket.get("epoch")):
+        if ticket["rec"] is not None and self.fall_back_if_overflowed(self._record_of(ticket), ticket.get("epoch")):
             return True
         self.band_stats["exact"] += 1
         return False

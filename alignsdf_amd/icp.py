@@ -151,6 +151,8 @@ def start_icp_device(points_source_dev, points_target_dev, max_iter=100, stop_er
     job.src = ((ps - offset_s) / scale_s * scale_t + offset_t).contiguous()
     job.tgt = pt.contiguous()
     job.host = [torch.zeros(8, dtype=torch.float64).pin_memory()]
+    # (an in-order copy on the stream the ICP is enqueued on, AHEAD of its kernels: finish_icp waits for the event behind them and
+    # reads this afterwards - no copy engine has to get in between decoder passes on its own, which is what start_icp avoids)
     job.host[0].copy_(torch.cat([offset_s, scale_s.reshape(1), offset_t, scale_t.reshape(1)]), non_blocking=True)
     job.norm = None                   # read from job.host[0] once the run is done (finish_icp)
     L = _native.lib()
@@ -166,15 +168,33 @@ def start_icp_device(points_source_dev, points_target_dev, max_iter=100, stop_er
     return job
 
 
+_CONTINUATION_STREAMS = {}
+
+
+def _continuation_stream(device):
+    """A side stream per device for the rare continuation of a non-converged run: finish_icp is called when job.stream already holds
+    pass 2 of the next sample and pass 1 of the one after - queued THERE the remaining iterations would wait behind both; on a side
+    stream (ordered behind the first batch) they start at the next kernel boundary."""
+    key = (device.type, device.index)
+    if key not in _CONTINUATION_STREAMS:
+        _CONTINUATION_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _CONTINUATION_STREAMS[key]
+
+
 def finish_icp(job, vertices):
     """Wait for a start_icp / start_icp_device job; returns the dict of icp_trans_scale for `vertices`."""
     job.done.synchronize()            # the ICP only - not whatever was queued behind it
     res = job.result.tolist()
     if res[6] == 0.0 and int(res[4]) < job.args[0]:
-        # not converged within the first batch (rare: runs take a handful of iterations): the remaining ones, now
-        with torch.cuda.stream(job.stream):
+        # not converged within the first batch (rare: runs take a handful of iterations): the remaining ones, now, on the side
+        # stream (ADVICE r03).  The run continues with the search mode it was begun with (csrc/icp.hip: remember_run).
+        side = _continuation_stream(job.device)
+        side.wait_event(job.done)
+        first_stream, job.stream = job.stream, side
+        with torch.cuda.stream(side):
             _enqueue_range(job, int(res[4]), job.args[0])
-            job.done.record(job.stream)
+            job.done.record(side)
+        job.stream = first_stream
         job.done.synchronize()
         res = job.result.tolist()
     scale, trans, iters, error = res[0], np.array([res[1], res[2], res[3]]), int(res[4]), res[5]

@@ -132,14 +132,21 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         tells it whether the decoder was re-bound to this sample."""
         rebound = False
         ticket = r.pop("fine_ticket", None)
+
+        def begin_counts():
+            # count phases of both volumes (no host synchronisation)
+            return {part: marching_cubes_begin(r["vol_" + part], 0.0, slot) for slot, (part, on) in enumerate((("hand", hb), ("obj", ob))) if on}
+
+        # the count phases are queued BEFORE the fine pass's guard record is read (it is accepted all but never refused): one
+        # host wait then covers the record and the sizes, instead of record -> launch -> sizes with the GPU idle in between
+        tickets = begin_counts()
         while hip.fine_needs_repeat(ticket):
             # pass 2 left the fp16 range (the decoder has been re-calibrated, or switched to the fp32 kernel) or its
-            # narrow-band form was not accepted: repeat this sample's pass 2
+            # narrow-band form was not accepted: repeat this sample's pass 2 - and its count phases
             bind(sample)
             rebound = True
             r["vol_hand"], r["vol_obj"], ticket = hip.fine_begin(N, r["origin"], float(r["voxel_size"]), mode, hand=hb, obj=ob, mc_only=True)
-        # count phases of both volumes first (no host synchronisation), then one wait, then the emits
-        tickets = {part: marching_cubes_begin(r["vol_" + part], 0.0, slot) for slot, (part, on) in enumerate((("hand", hb), ("obj", ob))) if on}
+            tickets = begin_counts()
         for part, on in (("hand", hb), ("obj", ob)):
             r["V_" + part] = r["F_" + part] = 0
             if on:
@@ -253,7 +260,7 @@ class GroundTruthPrefetcher:
     def __init__(self, task, data_root, allow_missing_gt=False, samples=30000, seed=1):
         from concurrent.futures import ThreadPoolExecutor
         from .frontend import quick_gil_handover
-        quick_gil_handover()
+        self._switch_interval = quick_gil_handover()
         self.task, self.data_root, self.allow_missing, self.samples, self.seed = task, data_root, allow_missing_gt, samples, seed
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-gt")
         self.proc = None if os.environ.get("ASDF_GT_WORKER", "process") == "thread" else _ground_truth_process()
@@ -300,30 +307,67 @@ class GroundTruthPrefetcher:
             logging.warning("eval_mode: ground-truth mesh %s not found; writing the unaligned mesh (allow_missing_gt)" % path)
         return pts
 
+    def discard(self, ply_filename_out):
+        """A prefetched sample the consumer does not need after all (no hand surface: nothing to align): drop its job - a failure
+        of a mesh nobody reads is not an error, and nothing stays behind in self.jobs."""
+        job = self.jobs.pop(ply_filename_out, None)
+        if job is not None:
+            job[1].cancel()
+
     def close(self):
+        from .frontend import restore_gil_handover
+        for _, job in self.jobs.values():           # (prefetched, never asked for)
+            job.cancel()
+        self.jobs.clear()
         self.pool.shutdown(wait=True)               # (the worker process is shared by later calls and ends with the interpreter)
+        restore_gil_handover(self._switch_interval)
 
 
 class FileWriter:
     """PLY files are written on a worker thread (tobytes + write release the GIL): the consumer hands over host arrays and
-    moves on to the next sample; close() waits for every file and re-raises the first failure."""
+    moves on to the next sample.  A failed write (disk full, permissions) surfaces at the NEXT write_ply / poll - one sample later,
+    not after the whole shard has been decoded - and close() waits for every file; close(failing=True), from a `finally` that is
+    unwinding another exception, only logs what the writer still has to report so that the original error survives."""
 
     def __init__(self):
         from concurrent.futures import ThreadPoolExecutor
         from .frontend import quick_gil_handover
-        quick_gil_handover()
+        self._switch_interval = quick_gil_handover()
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asdf-ply")
         self.jobs = []
 
+    def poll(self):
+        """Raise the failure of any write that has finished; forget the ones that succeeded."""
+        pending = []
+        for path, j in self.jobs:
+            if j.done():
+                j.result()
+            else:
+                pending.append((path, j))
+        self.jobs = pending
+
     def write_ply(self, path, verts, faces):
         from .ply import write_ply
+        self.poll()
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        self.jobs.append(self.pool.submit(write_ply, path, verts, faces))
+        self.jobs.append((path, self.pool.submit(write_ply, path, verts, faces)))
 
-    def close(self):
+    def close(self, failing=False):
+        from .frontend import restore_gil_handover
         self.pool.shutdown(wait=True)
-        for j in self.jobs:
-            j.result()
+        restore_gil_handover(self._switch_interval)
+        jobs, self.jobs = self.jobs, []
+        first = None
+        for path, j in jobs:
+            err = j.exception()
+            if err is not None:
+                if failing:
+                    import logging
+                    logging.error("PLY write of %s failed: %s", path, err)
+                elif first is None:
+                    first = err
+        if first is not None:
+            raise first
 
 
 def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
@@ -415,6 +459,8 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                     from .icp import start_alignment_device
                     target = gt.get(hand_path(key[1]) + ".ply")
                     r["icp_job"] = None if target is None else start_alignment_device(*r["kept_dev_hand"], r["origin"], r["voxel_size"], target)
+                else:
+                    gt.discard(hand_path(key[1]) + ".ply")          # no hand surface: the prefetched ground truth is not needed
 
             for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
                                                         label_out=label_out and hand_on, midpoint=begin_hand if gt is not None else None):
@@ -457,10 +503,15 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                 now = time.perf_counter()
                 rec["seconds"], t_prev = now - t_prev, now
                 records.append(rec)
-    finally:
+    except BaseException:
+        # unwinding: the helpers are closed without letting THEIR errors replace the one in flight
         if gt is not None:
             gt.close()
-        writer.close()                  # every file is on disk (or its error raised) before reconstruct() returns
+        writer.close(failing=True)
+        raise
+    if gt is not None:
+        gt.close()
+    writer.close()                      # every file is on disk (or its error raised) before reconstruct() returns
     return records
 
 

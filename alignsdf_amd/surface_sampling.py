@@ -7,49 +7,57 @@ import numpy as np
 from . import synthetic
 
 
-def load_obj(path):
-    """Minimal Wavefront OBJ reader: (verts float64 [V,3], faces int64 [F,3]); polygons are fan-triangulated.
-    Vertex lines are parsed in one numpy call, triangle faces too when every face line is a plain or slashed triple (what mesh
-    exporters write); anything else takes the line-by-line path.  ~10 x the speed of the loop on a 10 k-face mesh."""
-    with open(path, "r") as f:
-        lines = f.read().split("\n")
-    vlines = [ln for ln in lines if ln.startswith("v ")]
-    flines = [ln for ln in lines if ln.startswith("f ")]
-    verts = None
-    if vlines:
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")        # (np.fromstring's text mode is deprecated, and still the fastest parser here)
-            flat = np.fromstring(" ".join(ln[2:] for ln in vlines), dtype=np.float64, sep=" ")
-        if flat.size % len(vlines) == 0 and flat.size // len(vlines) >= 3:
-            verts = flat.reshape(len(vlines), -1)[:, :3]
-    if verts is None:
-        verts = np.asarray([[float(x) for x in ln.split()[1:4]] for ln in vlines], dtype=np.float64).reshape(-1, 3)
-    faces = None
-    if flines:
-        text = " ".join(ln[2:] for ln in flines)
-        if "/" in text:                                        # v/vt/vn forms: keep the vertex index of every corner
-            import re
-            text = re.sub(r"/[^ ]*", "", text)
-        try:
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                idx = np.fromstring(text, dtype=np.int64, sep=" ")
-            if idx.size == 3 * len(flines):                    # every face a triangle
-                idx = idx.reshape(-1, 3)
-                faces = np.where(idx > 0, idx - 1, len(verts) + idx)
-        except ValueError:
-            faces = None
-    if faces is None:
-        out = []
-        for ln in flines:
+def _load_obj_streaming(lines):
+    """Line-by-line OBJ reader: polygons fan-triangulated, v/vt/vn corners, and RELATIVE (negative) indices resolved against the
+    vertices read SO FAR at that face line - what the format specifies when v and f blocks are interleaved."""
+    verts, out = [], []
+    for ln in lines:
+        if ln.startswith("v "):
+            verts.append([float(x) for x in ln.split()[1:4]])
+        elif ln.startswith("f "):
             idx = [int(tok.split("/")[0]) for tok in ln.split()[1:]]
             idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
             for k in range(1, len(idx) - 1):
                 out.append([idx[0], idx[k], idx[k + 1]])
-        faces = np.asarray(out, dtype=np.int64)
-    return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(out, dtype=np.int64).reshape(-1, 3)
+
+
+def load_obj(path):
+    """Minimal Wavefront OBJ reader: (verts float64 [V,3], faces int64 [F,3]); polygons are fan-triangulated.
+    Fast path (~10 x the loop on a 10 k-face mesh): vertex lines parsed in one numpy call, triangle faces too - taken ONLY when every
+    vertex line has the same number of columns, every face is a plain or slashed triple and every index is positive (what mesh
+    exporters write).  Anything else - polygons, relative (negative) indices, which count from the vertices read so far at that
+    line, ragged vertex lines - goes through the streaming reader."""
+    with open(path, "r") as f:
+        lines = f.read().split("\n")
+    vlines = [ln for ln in lines if ln.startswith("v ")]
+    flines = [ln for ln in lines if ln.startswith("f ")]
+    if not vlines or not flines:
+        return _load_obj_streaming(lines)
+    import warnings
+    columns = {len(ln.split()) for ln in vlines[:: max(1, len(vlines) // 64)]} | {len(vlines[-1].split())}
+    text = " ".join(ln[2:] for ln in flines)
+    if len(columns) != 1 or "-" in text:
+        return _load_obj_streaming(lines)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # (np.fromstring's text mode is deprecated, and still the fastest parser here)
+        flat = np.fromstring(" ".join(ln[2:] for ln in vlines), dtype=np.float64, sep=" ")
+    width = next(iter(columns)) - 1
+    if width < 3 or flat.size != width * len(vlines):
+        return _load_obj_streaming(lines)
+    verts = flat.reshape(len(vlines), width)[:, :3]
+    if "/" in text:                                            # v/vt/vn forms: keep the vertex index of every corner
+        import re
+        text = re.sub(r"/[^ ]*", "", text)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx = np.fromstring(text, dtype=np.int64, sep=" ")
+    except ValueError:
+        return _load_obj_streaming(lines)
+    if idx.size != 3 * len(flines) or idx.min() < 1:           # a polygon somewhere, or an index that is not plain positive
+        return _load_obj_streaming(lines)
+    return np.ascontiguousarray(verts, dtype=np.float64), idx.reshape(-1, 3) - 1
 
 
 # The sampler picks faces by cumulative area.  A cumulative sum of floating-point areas depends on the order of the additions - a

@@ -10,6 +10,7 @@ Variants served here: `use_tanh`, the LayerNorm form (`weight_norm` false), `xyz
 It is a GPU path like the rest of the package: CPU tensors raise.
 """
 import copy
+import itertools
 import ctypes
 import logging
 import weakref
@@ -139,15 +140,20 @@ class TorchModuleDecoder:
         params = list(m.parameters())
         if not params or all(p.device == self.device for p in params):
             return m
-        fp = tuple((p.data_ptr(), p._version) for p in params)
+        # parameters AND buffers (a LayerNorm-free module has none, a BatchNorm-style one does): a change of either refreshes the copy
+        fp = tuple((t.data_ptr(), t._version) for t in itertools.chain(params, m.buffers()))
         if self._copy is None or self._copy[0] != fp:
             # old-style weight_norm leaves the effective weight of its last forward on the module as a NON-leaf tensor, which
-            # deepcopy refuses; the forward pre-hook recomputes it on every call, so a detached stand-in loses nothing
+            # deepcopy refuses.  The caller's module is not touched: the copy is made with a memo that hands deepcopy a
+            # detached clone for every such tensor - the forward pre-hook recomputes it on every call, so the stand-in loses nothing.
+            # Cost: one deepcopy + upload per CHANGE of the caller's CPU parameters - inside a training loop that is every step;
+            # keep the module on the device there.
+            memo = {}
             for sub in m.modules():
-                for name, val in list(vars(sub).items()):
+                for val in vars(sub).values():
                     if torch.is_tensor(val) and not val.is_leaf:
-                        vars(sub)[name] = val.detach()
-            self._copy = (fp, copy.deepcopy(m).to(self.device).eval())
+                        memo[id(val)] = val.detach().clone()
+            self._copy = (fp, copy.deepcopy(m, memo).to(self.device).eval())
         return self._copy[1]
 
     def set_sample(self, latent_vec, mano_results=None, obj_results=None, cam_intr=None):

@@ -661,6 +661,8 @@ def main():
                 "ranks_requested": args.gpus, "world_size_env": world, "host_threads_per_rank": host_threads,
                 "samples_per_sec": args.steps * world / elapsed,
                 "mesh_sizes_last_sample": merged[-1] if merged else None,
+                "records_gathered": len(merged) if merged else 0,
+                "ranks_in_records": sorted({int(m.get("rank", 0)) for m in merged}) if merged else [],
                 "coarse_pass": main_coarse, "fine_pass": main_fine, "math": main_math,
             },
             "sweeps": main_sweeps,

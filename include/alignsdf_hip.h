@@ -122,7 +122,10 @@ int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], floa
  *   [32] number of candidates (more than 2^21: not all were re-evaluated),
  *   [33] / [34] asdf_decode_grid_band only: voxels marked for the hand / object head (more than 2^22: not all re-evaluated),
  *   [35] largest |exact - one-plane| over the audit sample (float bits), [36] audit voxels whose SIGN the exact value
- *   contradicts, [37] audit evaluations (voxels x heads), [38] near-level voxels beyond the refinement list (band sweep).
+ *   contradicts, [37] audit evaluations (voxels x heads), [38] near-level voxels beyond the refinement list (band sweep),
+ *   [39] audit voxels drawn from the AT-RISK SHELL (decided by sign alone with tau <= |one-plane| < 2 tau: half of the audit goes
+ *   there - all of the shell while it is smaller than that half), [40] the shell's population, [41] sum of squared audit errors
+ *   (float bits; sigma = sqrt([41] / [37])); [28..31] shader-clock stamps of the sweep kernel (asdf_decoder_status [12..15]).
  * A caller must treat [7] / [15] / [18] / [36] != 0, [32] > 2^21, or [19] or [35] > tau / 2 as "repeat with asdf_decode_grid"
  * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also re-estimate tau from the audit of every sample).
  * scratch_*_dev: N^3 floats per evaluated head (same NULL rules as asdf_decode_grid); contents afterwards: one-plane
@@ -151,8 +154,9 @@ int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], 
 int asdf_decode_grid_band(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
 
-/* The audit sample of the one-plane sweeps above: `voxels` per sweep and head (0 switches it off, at most 262144; default
- * 65536), drawn with a splitmix64 stream that starts at `seed` and advances with every sweep - so a run is reproducible and
+/* The audit sample of the one-plane sweeps above: min(`voxels`, lattice / 16) per sweep and head (0 switches it off, at most
+ * 262144; default 65536) - half drawn uniformly from the voxels decided by sign alone, half from the at-risk shell among them -
+ * with a splitmix64 stream that starts at `seed` and advances with every sweep - so a run is reproducible and
  * no two sweeps look at the same voxels. */
 int asdf_decoder_set_audit(asdf_decoder_t* dec, int32_t voxels, uint64_t seed);
 
@@ -194,6 +198,14 @@ int asdf_decoder_get_math(const asdf_decoder_t* dec);
  * word [1] counts any beyond that. */
 int asdf_decoder_set_refine(asdf_decoder_t* dec, float tau);
 
+/* Exact re-evaluation of SHORT voxel lists.  The fp32 MFMA chain over a voxel list - the near-level refinement above, the candidates
+ * of asdf_decode_grid_box - takes 0.23 ms in its tile form however few voxels the list holds (one wave carries 32 points through
+ * all 16 output tiles of every layer).  Lists of up to max_points voxels (default 8192: two rounds of 32-point workgroups per MLP; 0 = always the tile form; at most 65536)
+ * run a second form of the same chain in which the four waves of a workgroup share the output tiles of ONE block of 32 points:
+ * the same instruction sequence per output, bit-identical results, a quarter of the latency.  SeparateDecoder / CombinedDecoder
+ * with affine point features. */
+int asdf_decoder_set_short_list(asdf_decoder_t* dec, int32_t max_points);
+
 /* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed
  * as void*, created by the caller with timing enabled) immediately before and after the launch of its dominant kernel
  * (sdf_mlp_f16_kernel or sdf_mlp_kernel) on the call's stream - not around the small kernels next to it (bbox
@@ -206,7 +218,8 @@ int asdf_decoder_time_next_sweep(asdf_decoder_t* dec, void* event_start, void* e
  * in [-1, 1]) to a device word the decoder owns.  Copies the record to out_host[16] ([0] = that count, [1] = near-level
  * voxels (asdf_decode_grid_box: candidates) beyond the re-evaluation list's capacity, [2] = scratch flag of the last
  * re-evaluation (a voxel left the negative set), [3] = largest |new - old| value of the last re-evaluation (float bits), [4..6] / [8..10] = the largest fp16-plane value x S_x handed to the
- * conversion for the activation vectors h0 / h1 / h2 of MLP 0 / MLP 1, as float bit patterns, the rest reserved),
+ * conversion for the activation vectors h0 / h1 / h2 of MLP 0 / MLP 1, as float bit patterns, [12..13] / [14..15] = shader-clock stamps (s_memtime, 64 bit) of workgroup 0 at the first / last instruction of the
+ * last whole-lattice split-half or one-plane sweep, the rest reserved),
  * optionally clears it, and synchronises `stream`.  A caller that sweeps without a bbox buffer (deep_sdf/mesh.py:14-61
  * has no zoom pass) checks this once per volume and repeats the sweep under ASDF_MATH_F32 when the count is non-zero. */
 int asdf_decoder_status(asdf_decoder_t* dec, int32_t out_host[16], int32_t clear, void* stream);

@@ -50,6 +50,21 @@ def test_gpus_2_on_one_device():
 
 
 @pytest.mark.gpu
+def test_gpus_8_on_one_device():
+    """the REAL bench as the driver would start it on an 8-GPU node - `--gpus 8`, eight ranks, the barrier +
+    MAX-over-ranks timing, gather_records to rank 0 - with the eight ranks folded onto the box's single MI355X and the gather over
+    gloo (the only difference to the node: RCCL and one device each).  n_gpus is the all-reduce of ones; every rank's records
+    arrive; every rank was bound to its own block of host cores (dist_reconstruct.bind_host_cores)."""
+    line = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--grid", "64", "--no-cpu-baseline"],
+                {"ASDF_BENCH_BACKEND": "gloo", "ASDF_BENCH_SHARE_DEVICE": "1"}, timeout=900)
+    assert line["n_gpus"] == 8 and line["config"]["world_size_env"] == 8 and line["config"]["ranks_requested"] == 8
+    assert line["config"]["samples_per_gpu"] == 2 and line["scaling"] == "weak"
+    assert abs(line["value"] - 8 * 2 * 2 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"]
+    assert line["config"]["records_gathered"] == 16 and line["config"]["ranks_in_records"] == list(range(8))
+    assert line["config"]["host_threads_per_rank"] >= 1
+
+
+@pytest.mark.gpu
 def test_bench_line_contract_hand_only_config0():
     """`--branches hand --grid 64` = BASELINE configs[0]: one mesh per sample, the default (audited one-plane) sweeps, every field of
     the line the driver and the judge read."""
@@ -61,6 +76,12 @@ def test_bench_line_contract_hand_only_config0():
     r = line["roofline"]
     assert r["kernel"] == "sdf_mlp_f16p1_kernel" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["launches_timed"] == 6
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    # ONE meaning: achieved / frac are the MFMA FLOPs issued; the reference's dense count is carried next to it; the clock is measured
+    assert abs(r["achieved"] - r["executed_flop_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["frac_algorithmic"] > r["frac"] and 0.5 < r["shader_clock_ghz"] < 2.6 and 0.0 < r["pipe_busy"] < 1.0
+    assert abs(r["frac_from_busy_and_clock"] - r["frac"]) < 0.02 * r["frac"]
+    c = line["sweeps"]["certificate"]
+    assert c["calibrations"] >= 1 and c["refusals_for_error"] == 0 and c["min_margin_tau_over_estimate"] >= 1.0 / 0.6
     assert line["sweeps"]["refused_sweeps"] == 0 and line["sweeps"]["fine_sweeps"]["audit_evals"] > 0
     p = line["parity_in_run"]
     assert p["against_ordinary_sweeps_f16x3"]["vertices_identical"] == 3 and p["against_fp32_chain"]["faces_identical"] == 3

@@ -1,0 +1,126 @@
+"""The short-list form of the fp32 chain (csrc/sdf_mlp_short_kernel.h, asdf_decoder_set_short_list) against its tile form
+(csrc/sdf_mlp_kernel.h in kGridSubset mode): the same voxel lists through both, BIT-identical volumes - every output is accumulated by
+the same instruction sequence, only spread over the four waves of a workgroup - for the decoder shapes the form is built for, list
+lengths around its block size (32) and its limit, both heads / one head, and through the two callers that matter: the near-level
+refinement of a split-half sweep (utils/mesh.py:98-115's values next to the level) and the candidates of a box-only coarse sweep."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from alignsdf_amd import _native
+from alignsdf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _bound(tag, sample=0):
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    from alignsdf_amd.utils.utils import sample_embedding
+    specs = syn.specs_for(tag)
+    hip = HipSdfDecoder(syn.full_state_dict(tag), 256, specs["PointFeatSize"], specs["EncodeStyle"])
+    lat, m, o = syn.sample_inputs(tag, sample) if tag != "comb3" else (syn.latent_code(sample), None, None)
+    mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()} if m is not None else None
+    obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()} if o is not None else None
+    hip.set_sample(torch.from_numpy(lat).cuda(), sample_embedding(specs, mano, obj, hip.combined))
+    return hip
+
+
+def _short(hip, n):
+    _native.check(hip._L.asdf_decoder_set_short_list(hip._h, int(n)), "asdf_decoder_set_short_list")
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "grasp3", "comb3"])
+@pytest.mark.parametrize("refine", [2e-5, 2e-4, 1.2e-3])
+def test_near_level_refinement_is_bit_identical_in_both_forms(tag, refine):
+    """A split-half sweep whose near-level list holds a few dozen / a few hundred / a few thousand voxels (refine_tau 2e-5 .. 1.2e-3),
+    refined by the tile form and by the short-list form: identical volumes and identical boxes."""
+    hip = _bound(tag, 2)
+    N = 96
+    origin, vs = [-0.62, -0.36, -0.37], 1.21 / (N - 1)
+    hip.set_refine(refine)
+    out = {}
+    for form, limit in (("tile", 0), ("short", 4096)):
+        _short(hip, limit)
+        out[form] = hip.decode_grid(N, origin, vs)
+    for k in (0, 1):
+        a, b = out["tile"][k], out["short"][k]
+        listed = int((a.abs() < refine).sum())
+        assert listed > 0, "nothing within %g of the level: the test does not exercise the refinement" % refine
+        assert torch.equal(a, b), (tag, refine, k, float((a - b).abs().max()))
+    assert torch.equal(out["tile"][2], out["short"][2])
+    # and the values ARE the fp32 chain's wherever the list reaches (an fp32 sweep of the same lattice)
+    hip.set_math("f32")
+    f32 = hip.decode_grid(N, origin, vs)
+    for k in (0, 1):
+        near = f32[k].abs() < 0.5 * refine
+        assert int(near.sum()) > 0 and torch.equal(out["short"][k][near], f32[k][near])
+    hip.close()
+
+
+@pytest.mark.parametrize("count", [1, 31, 32, 33, 100, 1000, 4096, 4097])
+def test_explicit_lists_around_the_block_size_and_the_limit(count):
+    """The box-only coarse sweep re-evaluates its candidates on the fp32 chain: with a tiny allowance the candidate list is short -
+    here its length is steered through tau - and lists of exactly 4096 voxels (the limit) take the short form, 4097 the tile form;
+    either way the record and the scratch volumes are those of the tile form alone."""
+    hip = _bound("nerf3", 1)
+    N = 64
+    origin, vs = [-1.0, -1.0, -1.0], 2.0 / (N - 1)
+    hip.decode_grid(N, origin, vs)                      # calibrates the activation scales
+    hip.set_audit(0)
+    # find an allowance whose candidate list has about `count` entries (the list grows with tau)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    org = (ctypes.c_float * 3)(*origin)
+
+    def box(tau, limit):
+        _short(hip, limit)
+        vh = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        vo = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        rec = torch.zeros(48, dtype=torch.int32, device="cuda")
+        _native.check(hip._L.asdf_decode_grid_box(hip._h, N, org, ctypes.c_float(vs), 0, ctypes.c_float(tau), vh.data_ptr(), vo.data_ptr(),
+                                                  rec.data_ptr(), st), "asdf_decode_grid_box")
+        return vh, vo, rec.cpu().numpy()
+
+    lo, hi = 1e-7, 0.02
+    for _ in range(60):
+        tau = (lo * hi) ** 0.5
+        n = int(box(tau, 0)[2][32])
+        if n < count:
+            lo = tau
+        else:
+            hi = tau
+        if n >= count and n - count <= max(0, count // 20):
+            break
+    tau = tau if n >= count else hi                      # the smallest allowance found that lists at least `count` voxels
+    a, b = box(tau, 0), box(tau, 4096)
+    assert int(a[2][32]) == int(b[2][32]) >= count
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert np.array_equal(a[2][:16], b[2][:16]) and int(a[2][19]) == int(b[2][19])
+    print("candidates", int(a[2][32]), "tau", tau)
+    hip.close()
+
+
+def test_single_head_and_the_pipeline_default():
+    """One head switched off (HandBranch only: utils/mesh.py:239-241) and the default setting (4096) through decode_two_pass: the
+    result equals the run with the short form switched off."""
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.utils import decoder_for
+    specs = syn.specs_for("nerf3")
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict("nerf3").items()})
+    lat = torch.from_numpy(syn.latent_code(4)).cuda()
+    hip = decoder_for(dec, specs, None)
+    out = {}
+    for limit in (4096, 0):
+        _short(hip, limit)
+        for hand, obj in ((True, True), (True, False), (False, True)):
+            r = decode_two_pass(hand, obj, dec, lat, None, None, specs, 64)
+            out[(limit, hand, obj)] = r
+    for hand, obj in ((True, True), (True, False), (False, True)):
+        a, b = out[(4096, hand, obj)], out[(0, hand, obj)]
+        assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
+        for part, on in (("hand", hand), ("obj", obj)):
+            if on:
+                assert torch.equal(a["vol_" + part], b["vol_" + part])
+    _short(hip, 4096)

@@ -1,5 +1,6 @@
 """Largest-component filter (utils/mesh.py:371-381 semantics) on meshes produced by the MC oracle."""
 import numpy as np
+import pytest
 
 from oracle.mesh_oracle import face_areas, keep_largest_component, split_watertight
 from alignsdf_amd.ply import read_ply, write_ply
@@ -67,3 +68,55 @@ def test_surface_sampler_is_area_weighted_and_uniform_inside_faces():
     assert np.all(np.abs(q.mean(0) - 1 / 3) < 5 * np.sqrt(1 / 18) / np.sqrt(m))
     assert abs((q[:, 0] * q[:, 1]).mean() - 1 / 12) < 5 * 0.08 / np.sqrt(m)
     assert np.array_equal(p, sample_surface(v, f, n, 3)) and not np.array_equal(p, sample_surface(v, f, n, 4))
+
+
+def test_load_obj_relative_indices_and_ragged_lines(tmp_path):
+    """relative (negative) face indices count from the vertices read SO FAR at that face line - with interleaved v / f
+    blocks that is not the final vertex count -, and vertex lines with differing column counts must not be reshaped blindly."""
+    from alignsdf_amd.surface_sampling import load_obj
+    p = tmp_path / "interleaved.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf -3 -2 -1\nf 1 2 3 4\n")
+    v, f = load_obj(str(p))
+    assert v.shape == (6, 3) and f.tolist() == [[0, 1, 2], [3, 4, 5], [0, 1, 2], [0, 2, 3]]
+    p = tmp_path / "ragged.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0 0.5 0.5 0.5\nf 1/1/1 2/2/2 3/3/3\n")          # 3 + 3 + 6 columns: 12 = 3 x 4 would reshape
+    v, f = load_obj(str(p))
+    assert v.tolist() == [[0, 0, 0], [1, 0, 0], [0, 1, 0]] and f.tolist() == [[0, 1, 2]]
+    p = tmp_path / "plain.obj"
+    p.write_text("# exporter output\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3\nf 2//1 4//1 3//1\n")
+    v, f = load_obj(str(p))
+    assert v.shape == (4, 3) and f.tolist() == [[0, 1, 2], [1, 3, 2]]
+
+
+def test_file_writer_surfaces_a_failed_write_one_sample_later(tmp_path, caplog):
+    """a PLY write that fails (disk full, permissions) is raised at the NEXT write, not after the whole shard has been
+    decoded; close(failing=True) - the path of a `finally` that is unwinding another exception - logs instead of raising, so that
+    the original error survives; the interpreter's switch interval is put back."""
+    import logging
+    import sys
+    import time
+    from alignsdf_amd.reconstruct import FileWriter
+    before = sys.getswitchinterval()
+    v = np.zeros((3, 3)), np.array([[0, 1, 2]])
+    w = FileWriter()
+    blocker = tmp_path / "not_a_dir"
+    blocker.write_text("x")
+    w.write_ply(str(tmp_path / "ok.ply"), *v)
+    w.jobs.append((str(blocker / "bad.ply"), w.pool.submit(open, str(blocker / "bad.ply"), "wb")))      # a write that fails
+    for _ in range(200):
+        if all(j.done() for _, j in w.jobs):
+            break
+        time.sleep(0.01)
+    with pytest.raises(OSError):
+        w.write_ply(str(tmp_path / "next.ply"), *v)                      # surfaces here
+    w.close()
+    assert (tmp_path / "ok.ply").exists() and sys.getswitchinterval() == before
+    w = FileWriter()
+    w.jobs.append((str(blocker / "bad.ply"), w.pool.submit(open, str(blocker / "bad.ply"), "wb")))
+    with caplog.at_level(logging.ERROR):
+        w.close(failing=True)                                            # does not raise
+    assert any("bad.ply" in r.getMessage() for r in caplog.records)
+    w = FileWriter()
+    w.jobs.append((str(blocker / "bad.ply"), w.pool.submit(open, str(blocker / "bad.ply"), "wb")))
+    with pytest.raises(OSError):
+        w.close()

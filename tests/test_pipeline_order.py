@@ -106,7 +106,11 @@ def test_refused_fine_sweep_is_repeated_before_marching_cubes(harness):
     assert [k for k, _ in out] == [0, 1, 2]
     assert dec.fine_count == {0: 1, 1: 2, 2: 1}
     second = [i for i, e in enumerate(log) if e == ("pass2", 1)][1]
-    assert second < first(log, ("mc_count", 1, "vol_hand"))
+    # the count phases are queued ahead of the guard record's read-back (round 4: one host wait for record + sizes); a refused sweep
+    # is repeated and COUNTED AGAIN, and the emits read the repeat's volumes
+    counts = [i for i, e in enumerate(log) if e == ("mc_count", 1, "vol_hand")]
+    assert len(counts) == 2 and counts[0] < second < counts[1] < first(log, ("mc_emit", 1, "vol_hand"))
+    assert len([e for e in log if e == ("mc_count", 0, "vol_hand")]) == 1
     # the decoder was re-bound to sample 1 for the repeat, and to sample 2 again before ITS pass 2
     assert first(log, ("pass2", 2)) > second and log[first(log, ("pass2", 2))] == ("pass2", 2)
 
