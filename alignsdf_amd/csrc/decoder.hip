@@ -34,6 +34,7 @@ struct FoldParams {
   int pf[ASDF_MAX_HEADS];
   int kp;                // point-feature K-steps (2 = affine xyz: the A fragments are folded here; > 2 = NeRF: static)
   float s2[ASDF_MAX_HEADS];   // scale of the layer-2 constants: 1 for the fp32 image, S_w2 S_x for the split-half image
+  float s0[ASDF_MAX_HEADS];   // scale of the layer-0 constants: 1, except in the one-plane image (S_x of h0: its accumulators need no rescale)
 };
 
 __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
   const CstOffsets co = cst_offsets(p.kp);
   float* cst = p.cst + (size_t)head * co.floats;
   const int t = row >> 5, rr = row & 31;
-  const float sc = layer ? p.s2[head] : 1.0f;      // a power of two: the scaled values are exact
+  const float sc = layer ? p.s2[head] : p.s0[head];      // a power of two: the scaled values are exact
   if (lane == 0) {
     const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + (p.kp == 2 ? a3 : 0.0f);
     const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict
 // volume (unmarked implies |v| >= tau); box sweep: voxels every evaluated head leaves outside [-tau, tau), some head inside 2 tau.
 __device__ __forceinline__ bool in_audit_shell(const float* __restrict__ a, const float* __restrict__ b,
                                                const unsigned char* __restrict__ mark, long long v, float tau) {
-  if (mark) return mark[v] == 0 && fabsf(a[v]) < 2.0f * tau;
+  if (mark) return mark[v] == 0 && (fabsf(a[v]) < 2.0f * tau || (b && fabsf(b[v]) < 2.0f * tau));      // (b: a CombinedDecoder's second column)
   bool decided = true, close = false;
   if (a) { const float t = a[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
   if (b) { const float t = b[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
@@ -573,6 +574,18 @@ struct asdf_decoder {
   float* stream16_hi;   // the high planes alone (1 KiB records): weight stream of the one-plane kernel (asdf_decode_grid_box)
   float* cst16;
   float* a16;       // [heads][kA16Floats] fp16 point-feature / bias operands of the one-plane kernels (K0b, per sample)
+  // The one-plane kernels' OWN image (round 4): weight scales chosen so that every accumulator already carries its activation's
+  // plane scale - S_w1' = S_x1 / S_x0, S_w2' = S_x2 / S_x1, layer 0's constants times S_x0 - and the epilogue needs no rescale
+  // (a v_pk_mul_f32 per register pair: with the range maximum, a third of the kernel's VALU issue).  cst16p1 = its constants
+  // block, stream16_hi's layer-1 / layer-2 records = the high planes times S_w' / S_w (exact: powers of two); both are rebuilt
+  // from the host copies whenever the activation scales change.
+  float* cst16p1;
+  float* cst16p1_host;
+  uint16_t* hi_host;      // high planes at the split-half scales (the base of every rebuild), hi_count halves
+  uint16_t* hi_scaled;    // staging buffer of the rescaled image
+  size_t hi_count;
+  float s0p[ASDF_MAX_HEADS], s2p[ASDF_MAX_HEADS];
+  int p1_usable;          // 0: a rescaled weight would leave the fp16 range - the one-plane sweeps are not offered for this decoder
   float s2[ASDF_MAX_HEADS];
   int math;
   bool sample_bound;
@@ -626,6 +639,50 @@ static constexpr int kCandDirect = 1 << 15;  // candidates of a box-only sweep t
 static constexpr int kBandCap = 1 << 22;     // voxels per head the narrow-band sweep re-evaluates at most (25 % of 256^3)
 
 // SeparateDecoder: 2 MLPs x 1 output; CombinedDecoder: 1 MLP x 2 outputs
+// (Re)build the one-plane image for the activation scales in force: constants block + the layer-1 / layer-2 records of the
+// high-plane stream (see asdf_decoder::cst16p1).  Host work on ~1 M halves + two uploads; the caller has synchronised.
+static hipError_t rebuild_one_plane(asdf_decoder* d) {
+  if (!d->stream16_hi || !d->hi_host) return hipSuccess;
+  const CstOffsets co = cst_offsets(d->kp);
+  const size_t n = (size_t)kHeads * co.floats;
+  std::memcpy(d->cst16p1_host, d->cst_host, n * sizeof(float));
+  d->p1_usable = 1;
+  std::memcpy(d->hi_scaled, d->hi_host, d->hi_count * sizeof(uint16_t));
+  for (int h = 0; h < d->spec.num_heads; ++h) {
+    const float sx0 = d->sx[h][0], sx1 = d->sx[h][1], sx2 = d->sx[h][2];
+    const float sw1p = sx1 / sx0, sw2p = sx2 / sx1, sw3 = d->sw[h][2];
+    const float* c = d->cst_host + (size_t)h * co.floats;
+    float* o = d->cst16p1_host + (size_t)h * co.floats;
+    for (int i = 0; i < kTilesL1 * 32; ++i) o[co.b1 + i] = c[co.b1 + i] * (sw1p * sx0);
+    const float s3 = sw3 * sx2;
+    for (int i = 0; i < kHidden; ++i) { o[co.b3 + i] = c[co.b3 + i] * s3; o[co.w4 + i] = c[co.w4 + i] / s3; o[co.w4b + i] = c[co.w4b + i] / s3; }
+    o[co.b4] = c[co.b4]; o[co.b4 + 1] = c[co.b4 + 1];
+    o[co.b4 + 2] = o[co.b4 + 3] = o[co.b4 + 4] = 1.0f;                       // (the multipliers of the split-half image: unused here)
+    d->s0p[h] = sx0;
+    d->s2p[h] = sw2p * sx1;
+    // records of one head: [0, 256) layer 1, [256, 512) layer 2, [512, 1024) layer 3 (unchanged), 512 halves each
+    const float f[2] = {sw1p / d->sw[h][0], sw2p / d->sw[h][1]};
+    for (int l = 0; l < 2; ++l) {
+      uint16_t* rec = d->hi_scaled + ((size_t)h * 1024 + (size_t)l * 256) * 512;
+      float top = 0.0f;
+      for (size_t i = 0; i < (size_t)256 * 512; ++i) {
+        _Float16 v;
+        std::memcpy(&v, rec + i, 2);
+        const float w = (float)v * f[l];
+        top = std::fmax(top, std::fabs(w));
+        v = (_Float16)w;
+        std::memcpy(rec + i, &v, 2);
+      }
+      // the largest weight must stay a comfortable fp16 number: below 2^15, and high enough that weights down to 2^-8 of it are
+      // still normal (they carry the product sums; smaller ones go subnormal, 2^-25 absolute - far below the one-plane error)
+      if (!(top < 32768.0f) || !(top >= 0.015625f)) d->p1_usable = 0;
+    }
+  }
+  hipError_t e = hipMemcpy(d->cst16p1, d->cst16p1_host, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d->stream16_hi, d->hi_scaled, d->hi_count * sizeof(uint16_t), hipMemcpyHostToDevice);
+  return e;
+}
+
 static bool spec_supported(const asdf_decoder_spec_t* s) {
   if (s->latent_size != kLatent || s->hidden != kHidden) return false;
   if (s->feature_mode == ASDF_FEATURES_NERF) {
@@ -641,7 +698,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 120; }
+int asdf_version(void) { return 122; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -672,7 +729,7 @@ int asdf_device_count(void) {
 
 void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
-  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi, d->a16};
+  float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi, d->a16, d->cst16p1};
   if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
   if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
   if (d->ev_join) (void)hipEventDestroy(d->ev_join);
@@ -690,6 +747,9 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   (void)hipFree(d->shell_count);
   std::free(d->cst_host);
   std::free(d->cst16_host);
+  std::free(d->cst16p1_host);
+  std::free(d->hi_host);
+  std::free(d->hi_scaled);
   delete d;
 }
 
@@ -741,6 +801,13 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
       for (size_t r = 0; r < nrec; ++r) std::memcpy(&hi[r * 512], &hp.stream16[r * 1024], 512 * sizeof(uint16_t));
       e = hipMalloc((void**)&d->stream16_hi, hi.size() * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMemcpy(d->stream16_hi, hi.data(), hi.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+      d->hi_count = hi.size();
+      d->hi_host = (uint16_t*)std::malloc(hi.size() * sizeof(uint16_t));
+      d->hi_scaled = (uint16_t*)std::malloc(hi.size() * sizeof(uint16_t));
+      d->cst16p1_host = (float*)std::malloc(hp.cst.size() * sizeof(float));
+      if (!d->hi_host || !d->hi_scaled || !d->cst16p1_host) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
+      std::memcpy(d->hi_host, hi.data(), hi.size() * sizeof(uint16_t));
+      if (e == hipSuccess) e = hipMalloc((void**)&d->cst16p1, hp.cst.size() * sizeof(float));
       if (e == hipSuccess) e = hipMalloc((void**)&d->a16, (size_t)kHeads * kA16Floats * sizeof(float));
       if (e == hipSuccess) e = hipMemset(d->a16, 0, (size_t)kHeads * kA16Floats * sizeof(float));
     }
@@ -752,6 +819,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     d->cst16_host = (float*)std::malloc(hp.cst.size() * sizeof(float));
     if (!d->cst_host || !d->cst16_host) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
     std::memcpy(d->cst_host, hp.cst.data(), hp.cst.size() * sizeof(float));
+    if (e == hipSuccess) e = rebuild_one_plane(d);          // the one-plane image at the default activation scales
     if (e == hipSuccess) e = k1h_prepare();
   }
   if (e == hipSuccess) e = k1_prepare();
@@ -824,15 +892,21 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
   }
   FoldParams fp;
   fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
-  for (int h = 0; h < kHeads; ++h) { fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0; fp.s2[h] = 1.0f; }
+  for (int h = 0; h < kHeads; ++h) { fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0; fp.s2[h] = 1.0f; fp.s0[h] = 1.0f; }
   fp.kp = d->kp;
   hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
   if (d->cst16) {      // the same fold into the split-half image, layer-2 constants scaled
     fp.cst = d->cst16;
     for (int h = 0; h < kHeads; ++h) fp.s2[h] = d->s2[h];
     hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
-    if (d->a16)       // the one-plane kernels' fp16 point-feature / bias operands, from the image just folded
-      hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16, d->a16, d->status);
+    if (d->a16) {
+      // ... and into the one-plane image (its own scales), whose layer-0 constants then become the kernels' fp16 point-feature /
+      // bias operands
+      fp.cst = d->cst16p1;
+      for (int h = 0; h < kHeads; ++h) { fp.s2[h] = d->s2p[h]; fp.s0[h] = d->s0p[h]; }
+      hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+      hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16p1, d->a16, d->status);
+    }
   }
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
@@ -1009,7 +1083,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
                          float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream) {
   if (!d || !origin || !bbox_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
-  if (!d->stream16_hi || !d->sample_bound) return ASDF_EINVAL;        // affine point features only (kp == 2)
+  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;        // affine point features only (kp == 2)
   const bool two_out = d->spec.num_heads == 1;
   if (two_out ? !(scratch_hand_dev && scratch_obj_dev) : !(scratch_hand_dev || scratch_obj_dev)) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1018,7 +1092,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   p.sdf0 = scratch_hand_dev; p.sdf1 = scratch_obj_dev; p.bbox = bbox_dev;
   p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
-  p.stream = d->stream16_hi; p.cst = d->cst16; p.a16 = d->a16; p.status = d->status;
+  p.stream = d->stream16_hi; p.cst = d->cst16p1; p.a16 = d->a16; p.status = d->status;
   p.first_mlp = 0; p.num_mlps = d->spec.num_heads; p.pf = d->spec.point_feats[0];
   if (!two_out) {
     if (!p.sdf1) p.num_mlps = 1;
@@ -1095,8 +1169,9 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
   if (!d || !origin || !rec_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
-  if (!d->stream16_hi || !d->sample_bound || d->spec.num_heads != 2) return ASDF_EINVAL;      // SeparateDecoder, affine features
-  if (!sdf_hand_dev && !sdf_obj_dev) return ASDF_EINVAL;
+  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;              // affine point features only
+  const bool two_out = d->spec.num_heads == 1;       // CombinedDecoder: one MLP, both columns from every evaluation
+  if (two_out ? !(sdf_hand_dev && sdf_obj_dev) : (!sdf_hand_dev && !sdf_obj_dev)) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)N * N * N;
   if (!d->band_idx) {
@@ -1114,10 +1189,12 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = rec_dev;      // (the box words are by-products; 7 / 15 carry the range report)
   p.P = P; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
   p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
-  p.stream = d->stream16_hi; p.cst = d->cst16; p.a16 = d->a16; p.status = d->status;
-  p.first_mlp = 0; p.num_mlps = 2; p.pf = d->spec.point_feats[0];
-  if (!p.sdf1) p.num_mlps = 1;
-  else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
+  p.stream = d->stream16_hi; p.cst = d->cst16p1; p.a16 = d->a16; p.status = d->status;
+  p.first_mlp = 0; p.num_mlps = d->spec.num_heads; p.pf = d->spec.point_feats[0];
+  if (!two_out) {
+    if (!p.sdf1) p.num_mlps = 1;
+    else if (!p.sdf0) { p.first_mlp = 1; p.num_mlps = 1; }
+  }
   // the record, the two band counts, status [1] near-level voxels beyond the list / [3] largest |exact - one-plane| of this call,
   // the audit record and the near-level count
   hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, st, p.bbox, ClearRange{d->band_count, 2}, ClearRange{d->status + 1, 3},
@@ -1125,16 +1202,20 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   const long long ntiles = (P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
-  k1h_box_launch(false, p, grid, st);
+  k1h_box_launch(two_out, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
   float* vols[2] = {sdf_hand_dev, sdf_obj_dev};
-  for (int h = 0; h < 2; ++h) {
+  // SeparateDecoder: one list per head (an MLP is evaluated for ITS marked voxels only).  CombinedDecoder (networks/model.py:149-188):
+  // every evaluation yields both columns, so the corners of the cells that can be active in EITHER volume are marked into one list
+  // (h = 0) and re-evaluated once.
+  for (int h = 0; h < (two_out ? 1 : 2); ++h) {
     if (!vols[h]) continue;
     ASDF_HIP(hipMemsetAsync(d->band_mark, 0, (size_t)P, st));
     const long long groups = (long long)(((N - 1) + 3) >> 2) * (N - 1) * (N - 1);
     const int mgrid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
     hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[h], N, tau, d->band_mark);
+    if (two_out) hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[1], N, tau, d->band_mark);
     const long long items = (P + 15) / 16;
     const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     int* list = d->band_idx + (size_t)h * kBandCap;
@@ -1142,34 +1223,38 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     // the audit picks of this head - unmarked voxels, i.e. voxels marching cubes will read the SIGN of and nothing else - ride
     // behind the marked ones in the same list (positions >= audit_rec[4 + h])
     ASDF_HIP(hipMemcpyAsync(d->audit_rec + 4 + h, d->band_count + h, sizeof(int), hipMemcpyDeviceToDevice, st));
-    { const int rc = enqueue_audit_picks(d, vols[h], nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
+    { const int rc = enqueue_audit_picks(d, vols[h], two_out ? vols[1] : nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
     // the values of the ordinary sweep at the listed voxels of this head: the split-half kernel over the list ...
     DecodeParams q = p;
     q.stream = d->stream16; q.cst = d->cst16; q.bbox = nullptr; q.neg_thr = 0.0f;
-    q.sdf0 = h == 0 ? vols[0] : nullptr; q.sdf1 = h == 1 ? vols[1] : nullptr;
-    q.first_mlp = h; q.num_mlps = 1;
+    if (!two_out) { q.sdf0 = h == 0 ? vols[0] : nullptr; q.sdf1 = h == 1 ? vols[1] : nullptr; }
+    q.first_mlp = two_out ? 0 : h; q.num_mlps = 1;
     q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = list; q.count_dev = d->band_count + h; q.P = kBandCap;
     q.audit = d->audit_n > 0 ? d->audit_rec : nullptr; q.audit_from = d->audit_rec + 4 + h;
     const int rgrid = kBandCap / kWgPts < d->num_cus ? kBandCap / kWgPts : d->num_cus;
-    k1h_subset_launch(false, q, rgrid, st);
+    k1h_subset_launch(two_out, q, rgrid, st);
   }
   if (d->refine_tau > 0.0f) {
     // ... and, as behind every split-half sweep, the fp32 chain where those values lie within refine_tau of the level (both
     // MLPs over the union of the two near-level lists: an extra exact value is harmless)
     for (int h = 0; h < 2; ++h)
-      if (vols[h])
-        hipLaunchKernelGGL(collect_near_level_list_kernel, dim3(256), dim3(256), 0, st, vols[h], d->band_idx + (size_t)h * kBandCap,
-                           d->band_count + h, kBandCap, d->refine_tau, d->near_idx, d->near_count, kNearCap, d->status);
+      if (vols[h]) {
+        const int l = two_out ? 0 : h;       // (a CombinedDecoder's one list serves both volumes)
+        hipLaunchKernelGGL(collect_near_level_list_kernel, dim3(256), dim3(256), 0, st, vols[h], d->band_idx + (size_t)l * kBandCap,
+                           d->band_count + l, kBandCap, d->refine_tau, d->near_idx, d->near_count, kNearCap, d->status);
+      }
     DecodeParams q = p;
     q.stream = d->stream; q.cst = d->cst; q.bbox = nullptr; q.neg_thr = 0.0f; q.status = nullptr;
     q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = d->near_count; q.P = kNearCap;
     const int ngrid = kNearCap / kWgPts < d->num_cus ? kNearCap / kWgPts : d->num_cus;
-    { const int rc = launch_subset(d, q, false, ngrid, st); if (rc != ASDF_OK) return rc; }
+    { const int rc = launch_subset(d, q, two_out, ngrid, st); if (rc != ASDF_OK) return rc; }
   }
   hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, rec_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }
+
+int asdf_decoder_one_plane_usable(const asdf_decoder_t* d) { return d && d->stream16_hi && d->p1_usable ? 1 : 0; }
 
 int asdf_decoder_set_short_list(asdf_decoder_t* d, int32_t max_points) {
   if (!d || max_points < 0 || max_points > (1 << 16)) return ASDF_EINVAL;
@@ -1245,6 +1330,7 @@ int asdf_decoder_set_act_scales(asdf_decoder_t* d, const float sx[ASDF_MAX_HEADS
   std::memcpy(d->cst16_host, d->cst_host, n * sizeof(float));
   scale_constants_f16(d->spec, d->kp, d->cst_host, d->sw, d->sx, d->cst16_host, d->s2);
   ASDF_HIP(hipMemcpy(d->cst16, d->cst16_host, n * sizeof(float), hipMemcpyHostToDevice));
+  ASDF_HIP(rebuild_one_plane(d));
   d->sample_bound = false;                                 // the folded per-sample constants carried the old layer-2 scale
   return ASDF_OK;
 }

@@ -43,14 +43,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
 // v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
 // v_pack per register on top)
+// (The one-plane kernels' own image - decoder.hip: rebuild_one_plane - is scaled so that an accumulator IS its activation's plane
+// value: no multiply, and no running maximum either - an activation that leaves the fp16 range becomes an infinity that reaches the
+// output as exactly +-1 or a NaN, which the tile's epilogue reports: ASDF16_P1_FOLD.  Three VALU instructions per register pair
+// instead of five.)
+#ifndef ASDF16_P1_FOLD
+#define ASDF16_P1_FOLD 1
+#endif
 __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
   f32x2 t;
   t[0] = __int_as_float(max(__float_as_int(a0), 0));
   t[1] = __int_as_float(max(__float_as_int(a1), 0));
+#if !ASDF16_P1_FOLD
   t = t * mul;
 #ifndef ASDF16_NO_RANGE_CHECK
   amax = fmaxf(amax, fmaxf(t[0], t[1]));
   asm volatile("" : "+v"(amax));
+#endif
 #endif
   const h2 r = __builtin_convertvector(t, h2);
   u32x4 d = __builtin_bit_cast(u32x4, dst);
@@ -855,8 +864,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
       amax = amax; amax1 = amax1; amax2 = amax2;
       const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
-      const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !(fabsf(sdf) <= 1.0f) || (TWO_OUT && !(fabsf(sdfb) <= 1.0f)) ||
-                                            (G == 2 && !(fabsf(sdfg) <= 1.0f)))) ? 1 : 0;
+      // (one-plane kernels, folded image: no running maximum - an overflowed activation is an infinity by now, and the output it
+      // reaches is exactly +-1 or a NaN: no decoder of a clamped SDF gets there honestly)
+      constexpr bool kStrict = PL == 1 && ASDF16_P1_FOLD;
+      auto out_ok = [&](float v) { return kStrict ? fabsf(v) < 1.0f : fabsf(v) <= 1.0f; };
+      const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !out_ok(sdf) || (TWO_OUT && !out_ok(sdfb)) ||
+                                            (G == 2 && !out_ok(sdfg)))) ? 1 : 0;
       if ((valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
         atomicMax(wrec + 16, __float_as_int(amax));
         atomicMax(wrec + 17, __float_as_int(amax1));

@@ -670,8 +670,12 @@ class HipSdfDecoder:
     # ---- the coarse pass of the two-pass flow (utils/mesh.py:27-63): consumed only through get_higher_res_cube, i.e. the
     # per-head boxes of its negative voxels.  begin() enqueues, finish() reads the record back (the one host
     # synchronisation the zoom cube needs anyway) and repeats the sweep where a guard asks for it.
+    def _one_plane_ok(self):
+        """The one-plane kernels' own weight image exists under the current activation scales (asdf_decoder_one_plane_usable)."""
+        return self._h is None or bool(self._L.asdf_decoder_one_plane_usable(self._h))
+
     def _box_usable(self):
-        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features
+        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features and self._one_plane_ok()
 
     def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
         return self._one_plane_launch(self._L.asdf_decode_grid_box, "asdf_decode_grid_box", N, origin3, voxel_size, grid_mode, hand, obj, tau)
@@ -744,7 +748,7 @@ class HipSdfDecoder:
 
     # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else
     def _band_usable(self):
-        return self.fine_mode == "band" and self.math == "f16x3" and not self.nerf_features and not self.combined
+        return self.fine_mode == "band" and self.math == "f16x3" and not self.nerf_features and self._one_plane_ok()
 
     def fine_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True, mc_only=False):
         """Enqueue the fine pass; returns (sdf_hand, sdf_obj, ticket).  The caller hands the ticket to fine_needs_repeat

@@ -150,9 +150,17 @@ int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], 
  * than 2^22: not all were re-evaluated), [35] .. [37] the audit: per head, asdf_decoder_set_audit UNMARKED voxels - voxels whose
  * sign is all marching cubes will read - drawn at random and re-evaluated with the marked ones; [38] near-level voxels beyond
  * the refinement list.  A caller must repeat with asdf_decode_grid when [7] / [15] / [36] / [38] != 0, [33] or [34] > 2^22, or
- * [19] or [35] > tau / 2 (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  SeparateDecoder, affine features. */
+ * [19] or [35] > tau / 2 (alignsdf_amd/hip_decoder.py: fine_begin / fine_needs_repeat).  Affine point features.  A CombinedDecoder
+ * (networks/model.py:149-188: both columns from one MLP) marks the cells that can be active in EITHER volume into ONE list ([33];
+ * [34] stays 0) and re-evaluates both columns of every listed voxel. */
 int asdf_decode_grid_band(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
+
+/* 1 when asdf_decode_grid_box / asdf_decode_grid_band are available for this decoder under its current activation scales.  The
+ * one-plane kernels keep their own weight image, scaled so that every accumulator already carries its activation's plane scale
+ * (no rescale in the epilogue); a decoder whose consecutive layers differ by more than 2^15 in activation magnitude cannot be
+ * carried that way (0: the caller runs ordinary sweeps).  Changes with asdf_decoder_set_act_scales. */
+int asdf_decoder_one_plane_usable(const asdf_decoder_t* dec);
 
 /* The audit sample of the one-plane sweeps above: min(`voxels`, lattice / 16) per sweep and head (0 switches it off, at most
  * 262144; default 65536) - half drawn uniformly from the voxels decided by sign alone, half from the at-risk shell among them -

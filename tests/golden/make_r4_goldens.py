@@ -30,6 +30,9 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 TMP = "/tmp/asdf_r4_%s_%d_s%d_%s.npy"
 PLAN = ((128, (0, 1, 2, 3, 5)), (256, (0, 3)))
+# "comb3": the CombinedDecoder (networks/model.py:79-188, ModelType 1encoder1decoder) of the sphere + box family at N = 128, samples
+# 1 and 2 - the pin of its narrow-band fine sweep (round 4: one list of the cells that can be active in either column)
+PLANS = {"comb3": ((128, (1, 2)),)}
 
 
 def out_path(tag):
@@ -45,10 +48,11 @@ def decode(tags):
     arch, um, uu, _ = mrg.import_reference()
     for tag in tags:
         specs, sd = syn.specs_for(tag), syn.full_state_dict(tag)
-        dec = arch.SeparateDecoder(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
+        cls = arch.CombinedDecoder if specs["ModelType"] == "1encoder1decoder" else arch.SeparateDecoder
+        dec = cls(256, specs["PointFeatSize"], specs["EncodeStyle"], **specs["NetworkSpecs"], use_classifier=False).eval()
         dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         gold = dict(np.load(out_path(tag))) if os.path.exists(out_path(tag)) else {}
-        for N, samples in PLAN:
+        for N, samples in PLANS.get(tag, PLAN):
             for s in samples:
                 if "%d/s%d/bbox" % (N, s) in gold:
                     continue
@@ -73,11 +77,12 @@ def mc(tags):
     import make_r3_goldens as r3
     from mc_stats import ambiguous_cells, mesh_components
     from skimage.measure import marching_cubes_lewiner
-    r3.PLAN, r3.TMP, r3.out_path = PLAN, TMP, out_path
-    r3.mc(tags)
+    for tag in tags:
+        r3.PLAN, r3.TMP, r3.out_path = PLANS.get(tag, PLAN), TMP, out_path
+        r3.mc([tag])
     for tag in tags:
         gold = dict(np.load(out_path(tag)))
-        for N, samples in PLAN:
+        for N, samples in PLANS.get(tag, PLAN):
             for s in samples:
                 if "%d/s%d/mc_hand" % (N, s) not in gold or "%d/s%d/ambiguous_hand" % (N, s) in gold:
                     continue
@@ -94,8 +99,9 @@ def mc(tags):
 
 def signs(tags):
     import make_r3_goldens as r3
-    r3.PLAN, r3.TMP, r3.out_path = PLAN, TMP, out_path
-    r3.signs(tags)
+    for tag in tags:
+        r3.PLAN, r3.TMP, r3.out_path = PLANS.get(tag, PLAN), TMP, out_path
+        r3.signs([tag])
 
 
 if __name__ == "__main__":

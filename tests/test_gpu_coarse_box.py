@@ -15,17 +15,22 @@ pytestmark = pytest.mark.gpu
 def _decoder(tag):
     from alignsdf_amd.hip_decoder import HipSdfDecoder
     specs = syn.specs_for(tag)
-    return HipSdfDecoder(syn.full_state_dict(tag), 256, specs["PointFeatSize"], specs["EncodeStyle"]), specs
+    hip = HipSdfDecoder(syn.full_state_dict(tag), 256, specs["PointFeatSize"], specs["EncodeStyle"])
+    hip._test_tag = tag if tag in syn.GRASP_TAGS else None      # (_bind: the grasp family has its own trained latent codes)
+    return hip, specs
 
 
 def _bind(hip, specs, sample):
     from alignsdf_amd.utils.utils import sample_embedding
-    mano = obj = None
-    if specs["EncodeStyle"] != "nerf":
+    tag = {(3, "nerf", "1encoder1decoder"): "comb3"}.get((specs["PointFeatSize"], specs["EncodeStyle"], specs["ModelType"]))
+    if tag is None:
+        tag = getattr(hip, "_test_tag", None) or ("nerf3" if specs["EncodeStyle"] == "nerf" else "both9")
+    lat, m, o = (syn.latent_code(sample), None, None) if tag == "comb3" else syn.sample_inputs(tag, sample)
+    if specs["EncodeStyle"] != "nerf" and m is None:
         m, o = syn.pose_inputs(sample)
-        mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()}
-        obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()}
-    hip.set_sample(torch.from_numpy(syn.latent_code(sample)).cuda(), sample_embedding(specs, mano, obj, hip.combined))
+    mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()} if m is not None else None
+    obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()} if o is not None else None
+    hip.set_sample(torch.from_numpy(lat).cuda(), sample_embedding(specs, mano, obj, hip.combined))
 
 
 def _boxes(b):
@@ -166,11 +171,12 @@ def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
 
 # ---- the narrow-band fine sweep (asdf_decode_grid_band, fine_mode "band"): for volumes that go to marching cubes only
 
-@pytest.mark.parametrize("tag,N", [("nerf3", 64), ("nerf3", 128), ("both9", 96), ("nerf3", 256)])
+@pytest.mark.parametrize("tag,N", [("nerf3", 64), ("nerf3", 128), ("both9", 96), ("nerf3", 256), ("comb3", 96), ("comb3", 128), ("grasp3", 128)])
 def test_band_volumes_give_the_identical_meshes(tag, N):
     """Exact values at every corner of every cell that can be active, the right sign everywhere else: marching cubes must
     return the very same vertices and faces as on the volumes of the ordinary sweep, whose values (split-half arithmetic, fp32
-    chain next to the level) the re-evaluated voxels hold."""
+    chain next to the level) the re-evaluated voxels hold.  comb3: the CombinedDecoder (networks/model.py:149-188) - one MLP, both
+    columns, ONE list of the cells that can be active in either volume (round 4)."""
     from alignsdf_amd.marching_cubes import marching_cubes_device
     hip, specs = _decoder(tag)
     hip.coarse_mode, hip.fine_mode = "box", "band"
