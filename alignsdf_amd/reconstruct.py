@@ -338,13 +338,15 @@ class FileWriter:
 
     def poll(self):
         """Raise the failure of any write that has finished; forget the ones that succeeded."""
-        pending = []
+        pending, first = [], None
         for path, j in self.jobs:
-            if j.done():
-                j.result()
-            else:
+            if not j.done():
                 pending.append((path, j))
-        self.jobs = pending
+            elif first is None:
+                first = j.exception()
+        self.jobs = pending                        # (a failure is reported once)
+        if first is not None:
+            raise first
 
     def write_ply(self, path, verts, faces):
         from .ply import write_ply
