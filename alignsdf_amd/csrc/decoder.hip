@@ -408,27 +408,50 @@ __global__ __launch_bounds__(256) void band_mark_kernel(const float* __restrict_
   }
 }
 
-// marked voxels -> index list (order arbitrary); *count counts all of them, also those beyond cap
+// marked voxels -> index list (order arbitrary); *count counts all of them, also those beyond cap.  One reservation on the count
+// word per WORKGROUP and round (wave scans + an LDS hand-over): half a million marked voxels used to be ~1e5 same-address atomics.
 __global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* __restrict__ mark, long long n, int* idx, int* count, int cap) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q * 16 < n; q += stride) {
-    if (q * 16 + 16 <= n) {
-      const uint4 w = reinterpret_cast<const uint4*>(mark)[q];
-      if (!(w.x | w.y | w.z | w.w)) continue;
-      const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-      int c = 0;
+  const long long items = (n + 15) / 16;
+  const long long rounds = (items + stride - 1) / stride;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_wave[4], s_base;
+  for (long long r = 0; r < rounds; ++r) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x + r * stride;
+    unsigned ww[4] = {0u, 0u, 0u, 0u};
+    if (q < items) {
+      if (q * 16 + 16 <= n) {
+        const uint4 w = reinterpret_cast<const uint4*>(mark)[q];
+        ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
+      } else {
+        for (long long i = q * 16; i < n; ++i)
+          if (mark[i]) ww[(i - q * 16) >> 2] |= 1u << (8 * ((i - q * 16) & 3));
+      }
+    }
+    int c = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c += __popc(ww[k] & 0x01010101u);
-      int at = atomicAdd(count, c);
+    for (int k = 0; k < 4; ++k) c += __popc(ww[k] & 0x01010101u);
+    // exclusive position of this thread's entries inside the workgroup's reservation
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      s_base = total ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    int at = s_base + (incl - c);
+    for (int w = 0; w < wave; ++w) at += s_wave[w];
+    if (c) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           if ((ww[k] >> (8 * b)) & 1) { if (at < cap) idx[at] = (int)(q * 16 + 4 * k + b); ++at; }
-    } else {
-      for (long long i = q * 16; i < n; ++i)
-        if (mark[i]) { const int at = atomicAdd(count, 1); if (at < cap) idx[at] = (int)i; }
     }
+    __syncthreads();
   }
 }
 
@@ -518,6 +541,13 @@ __global__ __launch_bounds__(256) void shell_pick_kernel(const float* __restrict
   const long long stride = (long long)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
   const long long rounds = (P + stride - 1) / stride;
+  // the picks of a workgroup are gathered in LDS and handed over with ONE reservation on the list's count word (32 k picks were
+  // 32 k same-address atomics: 0.19 ms per launch); what does not fit the LDS list goes straight to the global one
+  constexpr int kLocal = 2048;
+  __shared__ int s_list[kLocal];
+  __shared__ int s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
   int kept = 0;
   for (long long r = 0; r < rounds; ++r) {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x + r * stride;
@@ -526,10 +556,21 @@ __global__ __launch_bounds__(256) void shell_pick_kernel(const float* __restrict
     const unsigned long long m = __ballot(ok);
     if (!m) continue;
     int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
     base = __shfl(base, 0);
     const int at = base + __popcll(m & ((1ull << lane) - 1));
-    if (ok && at < cap) { list[at] = (int)v; ++kept; }
+    if (ok) {
+      if (at < kLocal) s_list[at] = (int)v;
+      else { const int k = atomicAdd(count, 1); if (k < cap) { list[k] = (int)v; ++kept; } }
+    }
+  }
+  __syncthreads();
+  const int nl = s_n < kLocal ? s_n : kLocal;
+  if (threadIdx.x == 0) s_base = nl ? atomicAdd(count, nl) : 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < nl; j += blockDim.x) {
+    const int k = s_base + j;
+    if (k < cap) { list[k] = s_list[j]; ++kept; }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) kept += __shfl_xor(kept, m);
