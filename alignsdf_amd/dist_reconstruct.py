@@ -106,7 +106,9 @@ def limit_host_threads(world_size, reserve=2, local_rank=None):
     stay free for the rank's ground-truth worker process and its writer / loader threads, which run next to the pool.  The host tail
     of a sample (surface sampling, OBJ parsing, PLY export) is numpy / torch CPU work that defaults to one thread per LOGICAL CPU in
     every process - eight ranks with 256 threads each on a 128-core box fight over the cores and each other's caches.
-    ASDF_HOST_THREADS overrides the count.  Returns the thread count set."""
+    ASDF_HOST_THREADS overrides the count.  The OMP / MKL / OpenBLAS variables are written into os.environ ON PURPOSE: the worker
+    process a rank starts later must come up with the same cap (it is a driver-level call - run_sharded and bench.py make it once per
+    rank; a library user who does not want the process environment touched sets the pools himself).  Returns the thread count set."""
     bound = bind_host_cores(world_size, local_rank) if local_rank is not None else None
     share = physical_cores() if bound else physical_cores() // max(1, int(world_size))      # (bound: the cores of the mask just set)
     n = os.environ.get("ASDF_HOST_THREADS")
