@@ -294,3 +294,60 @@ def test_default_sweeps_on_adversarial_decoders_give_the_ordinary_sweeps_meshes(
           "band", {k: default.band_stats[k] for k in ("band", "exact", "fallback", "max_err", "max_marked")})
     assert default.box_stats["audit_flips"] == 0 and default.band_stats["audit_flips"] == 0
     ordinary.close(); default.close()
+
+
+@pytest.mark.parametrize("tag", ["grasp3", "grasp9"])
+@pytest.mark.parametrize("N", [64, 96, 128])
+def test_grasp_family_at_other_sizes_and_single_branches(tag, N, monkeypatch):
+    """The trained grasp decoders away from the headline size: N = 64 / 96 (not a multiple of 64: ragged tiles) / 128, both branches
+    and each branch alone (HandBranch / ObjectBranch off: the other head is not evaluated, utils/mesh.py:239-247), 8 scenes - among them
+    the ones with a detached blob / piece: zoom cube and every mesh of the default sweeps equal those of ordinary sweeps, no sweep
+    refused for its error."""
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from alignsdf_amd.utils.utils import decoder_for
+    for k in ("ASDF_COARSE", "ASDF_FINE", "ASDF_MATH"):
+        monkeypatch.delenv(k, raising=False)
+    scenes = [0, 1, 3, 5, 7, 10, 13, 15]
+
+    def run(exact):
+        dec, specs = _module(tag)
+        out = {}
+        hip = None
+        for hand, obj in ((True, True), (True, False), (False, True)):
+            for s in scenes:
+                lat, m, o = syn.sample_inputs(tag, s)
+                lat = torch.from_numpy(lat).cuda()
+                mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()} if m is not None else None
+                objr = {k: torch.from_numpy(v).cuda() for k, v in o.items()} if o is not None else None
+                if hip is None:
+                    hip = decoder_for(dec, specs, mano)
+                    if exact:
+                        hip.coarse_mode = hip.fine_mode = "exact"
+                r = decode_two_pass(hand, obj, dec, lat, mano, objr, specs, N, mc_only=True)
+                meshes = []
+                for part, on in (("hand", hand), ("obj", obj)):
+                    if on:
+                        try:
+                            meshes.append(marching_cubes_device(r["vol_" + part], 0.0))
+                        except (ValueError, RuntimeError) as e:
+                            meshes.append(str(e))
+                out[(hand, obj, s)] = (r["origin"], float(r["voxel_size"]), meshes)
+        return out, hip
+
+    want, _ = run(True)
+    got, hip = run(False)
+    assert (hip.coarse_mode, hip.fine_mode) == ("box", "band")
+    for key in want:
+        a, b = want[key], got[key]
+        assert a[0] == b[0] and a[1] == b[1], key
+        for x, y in zip(a[2], b[2]):
+            if isinstance(x, str) or isinstance(y, str):
+                assert x == y, key
+            else:
+                assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), key
+    c = hip.certificate()
+    assert c["refusals_for_error"] == 0 and hip.band_stats["audit_flips"] == 0 and hip.box_stats["audit_flips"] == 0
+    assert hip.band_stats["band"] >= 20, hip.band_stats
+    print(tag, N, "box", {k: hip.box_stats[k] for k in ("box", "exact", "fallback", "max_candidates")},
+          "band", {k: hip.band_stats[k] for k in ("band", "exact", "fallback", "max_marked", "tau_max")}, "tail", c["tail_ratio"])
