@@ -50,7 +50,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef ASDF16_P1_FOLD
 #define ASDF16_P1_FOLD 1
 #endif
+#ifndef ASDF16_P1_PKRELU
+#define ASDF16_P1_PKRELU 1      // folded image: convert first, then ONE packed integer max on the two halves (sign bit set -> +0): the same
+#endif                          // values as ReLU-then-convert, a positive NaN / infinity passes (the range report needs them)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
+#if ASDF16_P1_FOLD && ASDF16_P1_PKRELU
+  f32x2 raw;
+  raw[0] = a0; raw[1] = a1;
+  const h2 c = __builtin_convertvector(raw, h2);
+  s16x2 q = __builtin_bit_cast(s16x2, c);
+  const s16x2 zero = {0, 0};
+  q = __builtin_elementwise_max(q, zero);
+  u32x4 d0 = __builtin_bit_cast(u32x4, dst);
+  d0[w] = __builtin_bit_cast(unsigned, q);
+  dst = __builtin_bit_cast(h8, d0);
+  return;
+#endif
   f32x2 t;
   t[0] = __int_as_float(max(__float_as_int(a0), 0));
   t[1] = __int_as_float(max(__float_as_int(a1), 0));
