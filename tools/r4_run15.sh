@@ -1,0 +1,2 @@
+#!/bin/bash
+timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | tail -6
