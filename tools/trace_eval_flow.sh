@@ -1,7 +1,7 @@
 # Kernel trace of the eval-mode file flow: where does the time over the plain sample pipeline go - GPU work or idle gaps?
 #   gpurun -- 'bash tools/trace_eval_flow.sh'    -> gpurun_out/r3/trace_eval/summary.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3/trace_eval; rm -rf $O; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/${R:-r3}/trace_eval; rm -rf $O; mkdir -p $O
 ASDF_TIMING_REPS=1 ASDF_TIMING_FLOW_ONLY=1 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python tools/time_reconstruct_files.py 256 8 eval > $O/run.log 2>&1
 python3 - <<PY | tee $O/summary.txt
 import csv, glob, collections
