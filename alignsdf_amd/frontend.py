@@ -14,6 +14,8 @@ this build (it needs the datasets and MANO assets); what is here:
   are enqueued on the compute stream where the sample pipeline fetches sample k+2 - between pass 1 and pass 2 of sample k+1 -
   and execute in that gap (tools/time_frontend_overlap.py, profiles/r02_frontend_overlap.txt).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -82,7 +84,7 @@ def encoder_code_source(encoder, image_of, device="cuda"):
     return source
 
 
-def quick_gil_handover(interval=5e-4):
+def quick_gil_handover(interval=float(os.environ.get("ASDF_GIL_INTERVAL", 5e-4))):
     """Worker threads (image decode, ground-truth parsing, PLY writes) hold the interpreter lock between their C calls; with
     CPython's default 5 ms switch interval the main thread - whose job is to keep the GPU's queue full - can wait that long
     for it every time.  0.5 ms makes a worker hand it back promptly."""
