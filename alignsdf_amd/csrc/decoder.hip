@@ -691,15 +691,17 @@ static hipError_t rebuild_one_plane(asdf_decoder* d) {
   std::memcpy(d->hi_scaled, d->hi_host, d->hi_count * sizeof(uint16_t));
   for (int h = 0; h < d->spec.num_heads; ++h) {
     const float sx0 = d->sx[h][0], sx1 = d->sx[h][1], sx2 = d->sx[h][2];
-    const float sw1p = sx1 / sx0, sw2p = sx2 / sx1, sw3 = d->sw[h][2];
+    // (the kernels' ReLU is c + |c| = 2 relu(c) - it keeps NaNs and infinities alive, sdf_mlp_f16_kernel.h - so the accumulators of
+    // layers 0..2 carry HALF their activation's plane scale, and the last layer's weights the other 1 / 2 of its a w + |a| w form)
+    const float sw1p = 0.5f * sx1 / sx0, sw2p = 0.5f * sx2 / sx1, sw3 = d->sw[h][2];
     const float* c = d->cst_host + (size_t)h * co.floats;
     float* o = d->cst16p1_host + (size_t)h * co.floats;
     for (int i = 0; i < kTilesL1 * 32; ++i) o[co.b1 + i] = c[co.b1 + i] * (sw1p * sx0);
     const float s3 = sw3 * sx2;
-    for (int i = 0; i < kHidden; ++i) { o[co.b3 + i] = c[co.b3 + i] * s3; o[co.w4 + i] = c[co.w4 + i] / s3; o[co.w4b + i] = c[co.w4b + i] / s3; }
+    for (int i = 0; i < kHidden; ++i) { o[co.b3 + i] = c[co.b3 + i] * s3; o[co.w4 + i] = 0.5f * c[co.w4 + i] / s3; o[co.w4b + i] = 0.5f * c[co.w4b + i] / s3; }
     o[co.b4] = c[co.b4]; o[co.b4 + 1] = c[co.b4 + 1];
     o[co.b4 + 2] = o[co.b4 + 3] = o[co.b4 + 4] = 1.0f;                       // (the multipliers of the split-half image: unused here)
-    d->s0p[h] = sx0;
+    d->s0p[h] = 0.5f * sx0;
     d->s2p[h] = sw2p * sx1;
     // records of one head: [0, 256) layer 1, [256, 512) layer 2, [512, 1024) layer 3 (unchanged), 512 halves each
     const float f[2] = {sw1p / d->sw[h][0], sw2p / d->sw[h][1]};

@@ -43,27 +43,28 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
 // v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
 // v_pack per register on top)
-// (The one-plane kernels' own image - decoder.hip: rebuild_one_plane - is scaled so that an accumulator IS its activation's plane
-// value: no multiply, and no running maximum either - an activation that leaves the fp16 range becomes an infinity that reaches the
-// output as exactly +-1 or a NaN, which the tile's epilogue reports: ASDF16_P1_FOLD.  Three VALU instructions per register pair
-// instead of five.)
+// (The one-plane kernels' own image - decoder.hip: rebuild_one_plane - is scaled so that an accumulator carries its activation's
+// plane scale: no multiply, and no running maximum either: ASDF16_P1_FOLD.)
 #ifndef ASDF16_P1_FOLD
 #define ASDF16_P1_FOLD 1
 #endif
-#ifndef ASDF16_P1_PKRELU
-#define ASDF16_P1_PKRELU 1      // folded image: convert first, then ONE packed integer max on the two halves (sign bit set -> +0): the same
-#endif                          // values as ReLU-then-convert, a positive NaN / infinity passes (the range report needs them)
-typedef short s16x2 __attribute__((ext_vector_type(2)));
+// The ReLU of the folded image must PRESERVE a poisoned value.  The matrix pipe's inf - inf is a NEGATIVE NaN (0xffc00000,
+// tools/trapsts_probe.hip), and an integer maximum against 0 - the cheapest ReLU - turns it (and a -inf) into a perfectly finite 0:
+// measured, a layer-2 overflow of 512 x the fp16 range reached the output as a finite value.  So: convert first, then
+//     2 relu(c) = c + |c|        (v_and_b32 0x7fff7fff + v_pk_add_f16)
+// exact for finite halves (0 for negative ones, 2 c otherwise), and NaN + NaN = NaN, -inf + inf = NaN, inf + inf = inf: whatever left
+// the fp16 range stays non-finite through every layer, reaches the output as a NaN or exactly +-1, and is reported there.  The factor
+// 2 lives in the image's scales (decoder.hip: rebuild_one_plane carries S_x / 2 in the accumulators).  Three VALU instructions per
+// register pair (round 3: five, with a running maximum that the 512-register budget has no room for: +39 % time when it spills).
 __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
-#if ASDF16_P1_FOLD && ASDF16_P1_PKRELU
+#if ASDF16_P1_FOLD
   f32x2 raw;
   raw[0] = a0; raw[1] = a1;
   const h2 c = __builtin_convertvector(raw, h2);
-  s16x2 q = __builtin_bit_cast(s16x2, c);
-  const s16x2 zero = {0, 0};
-  q = __builtin_elementwise_max(q, zero);
+  const h2 m = __builtin_bit_cast(h2, __builtin_bit_cast(unsigned, c) & 0x7fff7fffu);
+  const h2 r2 = c + m;
   u32x4 d0 = __builtin_bit_cast(u32x4, dst);
-  d0[w] = __builtin_bit_cast(unsigned, q);
+  d0[w] = __builtin_bit_cast(unsigned, r2);
   dst = __builtin_bit_cast(h8, d0);
   return;
 #endif
@@ -743,6 +744,17 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const float w = kW4Tile ? w4t[2 * c + r] : w4c[r];
+          if (PL == 1 && ASDF16_P1_FOLD) {
+            // relu(a) w = a (w / 2) + |a| (w / 2): two FMAs like max + FMA, and a NaN / infinity of either sign stays one (the image's
+            // last-layer weights carry the 1 / 2)
+            if (g != 1) {
+              const float v = a[2 * c + r];
+              part = fmaf(fabsf(v), w, fmaf(v, w, part));
+              if (TWO_OUT) partb = fmaf(fabsf(v), w4bc[r], fmaf(v, w4bc[r], partb));
+            }
+            if (G == 2 && g != 0) { const float v = ab[2 * c + r]; partg = fmaf(fabsf(v), w, fmaf(v, w, partg)); }
+            continue;
+          }
           if (g != 1) {
             const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
             part = fmaf(v, w, part);
@@ -879,14 +891,14 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
       amax = amax; amax1 = amax1; amax2 = amax2;
-      const float amax_all = fmaxf(amax, fmaxf(amax1, amax2));
-      // (one-plane kernels, folded image: no running maximum - an overflowed activation is an infinity by now, and the output it
-      // reaches is exactly +-1 or a NaN: no decoder of a clamped SDF gets there honestly)
+      // (one-plane kernels, folded image: no running maximum - every ReLU preserves a poisoned value, so an activation that left the
+      // fp16 range arrives HERE as a NaN or as exactly +-1: no decoder of a clamped SDF gets there honestly)
       constexpr bool kStrict = PL == 1 && ASDF16_P1_FOLD;
+      const bool act_over = !(fmaxf(amax, fmaxf(amax1, amax2)) < 65504.0f);
       auto out_ok = [&](float v) { return kStrict ? fabsf(v) < 1.0f : fabsf(v) <= 1.0f; };
-      const int bad = ((valid || validb) && (!(amax_all < 65504.0f) || !out_ok(sdf) || (TWO_OUT && !out_ok(sdfb)) ||
+      const int bad = ((valid || validb) && (act_over || !out_ok(sdf) || (TWO_OUT && !out_ok(sdfb)) ||
                                             (G == 2 && !out_ok(sdfg)))) ? 1 : 0;
-      if ((valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
+      if (!kStrict && (valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
         atomicMax(wrec + 16, __float_as_int(amax));
         atomicMax(wrec + 17, __float_as_int(amax1));
         atomicMax(wrec + 18, __float_as_int(amax2));

@@ -416,3 +416,45 @@ def test_large_candidate_lists_take_the_two_step_form(tag, N, hand, obj):
         assert 0.0 < errs[taus[2]] < 0.01
     assert forms == {False, True}, "both forms of re-evaluation should have run (%s)" % forms
     hip.close()
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "grasp3", "comb3"])
+def test_one_plane_kernel_reports_an_fp16_overflow_through_its_outputs(tag):
+    """The one-plane kernels keep no running maximum of their activations (round 4: their own weight image, three VALU instructions per
+    register pair): an activation that leaves the fp16 range becomes an infinity, which must reach the output as exactly +-1 or a NaN
+    and be REPORTED (words 7 / 15 of the record) - with activation scales 2^7 .. 2^9 too large for the decoder the sweep has to say so,
+    and with the calibrated scales it must not."""
+    import ctypes
+    from alignsdf_amd import _native
+    hip, specs = _decoder(tag)
+    _bind(hip, specs, 1)
+    N = 48
+    org, vs = [-1.0, -1.0, -1.0], 2.0 / (N - 1)
+    hip.decode_grid(N, org, vs)                                  # calibrates the activation scales (peaks land in [1024, 2048))
+    good = hip.act_scales().copy()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def sweep():
+        vh = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        vo = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        rec = torch.zeros(48, dtype=torch.int32, device="cuda")
+        o3 = (ctypes.c_float * 3)(*org)
+        _native.check(hip._L.asdf_decode_grid_box(hip._h, N, o3, ctypes.c_float(vs), 0, ctypes.c_float(2e-3), vh.data_ptr(), vo.data_ptr(),
+                                                  rec.data_ptr(), st), "asdf_decode_grid_box")
+        r = rec.cpu().numpy()
+        return (int(r[7]) & 0x3fffffff) + (int(r[15]) & 0x3fffffff)
+
+    assert sweep() == 0
+    for layer in range(3):
+        for boost in (128.0, 512.0):
+            sx = good.copy()
+            sx[:, layer] *= boost                              # peak x boost >= 1.3e5 > 65504: that layer's planes overflow
+            hip.set_act_scales(sx)
+            if not hip._one_plane_ok():
+                continue                                        # (the image cannot be built for such a jump between layers: not offered at all)
+            _bind(hip, specs, 1)
+            assert sweep() > 0, (tag, layer, boost)
+    hip.set_act_scales(good)
+    _bind(hip, specs, 1)
+    assert sweep() == 0
+    hip.close()
