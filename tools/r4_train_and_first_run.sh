@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, GPU call 1: train the grasp decoders (PyTorch-ROCm), then the GPU suite and a bench line on the new audit
+# round 4: train the grasp decoders on the GPU box (PyTorch-ROCm), then the GPU suite and a bench line - how tests/golden/grasp_decoder_*.npz were made
 set -x
 mkdir -p gpurun_out/r4
 python tests/golden/train_grasp_decoders.py grasp3 grasp9 --device cuda --steps 20000 --per-scene 2048 --out gpurun_out/r4 > gpurun_out/r4/train.log 2>&1
