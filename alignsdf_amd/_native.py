@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 122        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 123        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (

@@ -703,6 +703,10 @@ static hipError_t rebuild_one_plane(asdf_decoder* d) {
     o[co.b4 + 2] = o[co.b4 + 3] = o[co.b4 + 4] = 1.0f;                       // (the multipliers of the split-half image: unused here)
     d->s0p[h] = 0.5f * sx0;
     d->s2p[h] = sw2p * sx1;
+    if (d->spec.feature_mode == ASDF_FEATURES_NERF) {
+      // the NeRF encoding's point-feature fragments are static weights (pack_decoder), not a per-sample fold: scaled here
+      for (int i = 0; i < kTilesHidden * d->kp * 64; ++i) { o[co.a0 + i] = c[co.a0 + i] * d->s0p[h]; o[co.a2 + i] = c[co.a2 + i] * d->s2p[h]; }
+    }
     // records of one head: [0, 256) layer 1, [256, 512) layer 2, [512, 1024) layer 3 (unchanged), 512 halves each
     const float f[2] = {sw1p / d->sw[h][0], sw2p / d->sw[h][1]};
     for (int l = 0; l < 2; ++l) {
@@ -741,7 +745,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 122; }
+int asdf_version(void) { return 123; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -837,7 +841,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     up(&d->cst16, hp.cst16);
     if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && d->kp == 2) {
+    if (e == hipSuccess) {
       // records of [plane hi / lo][lane][8 halves] -> the hi halves alone, same record order
       const size_t nrec = hp.stream16.size() / 1024;
       std::vector<uint16_t> hi(nrec * 512);
@@ -851,8 +855,10 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
       if (!d->hi_host || !d->hi_scaled || !d->cst16p1_host) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
       std::memcpy(d->hi_host, hi.data(), hi.size() * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc((void**)&d->cst16p1, hp.cst.size() * sizeof(float));
-      if (e == hipSuccess) e = hipMalloc((void**)&d->a16, (size_t)kHeads * kA16Floats * sizeof(float));
-      if (e == hipSuccess) e = hipMemset(d->a16, 0, (size_t)kHeads * kA16Floats * sizeof(float));
+      if (e == hipSuccess && d->kp == 2) {      // (affine point features: layer 0's bias row and point columns as one fp16 A operand, K0b)
+        e = hipMalloc((void**)&d->a16, (size_t)kHeads * kA16Floats * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(d->a16, 0, (size_t)kHeads * kA16Floats * sizeof(float));
+      }
     }
     for (int h = 0; h < kHeads; ++h) {
       d->s2[h] = h < spec->num_heads ? hp.s2[h] : 1.0f;
@@ -864,6 +870,7 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
     std::memcpy(d->cst_host, hp.cst.data(), hp.cst.size() * sizeof(float));
     if (e == hipSuccess) e = rebuild_one_plane(d);          // the one-plane image at the default activation scales
     if (e == hipSuccess) e = k1h_prepare();
+    if (e == hipSuccess) e = k1s_nerf_prepare();
   }
   if (e == hipSuccess) e = k1_prepare();
   if (e == hipSuccess) e = k1_cls_prepare();
@@ -942,13 +949,13 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
     fp.cst = d->cst16;
     for (int h = 0; h < kHeads; ++h) fp.s2[h] = d->s2[h];
     hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
-    if (d->a16) {
+    if (d->cst16p1) {
       // ... and into the one-plane image (its own scales), whose layer-0 constants then become the kernels' fp16 point-feature /
-      // bias operands
+      // bias operands (affine features; the NeRF-encoded kernels read them from the constants block as they are)
       fp.cst = d->cst16p1;
       for (int h = 0; h < kHeads; ++h) { fp.s2[h] = d->s2p[h]; fp.s0[h] = d->s0p[h]; }
       hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
-      hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16p1, d->a16, d->status);
+      if (d->a16) hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16p1, d->a16, d->status);
     }
   }
   ASDF_HIP(hipGetLastError());
@@ -1126,7 +1133,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
                          float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream) {
   if (!d || !origin || !bbox_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
-  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;        // affine point features only (kp == 2)
+  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;
   const bool two_out = d->spec.num_heads == 1;
   if (two_out ? !(scratch_hand_dev && scratch_obj_dev) : !(scratch_hand_dev || scratch_obj_dev)) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1149,7 +1156,8 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
-  k1h_box_launch(two_out, p, grid, st);
+  if (d->kp == 2) k1h_box_launch(two_out, p, grid, st);
+  else k1s_nerf_launch(d->kp, two_out, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
   // audit: voxels both heads decided by sign alone, drawn at random, through the split-half kernel (the arithmetic of the
@@ -1161,7 +1169,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
     a.mode = kGridSubset; a.grid_mode = p.mode; a.idx = d->audit_idx; a.count_dev = d->audit_count; a.P = kAuditCap;
     a.audit = d->audit_rec; a.audit_from = nullptr;
     const int agrid = kAuditCap / kWgPts < d->num_cus ? kAuditCap / kWgPts : d->num_cus;
-    k1h_subset_launch(two_out, a, agrid, st);
+    k1h_subset_launch(d->kp, two_out, a, agrid, st);
   }
   // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
   const long long items = (N & 3) == 0 ? p.P / 4 : p.P;
@@ -1185,7 +1193,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
     e.stream = d->stream16; e.cst = d->cst16; e.bbox = nullptr; e.neg_thr = 0.0f;
     e.mode = kGridSubset; e.grid_mode = p.mode; e.idx = d->near_idx; e.count_dev = twostep_count; e.P = kCandCap;
     e.audit = nullptr; e.audit_from = nullptr;
-    k1h_subset_launch(two_out, e, rgrid, st);
+    k1h_subset_launch(d->kp, two_out, e, rgrid, st);
     if (d->refine_tau > 0.0f) {
       // ... the fp32 chain where they lie within refine_tau of the level ...
       const float* vols[2] = {p.sdf0, p.sdf1};
@@ -1212,7 +1220,7 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
   if (!d || !origin || !rec_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
-  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;              // affine point features only
+  if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;
   const bool two_out = d->spec.num_heads == 1;       // CombinedDecoder: one MLP, both columns from every evaluation
   if (two_out ? !(sdf_hand_dev && sdf_obj_dev) : (!sdf_hand_dev && !sdf_obj_dev)) return ASDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1245,7 +1253,8 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   const long long ntiles = (P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
-  k1h_box_launch(two_out, p, grid, st);
+  if (d->kp == 2) k1h_box_launch(two_out, p, grid, st);
+  else k1s_nerf_launch(d->kp, two_out, p, grid, st);
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
   float* vols[2] = {sdf_hand_dev, sdf_obj_dev};
@@ -1275,7 +1284,7 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
     q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = list; q.count_dev = d->band_count + h; q.P = kBandCap;
     q.audit = d->audit_n > 0 ? d->audit_rec : nullptr; q.audit_from = d->audit_rec + 4 + h;
     const int rgrid = kBandCap / kWgPts < d->num_cus ? kBandCap / kWgPts : d->num_cus;
-    k1h_subset_launch(two_out, q, rgrid, st);
+    k1h_subset_launch(d->kp, two_out, q, rgrid, st);
   }
   if (d->refine_tau > 0.0f) {
     // ... and, as behind every split-half sweep, the fp32 chain where those values lie within refine_tau of the level (both

@@ -25,7 +25,8 @@ hipError_t k1h_prepare() {
   return e;
 }
 
-void k1h_subset_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+void k1h_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  if (kp != 2) { k1h_nerf_subset_launch(kp, two_out, p, grid, st); return; }
   if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_subset_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
   else hipLaunchKernelGGL(sdf_mlp_f16_subset_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
 }

@@ -1,0 +1,35 @@
+// K1s for the in-kernel NeRF encoding (PointFeatSize 9 / 15, utils/mesh.py:53-55): the ONE-PLANE kernel of the audited box-only /
+// narrow-band sweeps (sdf_mlp_f16_kernel.h, PL = 1) with the point features on the fp32 MFMA (KP = 5 / 8 K-steps, sin / cos generated in
+// the kernel) and one 32-point group per wave - the 40 / 75 KiB constants block of these decoders leaves room for the 16 KiB stages of
+// the one-plane weight stream (4 x 16 KiB ring), not for a second group's registers.  Round 4: until then NeRF-encoded decoders ran
+// ordinary sweeps on both passes.
+#include "k1_launch.h"
+#include "sdf_mlp_f16_kernel.h"
+
+namespace asdf {
+
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_nerf9_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 5, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_nerf15_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 8, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_f16_body<true, 0, 5, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_f16_body<true, 0, 8, 1, 1>(p); }
+
+hipError_t k1s_nerf_prepare() {
+  hipError_t e = hipSuccess;
+  for (const void* k : {(const void*)sdf_mlp_f16p1_nerf9_kernel, (const void*)sdf_mlp_f16p1_nerf15_kernel,
+                        (const void*)sdf_mlp_f16p1_combined_nerf9_kernel, (const void*)sdf_mlp_f16p1_combined_nerf15_kernel})
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_f16(kMaxKP, 1));
+  return e;
+}
+
+void k1s_nerf_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
+  const int lds = lds_bytes_f16(kp, 1);
+  if (kp == 5) {
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_f16p1_combined_nerf9_kernel, dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_f16p1_nerf9_kernel, dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (two_out) hipLaunchKernelGGL(sdf_mlp_f16p1_combined_nerf15_kernel, dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(sdf_mlp_f16p1_nerf15_kernel, dim3(grid), dim3(256), lds, st, p);
+  }
+}
+
+}  // namespace asdf

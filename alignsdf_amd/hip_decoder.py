@@ -232,10 +232,9 @@ class HipSdfDecoder:
         # ASDF_MATH overrides the default
         self.math = "f32"
         want = os.environ.get("ASDF_MATH", DEFAULT_MATH)
-        if want == "f16x3" and self.nerf_features and self.point_feat_size == 15 and not self.combined and "ASDF_MATH" not in os.environ:
-            # the 8-K-step split-half instantiation of PointFeatSize 15 (two MLPs) keeps 400 B per lane in scratch; the fp32 chain
-            # has room for it.  No shipped config uses this shape; ASDF_MATH=f16x3 still selects the split-half kernel.
-            want = "f32"
+        # (PointFeatSize 15 with two MLPs: until round 4 this shape kept the fp32 chain because its 8-K-step split-half instantiation
+        # holds 400 B per lane in scratch.  Measured at N = 256 - profiles/r04_nerf_one_plane.txt - the fp32 chain takes 472 ms per
+        # sample, that split-half kernel 194 ms and the audited one-plane sweeps in front of it 69 ms: the default is the default.)
         if want == "f16x3":
             self.set_math("f16x3")
         elif want not in ("f32", "f16x3"):
@@ -675,7 +674,7 @@ class HipSdfDecoder:
         return self._h is None or bool(self._L.asdf_decoder_one_plane_usable(self._h))
 
     def _box_usable(self):
-        return self.coarse_mode == "box" and self.math == "f16x3" and not self.nerf_features and self._one_plane_ok()
+        return self.coarse_mode == "box" and self.math == "f16x3" and self._one_plane_ok()
 
     def _box_launch(self, N, origin3, voxel_size, grid_mode, hand, obj, tau):
         return self._one_plane_launch(self._L.asdf_decode_grid_box, "asdf_decode_grid_box", N, origin3, voxel_size, grid_mode, hand, obj, tau)
@@ -748,7 +747,7 @@ class HipSdfDecoder:
 
     # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else
     def _band_usable(self):
-        return self.fine_mode == "band" and self.math == "f16x3" and not self.nerf_features and self._one_plane_ok()
+        return self.fine_mode == "band" and self.math == "f16x3" and self._one_plane_ok()
 
     def fine_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True, mc_only=False):
         """Enqueue the fine pass; returns (sdf_hand, sdf_obj, ticket).  The caller hands the ticket to fine_needs_repeat

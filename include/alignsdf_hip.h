@@ -129,7 +129,7 @@ int asdf_decode_grid(asdf_decoder_t* dec, int32_t N, const float origin[3], floa
  * A caller must treat [7] / [15] / [18] / [36] != 0, [32] > 2^21, or [19] or [35] > tau / 2 as "repeat with asdf_decode_grid"
  * (alignsdf_amd/hip_decoder.py: coarse_begin / coarse_finish, which also re-estimate tau from the audit of every sample).
  * scratch_*_dev: N^3 floats per evaluated head (same NULL rules as asdf_decode_grid); contents afterwards: one-plane
- * values, exact ones at the re-evaluated voxels.  Affine point features only (ASDF_EINVAL otherwise). */
+ * values, exact ones at the re-evaluated voxels.  ASDF_EINVAL before a sample is bound or when the one-plane image does not exist (asdf_decoder_one_plane_usable). */
 int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                          float* scratch_hand_dev, float* scratch_obj_dev, int32_t* bbox_dev, void* stream);
 

@@ -116,16 +116,19 @@ def test_an_allowance_that_is_too_small_is_noticed_and_the_sweep_repeated():
 
 def test_box_entry_point_argument_checks(native_lib):
     import ctypes
-    hip, specs = _decoder("nerf9")          # NeRF-encoded features: no one-plane kernel
-    _bind(hip, specs, 0)
+    hip, specs = _decoder("nerf9")          # no sample bound yet: refused (NeRF-encoded decoders have a one-plane kernel since round 4)
     rec = torch.zeros(48, dtype=torch.int32, device="cuda")
     vol = torch.zeros(32 ** 3, dtype=torch.float32, device="cuda")
     org = (ctypes.c_float * 3)(-1.0, -1.0, -1.0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = native_lib
     assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), vol.data_ptr(), vol.data_ptr(), rec.data_ptr(), st) == -1
+    _bind(hip, specs, 0)
+    assert L.asdf_decode_grid_box(hip._h, 32, org, ctypes.c_float(2 / 31), 0, ctypes.c_float(1e-3), vol.data_ptr(), vol.data_ptr(), rec.data_ptr(), st) == 0
     hip.coarse_mode = "box"
-    assert not hip._box_usable()            # ... and the Python layer runs ordinary sweeps for it
+    assert hip._box_usable()
+    hip.set_math("f32")
+    assert not hip._box_usable()            # the fp32 chain keeps ordinary sweeps
     hip.close()
     hip, specs = _decoder("nerf3")
     _bind(hip, specs, 0)
@@ -140,7 +143,7 @@ def test_box_entry_point_argument_checks(native_lib):
 def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
     """ASDF_COARSE=box through the product's entry points (decoder_for -> pipelined_two_pass): cubes, volumes and meshes of
     every sample are those of the ordinary coarse pass - for the ObMan decoder, the MANO-aligned DexYCB decoder (affine point
-    features) and a NeRF-encoded decoder, which has no one-plane kernel and silently keeps ordinary sweeps."""
+    features) and a NeRF-encoded decoder (its own one-plane instantiation since round 4: csrc/k1s_nerf_kernels.hip)."""
     from alignsdf_amd.networks.model import build_decoder
     from alignsdf_amd.reconstruct import pipelined_two_pass, synthetic_code_source
     from alignsdf_amd.utils.utils import decoder_for
@@ -157,10 +160,7 @@ def test_sample_pipeline_with_the_box_coarse_pass(tag, monkeypatch):
         hip = decoder_for(dec, specs, samples[0][2])
         assert hip.coarse_mode == mode
         if mode == "box":
-            if tag != "nerf9":
-                assert hip.box_stats["box"] == len(samples) - 1 and hip.box_stats["fallback"] == 0, hip.box_stats
-            else:
-                assert hip.box_stats["box"] == 0
+            assert hip.box_stats["box"] == len(samples) - 1 and hip.box_stats["fallback"] == 0, hip.box_stats
     for k, a in out["exact"].items():
         b = out["box"][k]
         assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])

@@ -14,7 +14,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def compiled(tmp_path_factory):
     """One device-only compile of every decoder translation unit (side by side): (resource-usage remarks, ISA text)."""
     out_dir = tmp_path_factory.mktemp("isa")
-    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip"]
+    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_nerf_kernels.hip"]
     procs = [(u, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
                                    "--cuda-device-only", u, "-o", str(out_dir / (u + ".s")), "-Rpass-analysis=kernel-resource-usage"],
                                   cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for u in units]
@@ -62,6 +62,13 @@ def test_main_decoder_kernel_has_no_scratch(compiled):
     assert len(k) == 1 and k[0]["scratch"] == 0 and k[0]["occupancy"] == 1, k
     k = [v for name, v in stats.items() if "20sdf_mlp_f16p1_kernelE" in name]
     assert len(k) == 1 and k[0]["scratch"] <= 256 and k[0]["vgpr"] + k[0]["agpr"] <= 512 and k[0]["occupancy"] == 1, k
+    # round 4: the one-plane instantiations of the NeRF-encoded decoders (one point group per wave) - scratch-free except the
+    # CombinedDecoder with 8 K-steps of point features (a few hundred bytes of per-thread constants)
+    for frag in ("26sdf_mlp_f16p1_nerf9_kernelE", "27sdf_mlp_f16p1_nerf15_kernelE", "35sdf_mlp_f16p1_combined_nerf9_kernelE"):
+        k = [v for name, v in stats.items() if frag in name]
+        assert len(k) == 1 and k[0]["scratch"] == 0 and k[0]["vgpr"] + k[0]["agpr"] <= 512 and k[0]["occupancy"] == 1, (frag, k)
+    k = [v for name, v in stats.items() if "36sdf_mlp_f16p1_combined_nerf15_kernelE" in name]
+    assert len(k) == 1 and k[0]["scratch"] <= 256 and k[0]["occupancy"] == 1, k
     # the streaming kernels must not touch scratch either
     for k, v in stats.items():
         if "fold_sample" in k or "neg_bbox" in k:
