@@ -10,9 +10,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libalignsdf_hip.so")
-SOURCES = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_nerf_kernels.hip", "mc33.hip", "icp.hip", "mesh_cc.hip"]
+SOURCES = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip", "mc33.hip", "icp.hip", "mesh_cc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+# MFMA accumulators in VGPRs (the compiler's default heuristic puts them in AGPRs at this register pressure and the epilogues then read
+# every accumulator back through v_accvgpr_read): measured per translation unit, same box, interleaved - the one-plane kernels -4.6 %
+# time (1 862 -> 70 reads per tile body), the fp32 chain -0.4 % and no scratch left in its CombinedDecoder form; the split-half kernels
+# (k1h_kernels.hip) +0.5 % and k1h_nerf_kernels.hip crashes this compiler in that form: both stay on the default.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+TU_FLAGS = {"k1s_kernels.hip": VGPR_FORM, "k1s_nerf_kernels.hip": VGPR_FORM, "k1_kernels.hip": VGPR_FORM, "k1_cls_kernels.hip": VGPR_FORM}
 
 
 def _stale(target, deps):
@@ -26,12 +32,13 @@ def build(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library. Returns its path."""
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "alignsdf_hip.h"))
+    deps.append(os.path.abspath(__file__))          # (the per-unit flags live here)
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, deps):
-            cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+            cmd = [HIPCC, *FLAGS, *TU_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((src, subprocess.Popen(cmd, cwd=CSRC)))      # the translation units compile side by side

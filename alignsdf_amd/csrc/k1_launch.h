@@ -12,6 +12,7 @@ hipError_t k1_prepare();
 hipError_t k1_cls_prepare();
 hipError_t k1h_prepare();            // includes the NeRF-encoded family
 hipError_t k1h_nerf_prepare();
+hipError_t k1s_prepare();           // the one-plane kernels (k1s_kernels.hip)
 hipError_t k1s_nerf_prepare();      // the one-plane kernels of the NeRF-encoded decoders (k1s_nerf_kernels.hip)
 
 // kp = point-feature K-steps (2 affine xyz, 5 / 8 NeRF encoding of 9 / 15 features); two_out = CombinedDecoder
@@ -21,7 +22,7 @@ void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_
 void k1_short_launch(bool two_out, const DecodeParams& p, hipStream_t st);
 void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
-void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel, kp == 2 only; p.stream = high planes
+void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel (k1s_kernels.hip), kp == 2 only; p.stream = high planes
 void k1h_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // split-half kernel over a voxel list
 void k1h_nerf_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // ... kp 5 / 8 (k1h_nerf_kernels.hip)
 void k1h_nerf_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // kp 5 / 8 (k1h_nerf_kernels.hip)

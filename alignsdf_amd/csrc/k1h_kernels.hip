@@ -6,10 +6,6 @@ namespace asdf {
 
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_kernel(const DecodeParams p) { sdf_mlp_f16_body<false>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true>(p); }
-// one fp16 plane per operand, one MFMA per product sum: the box-only coarse sweep (asdf_decode_grid_box)
-// (SeparateDecoder: two point groups per wave - 256 points per workgroup tile, every A fragment feeds two MFMAs)
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 1, 2>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16p1_combined_kernel(const DecodeParams p) { sdf_mlp_f16_body<true, 0, 2, 1>(p); }
 
 // the split-half arithmetic on a voxel list (the exact values of the narrow-band fine sweep)
 __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_subset_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 2, 1, true>(p); }
@@ -20,8 +16,7 @@ hipError_t k1h_prepare() {
   for (const void* k : {(const void*)sdf_mlp_f16_kernel, (const void*)sdf_mlp_f16_combined_kernel, (const void*)sdf_mlp_f16_subset_kernel,
                         (const void*)sdf_mlp_f16_subset_combined_kernel})
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16);
-  for (const void* k : {(const void*)sdf_mlp_f16p1_kernel, (const void*)sdf_mlp_f16p1_combined_kernel})
-    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesF16P1);
+  if (e == hipSuccess) e = k1s_prepare();
   return e;
 }
 
@@ -29,11 +24,6 @@ void k1h_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hi
   if (kp != 2) { k1h_nerf_subset_launch(kp, two_out, p, grid, st); return; }
   if (two_out) hipLaunchKernelGGL(sdf_mlp_f16_subset_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
   else hipLaunchKernelGGL(sdf_mlp_f16_subset_kernel, dim3(grid), dim3(256), kLdsBytesF16, st, p);
-}
-
-void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st) {
-  if (two_out) hipLaunchKernelGGL(sdf_mlp_f16p1_combined_kernel, dim3(grid), dim3(256), kLdsBytesF16P1, st, p);
-  else hipLaunchKernelGGL(sdf_mlp_f16p1_kernel, dim3(grid), dim3(256), kLdsBytesF16P1, st, p);
 }
 
 void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st) {

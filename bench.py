@@ -222,7 +222,7 @@ def golden_counts(tag, N, hand_only=False, golden_dir=os.path.join(ROOT, "tests"
     """[[V, F] hand, [V, F] obj] of synthetic sample 0 as the REFERENCE (decoder + skimage) produced them, from the committed
     fixtures (tests/golden/ref_fullsize*.npz), or None when there is no fixture for this configuration."""
     name = "ref_fullsize_hand64.npz" if hand_only else ("ref_fullsize.npz" if tag == "nerf3" else "ref_fullsize_%s.npz" % tag)
-    if tag.startswith("grasp"):
+    if tag.startswith("grasp") or tag == "nerf9":
         path = os.path.join(golden_dir, "ref_fullsize_r4_%s.npz" % tag)
         if hand_only or not os.path.exists(path):
             return None
@@ -547,7 +547,8 @@ def main():
                                      ("configs[2]: hand+object, N=256", "nerf3", 256, False),
                                      ("configs[4] decoder (DexYCB MANO-aligned, PointFeatSize 9), N=256, one GPU", "both9", 256, False),
                                      ("grasp family (every layer trained, hands closing on objects in contact), ObMan decoder shape, N=256", "grasp3", 256, False),
-                                     ("grasp family, DexYCB MANO-aligned decoder shape (PointFeatSize 9, per-sample poses), N=256", "grasp9", 256, False)):
+                                     ("grasp family, DexYCB MANO-aligned decoder shape (PointFeatSize 9, per-sample poses), N=256", "grasp9", 256, False),
+                                     ("NeRF-encoded decoder (PointFeatSize 9, utils/mesh.py:53-55: its own one-plane kernel), N=256", "nerf9", 256, False)):
                 if (tag, n, ho) == (args.tag, N, hand_only):
                     continue
                 if tag in syn.GRASP_TAGS and not os.path.exists(os.path.join(ROOT, "tests", "golden", "grasp_decoder_%s.npz" % tag)):
@@ -652,7 +653,8 @@ def main():
                             "decoder (PointFeatSize %d, EncodeStyle %s); coarse pass: %s, fine pass: %s" % (
                                 "hand-only" if hand_only else "hand+object dual", N,
                                 {"nerf3": "ObMan", "both9": "DexYCB MANO-aligned", "grasp3": "ObMan-shaped, trained on the synthetic grasp family",
-                                 "grasp9": "DexYCB-shaped (MANO-aligned), trained on the synthetic grasp family"}[args.tag],
+                                 "grasp9": "DexYCB-shaped (MANO-aligned), trained on the synthetic grasp family",
+                                 "nerf9": "NeRF-encoded (utils/mesh.py:53-55)"}[args.tag],
                                 specs["PointFeatSize"], specs["EncodeStyle"],
                                 "audited box-only one-plane sweep + exact re-evaluation of the voxels that can move the boxes" if main_coarse == "box" else "ordinary sweep",
                                 "audited narrow-band sweep (one-plane signs, ordinary values at every corner of every cell that can be active)" if main_fine == "band" else "ordinary sweep"),

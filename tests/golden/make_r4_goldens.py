@@ -32,7 +32,9 @@ TMP = "/tmp/asdf_r4_%s_%d_s%d_%s.npy"
 PLAN = ((128, (0, 1, 2, 3, 5)), (256, (0, 1, 3, 5)))
 # "comb3": the CombinedDecoder (networks/model.py:79-188, ModelType 1encoder1decoder) of the sphere + box family at N = 128, samples
 # 1 and 2 - the pin of its narrow-band fine sweep (round 4: one list of the cells that can be active in either column)
-PLANS = {"comb3": ((128, (1, 2)),)}
+# "nerf9" / "nerf15": NeRF-ENCODED decoders (utils/mesh.py:53-55, PointFeatSize 9 / 15; sphere + box family) - the pin of their one-plane
+# instantiations (csrc/k1s_nerf_kernels.hip, round 4)
+PLANS = {"comb3": ((128, (1, 2)),), "nerf9": ((128, (0, 1, 2)), (256, (0, 1))), "nerf15": ((128, (0, 1)),)}
 
 
 def out_path(tag):

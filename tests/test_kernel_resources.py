@@ -14,8 +14,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def compiled(tmp_path_factory):
     """One device-only compile of every decoder translation unit (side by side): (resource-usage remarks, ISA text)."""
     out_dir = tmp_path_factory.mktemp("isa")
-    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_nerf_kernels.hip"]
-    procs = [(u, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+    from alignsdf_amd.build_native import TU_FLAGS          # (the per-unit flags of the shipped build: MFMA accumulators in VGPRs for some)
+    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip"]
+    procs = [(u, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *TU_FLAGS.get(u, []), "-S",
                                    "--cuda-device-only", u, "-o", str(out_dir / (u + ".s")), "-Rpass-analysis=kernel-resource-usage"],
                                   cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for u in units]
     remarks, isa = "", ""
@@ -99,3 +100,6 @@ def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
     scratch = [i for i, l in enumerate(body) if "scratch_" in l and not l.strip().startswith(";")]
     # (2048 of the three 512-wide layers + 32 of layer 0, whose point features are an fp16 operand since round 3)
     assert len(mfma) == 2048 + 32 and len([i for i in scratch if mfma[0] < i < mfma[-1]]) <= 8
+    # round 4: built with MFMA accumulators in VGPRs (build_native.TU_FLAGS) the epilogues read them in place - the default form read
+    # every accumulator back out of the AGPRs (1 862 v_accvgpr_read per tile body, 4.6 % of the kernel's time)
+    assert len([l for l in body if "v_accvgpr_read" in l]) <= 200 and not scratch
