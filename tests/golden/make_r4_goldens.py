@@ -8,6 +8,9 @@ script runs the reference's create_mesh_combined_decoder (utils/mesh.py:17-195) 
     grasp3 (ObMan decoder shape, raw xyz)                  N = 128: scenes 0 1 2 3 5,   N = 256: scenes 0 1 3 5
     grasp9 (DexYCB MANO-aligned, per-scene poses)          N = 128: scenes 0 1 2 3 5,   N = 256: scenes 0 1 3 5
 
+    nerf9 / nerf15 (NeRF-ENCODED decoders, utils/mesh.py:53-55; sphere + box family)   nerf9 N = 128: samples 0 1 2, N = 256: 0 1;  nerf15 N = 128: 0 1
+    comb3 (CombinedDecoder)                                 N = 128: samples 1 2
+
 (scenes 1 and 5 carry a detached blob in the hand volume, scene 3 a detached piece of the object: several components) and records,
 per (tag, N, scene), what make_r3_goldens.py records - boxes, zoom cube, 8192 probes per head and pass, and from skimage 0.18.3
 (/opt/conda/bin/python3.9, the reference's own call, utils/mesh.py:354) V / F and checksums, then the packed SIGN of every voxel of
