@@ -121,10 +121,39 @@ __device__ __forceinline__ void lds_dma16_off(const float* gsrc, unsigned lds_ds
 
 // Reference grid coordinates, bit-for-bit (utils/mesh.py:32-40): fp32 true division, fp32 fmod,
 // then separately rounded multiply and add (no FMA contraction).
+// fmodf(a, b) for a >= 0 and an integer-valued b >= 1 with a / b < 2^20, bit for bit: the remainder a - b trunc(a / b) is exactly
+// representable, so one FMA produces it without rounding once trunc(a / b) is known, and a quotient estimate that is off by one
+// (a rb carries ~2 ulp) leaves a remainder in [-b, 2 b) that one exact +-b repairs.  (The library fmodf is a shift-and-subtract loop:
+// two of them, a 64-bit modulo and a 64-bit conversion per point were ~4 % of the one-plane kernel's cycles.)
+__device__ __forceinline__ float fmod_small(float a, float b, float rb) {
+  const float k = truncf(a * rb);
+  float r = fmaf(-k, b, a);
+  if (r < 0.0f) r += b;
+  else if (r >= b) r -= b;
+  return r;
+}
+
 __device__ __forceinline__ void grid_point(long long i, int N, int mode, float vs, float o0, float o1, float o2,
                                            float& c0, float& c1, float& c2) {
   float i0, i1, i2;
-  if (mode == kGridReference) {
+  if (N <= 1290) {
+    // every lattice the C ABI accepts (N <= 1024): N^3 < 2^31, the index arithmetic fits 32 bits
+    const unsigned u = (unsigned)i, n = (unsigned)N;
+    if (mode == kGridReference) {
+      const float Nf = (float)N, rN = __frcp_rn(Nf);
+      const float fi = (float)(int)u;                 // int64 -> fp32 (RNE), as torch does (the same value: u < 2^31)
+      const float q1 = __fdiv_rn(fi, Nf);             // overall_index / N
+      i2 = (float)(u % n);
+      i1 = fmod_small(q1, Nf, rN);
+      i0 = fmod_small(__fdiv_rn(q1, Nf), Nf, rN);
+    } else {
+      const unsigned q = u / n;
+      i2 = (float)(u - q * n);
+      const unsigned q2 = q / n;
+      i1 = (float)(q - q2 * n);
+      i0 = (float)q2;
+    }
+  } else if (mode == kGridReference) {
     const float Nf = (float)N;
     const float fi = (float)i;                      // int64 -> fp32 (RNE), as torch does
     const float q1 = __fdiv_rn(fi, Nf);             // overall_index / N
@@ -139,6 +168,13 @@ __device__ __forceinline__ void grid_point(long long i, int N, int mode, float v
   c0 = __fadd_rn(__fmul_rn(i0, vs), o0);
   c1 = __fadd_rn(__fmul_rn(i1, vs), o1);
   c2 = __fadd_rn(__fmul_rn(i2, vs), o2);
+}
+
+// lattice index -> (i0, i1, i2) in 32-bit arithmetic (N <= 1024: every index is below 2^30)
+__device__ __forceinline__ void lattice_ijk(long long i, int N, int& i0, int& i1, int& i2) {
+  const unsigned u = (unsigned)i, n = (unsigned)N;
+  const unsigned q = u / n, q2 = q / n;
+  i2 = (int)(u - q * n); i1 = (int)(q - q2 * n); i0 = (int)q2;
 }
 
 #define ASDF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)

@@ -490,6 +490,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         }
         return r;
       };
+      ASDF16_MARK(7);      // (coordinates done)
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       h8 bq0, bq0b;
       if (kPt16) {
@@ -890,7 +891,6 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // a lane is out of range when a value handed to the fp16 conversion reached 65504 (|x| >= 8188) or an output left
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
-      amax = amax; amax1 = amax1; amax2 = amax2;
       // (one-plane kernels, folded image: no running maximum - every ReLU preserves a poisoned value, so an activation that left the
       // fp16 range arrives HERE as a NaN or as exactly +-1: no decoder of a clamped SDF gets there honestly)
       constexpr bool kStrict = PL == 1 && ASDF16_P1_FOLD;
@@ -906,11 +906,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       if (!SUB && p.bbox && p.mode != kPointList) {
         // with two point groups every lane folds ITS point: lanes 0..31 the first group's, lanes 32..63 the second's
         const long long pf_ = (G == 2 && half == 1) ? pib : pi;
-        const int i2 = (int)(pf_ % p.N), i1 = (int)((pf_ / p.N) % p.N), i0 = (int)((pf_ / p.N) / p.N);
         auto fold = [&](bool neg, int* rec, int extra) {
 #if ASDF16_FOLD_BALLOT
           if (PL == 1 && !__any(neg || extra != 0)) return;      // (wave-uniform: most tiles of a sweep hold no negative voxel)
 #endif
+          int i0, i1, i2;                                        // (behind the early return: two integer divisions per lane)
+          lattice_ijk(pf_, p.N, i0, i1, i2);
           int a0 = neg ? i0 : 0x7fffffff, a1 = neg ? i1 : 0x7fffffff, a2 = neg ? i2 : 0x7fffffff;
           int b0 = neg ? i0 : -1, b1 = neg ? i1 : -1, b2 = neg ? i2 : -1, n = neg ? 1 : 0;
 #pragma unroll
@@ -936,7 +937,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       ASDF16_MARK(5);
 #ifdef ASDF16_SEGMENT_TIMES
       if (blockIdx.x == 0 && wave == 0 && lane == 0 && slot == 0 && tile == (long long)blockIdx.x + 2 * gridDim.x)
-        for (int k = 0; k < 6; ++k) g_seg[k] = (unsigned long long)seg_t[k];
+        { for (int k = 0; k < 6; ++k) g_seg[k] = (unsigned long long)seg_t[k]; g_seg[7] = (unsigned long long)seg_t[7]; }
       if (blockIdx.x == 0 && wave == 0 && lane == 0 && slot == 0 && tile == (long long)blockIdx.x + 3 * gridDim.x) g_seg[6] = (unsigned long long)seg_t[0];
 #endif
     }   // tiles

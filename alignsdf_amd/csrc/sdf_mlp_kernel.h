@@ -318,7 +318,8 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
             if (p.status) atomicMax(p.status + 3, __float_as_int(fabsf(now - before)));
             if (was == is) return;
             if (is) {
-              const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
+              int i0, i1, i2;
+              lattice_ijk(po, p.N, i0, i1, i2);
               atomicMin(rec + 0, i0); atomicMin(rec + 1, i1); atomicMin(rec + 2, i2);
               atomicMax(rec + 3, i0); atomicMax(rec + 4, i1); atomicMax(rec + 5, i2);
               atomicAdd(rec + 6, 1);
@@ -352,7 +353,8 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
         }
       }
       if (p.bbox && valid && half == 0 && p.mode != kPointList && p.mode != kGridSubset) {
-        const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
+        int i0, i1, i2;
+        lattice_ijk(po, p.N, i0, i1, i2);
         if (sdf < 0.0f) {
           bmin0 = min(bmin0, i0); bmin1 = min(bmin1, i1); bmin2 = min(bmin2, i2);
           bmax0 = max(bmax0, i0); bmax1 = max(bmax1, i1); bmax2 = max(bmax2, i2); ++bcnt;

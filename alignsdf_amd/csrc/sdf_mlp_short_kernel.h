@@ -169,7 +169,8 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p) {
         if (p.status) atomicMax(p.status + 3, __float_as_int(fabsf(now - before)));
         if (was == is) return;
         if (is) {
-          const int i2 = (int)(po % p.N), i1 = (int)((po / p.N) % p.N), i0 = (int)((po / p.N) / p.N);
+          int i0, i1, i2;
+              lattice_ijk(po, p.N, i0, i1, i2);
           atomicMin(rec + 0, i0); atomicMin(rec + 1, i1); atomicMin(rec + 2, i2);
           atomicMax(rec + 3, i0); atomicMax(rec + 4, i1); atomicMax(rec + 5, i2);
           atomicAdd(rec + 6, 1);

@@ -60,6 +60,23 @@ def grid_coords(N, voxel_size, origin3, integer_mode=False):
     return out
 
 
+def grid_coords_window(N, voxel_size, origin3, first, count, integer_mode=False):
+    """Rows [first, first + count) of grid_coords(N, ...) without building the N^3 lattice (N = 512 / 1024): the same operations on
+    the same index values (utils/mesh.py:27-40)."""
+    overall = torch.arange(first, first + count, 1, dtype=torch.int64)
+    if integer_mode:
+        cols = torch.stack([(overall // N) // N, (overall // N) % N, overall % N], 1).float()
+    else:
+        cols = torch.zeros(count, 3)
+        cols[:, 2] = overall % N
+        cols[:, 1] = (overall / N) % N
+        cols[:, 0] = ((overall / N) / N) % N
+    out = torch.zeros(count, 3)
+    for a in range(3):
+        out[:, a] = (cols[:, a] * voxel_size) + origin3[a]
+    return out
+
+
 def kinematic_embedding(xyz, mano_results, point_feat_size, scale_factor, obj_results, encode_style):
     """Pose-aligned point features, following utils/utils.py:376-430 step by step (batch of one sample).
     xyz [M,3] normalised -> [M, point_feat_size]."""

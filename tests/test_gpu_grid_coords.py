@@ -57,6 +57,23 @@ def test_integer_mode_and_windows(N):
     assert np.array_equal(win, got[first:first + count])
 
 
+@pytest.mark.parametrize("N", [17, 255, 257, 511, 512, 777, 1023, 1024])
+def test_windows_of_large_and_odd_lattices_bit_for_bit(N):
+    """grid_point's 32-bit index arithmetic and its one-FMA fmod (csrc/sdf_mlp_common.h: fmod_small) against the reference's operations
+    on windows of lattices up to the largest the C ABI accepts: the start, the end, around 2^24 (where int64 -> fp32 starts to round)
+    and pseudo-random places, in both lattice modes."""
+    from oracle import sdf_oracle as orc
+    P = N ** 3
+    rng = np.random.RandomState(N)
+    firsts = [0, max(0, P - 70000), max(0, min(P - 70000, (1 << 24) - 35000))] + [int(f) for f in rng.randint(0, max(1, P - 70000), 5)]
+    for first in firsts:
+        count = min(70000, P - first)
+        for mode, integer in ((_native.GRID_REFERENCE, False), (_native.GRID_INTEGER, True)):
+            got = device_coords(N, [-1.0, -0.37, 0.21], 2.0 / (N - 1), mode, first, count)
+            want = orc.grid_coords_window(N, 2.0 / (N - 1), [-1.0, -0.37, 0.21], first, count, integer_mode=integer).numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, first, mode)
+
+
 def test_argument_checks(native_lib):
     org = (ctypes.c_float * 3)(0, 0, 0)
     buf = torch.empty(30, device="cuda")

@@ -45,6 +45,7 @@ static void seg_report() {
     printf("    %-40s %8.0f cycles   MFMA time of its instructions %8.0f   (%5.1f %%)\n", name[k], c, ideal[k], ideal[k] > 0 ? 100.0 * ideal[k] / c : 0.0);
     tot += c; toti += ideal[k];
   }
+  printf("    (of the first segment: %.0f cycles until the coordinates are done)\n", (double)(g[7] - g[0]));
   printf("    %-40s %8.0f cycles   %8.0f   (%5.1f %%);  tile period (start to start of the next) %.0f cycles\n", "one tile of one MLP", tot, toti, 100.0 * toti / tot,
          (double)(g[6] - g[0]) / 1.0);
 }
