@@ -359,7 +359,7 @@ template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1, bool SUB
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using CL = CstLayout<KP>;
   using SG = S16<PL, G>;
-  static_assert(G == 1 || (!TWO_OUT && KP == 2), "two point groups: SeparateDecoder with affine features");
+  static_assert(G == 1 || !TWO_OUT, "two point groups: SeparateDecoder");
   constexpr int kTilePts = kWgPts * G;           // points per workgroup tile
   static_assert(lds_bytes_f16(KP, PL) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -452,7 +452,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // second point group (G == 2): the next 32 points
       const long long pib = pi + kWavePts;
       const bool validb = G == 2 && pib < npts;
-      float bpb[2] = {0.0f, 0.0f};
+      float bpb[KP];
+#pragma unroll
+      for (int s = 0; s < KP; ++s) bpb[s] = 0.0f;
       float y0 = 0.f, y1 = 0.f, y2 = 0.f;
       if (G == 2) {
         if (p.mode == kPointList) {
@@ -460,8 +462,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         } else {
           grid_point(validb ? pib : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, y0, y1, y2);
         }
-        bpb[0] = half ? y1 : y0;
-        bpb[1] = half ? 0.0f : y2;
+        if (KP == 2) {
+          bpb[0] = half ? y1 : y0;
+          bpb[1] = half ? 0.0f : y2;
+        } else {
+#pragma unroll
+          for (int s = 0; s < KP; ++s) bpb[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, y0, y1, y2) : 0.0f;
+        }
       }
       // largest plane value (x S_x) this lane hands to the fp16 conversion, per activation vector h0 / h1 / h2: >= 65504
       // is an overflow (range report); the maxima themselves go to the decoder's status record, from which the host
@@ -555,7 +562,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane];
           if (g != 1) acc = ASDF_MFMA(af, bp[s], acc);
-          if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
+          if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s], accb);
         }
         split_tile<PL, G>(acc, accb, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax, g);
       };
@@ -588,7 +595,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
           for (int s = 0; s < KP; ++s) {
             la[t % 3] = ASDF_MFMA(lf[t % 3][s], bp[s], la[t % 3]);
-            if (G == 2) lb[t % 3] = ASDF_MFMA(lf[t % 3][s], bpb[s < 2 ? s : 0], lb[t % 3]);
+            if (G == 2) lb[t % 3] = ASDF_MFMA(lf[t % 3][s], bpb[s], lb[t % 3]);
           }
         };
         l0p_load(0);
@@ -685,7 +692,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
           acc = ASDF_MFMA(af, bp[s], acc);
-          if (G == 2) accb = ASDF_MFMA(af, bpb[s < 2 ? s : 0], accb);
+          if (G == 2) accb = ASDF_MFMA(af, bpb[s], accb);
         }
         auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;

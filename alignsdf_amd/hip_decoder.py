@@ -233,8 +233,8 @@ class HipSdfDecoder:
         self.math = "f32"
         want = os.environ.get("ASDF_MATH", DEFAULT_MATH)
         # (PointFeatSize 15 with two MLPs: until round 4 this shape kept the fp32 chain because its 8-K-step split-half instantiation
-        # holds 400 B per lane in scratch.  Measured at N = 256 - profiles/r04_nerf_one_plane.txt - the fp32 chain takes 472 ms per
-        # sample, that split-half kernel 194 ms and the audited one-plane sweeps in front of it 69 ms: the default is the default.)
+        # holds 400 B per lane in scratch.  Measured at N = 256 - profiles/r04_nerf_one_plane.txt - the fp32 chain takes 464 ms per
+        # sample, that split-half kernel 194 ms and the audited one-plane sweeps in front of it 63 ms: the default is the default.)
         if want == "f16x3":
             self.set_math("f16x3")
         elif want not in ("f32", "f16x3"):
