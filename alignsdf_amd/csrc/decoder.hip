@@ -610,11 +610,11 @@ struct asdf_decoder {
   float* embed;     // [heads][MAXPF][4]
   float* cls;       // [kMaxClasses][512 in D-layout order] + [kMaxClasses]; null until asdf_decoder_set_classifier
   int num_class;
-  // split-half image (pack_decoder_f16; kp == 2 only, null otherwise) and the arithmetic in use
+  // split-half image (pack_decoder_f16) and the arithmetic in use
   float* stream16;
   float* stream16_hi;   // the high planes alone (1 KiB records): weight stream of the one-plane kernel (asdf_decode_grid_box)
   float* cst16;
-  float* a16;       // [heads][kA16Floats] fp16 point-feature / bias operands of the one-plane kernels (K0b, per sample)
+  float* a16;       // [heads][kA16Floats] fp16 point-feature / bias operands of the one-plane kernels (K0b, per sample; affine features only)
   // The one-plane kernels' OWN image (round 4): weight scales chosen so that every accumulator already carries its activation's
   // plane scale - S_w1' = S_x1 / S_x0, S_w2' = S_x2 / S_x1, layer 0's constants times S_x0 - and the epilogue needs no rescale
   // (a v_pk_mul_f32 per register pair: with the range maximum, a third of the kernel's VALU issue).  cst16p1 = its constants

@@ -17,7 +17,7 @@ struct HostPack {
   std::vector<float> cst;      // [heads][cst_offsets(kp).floats]  static parts filled, per-sample parts zero
   int kp;                      // point-feature K-steps of layers 0 / 2
   std::vector<float> emb;      // [heads][ASDF_MAX_POINT_FEATS][4]  identity-on-xyz default
-  // split-half image (ASDF_MATH_F16X3, kp == 2 only; see sdf_mlp_f16_kernel.h)
+  // split-half image (ASDF_MATH_F16X3; see sdf_mlp_f16_kernel.h)
   std::vector<uint16_t> stream16;   // [kStagesAll][kStageFloats * 2] fp16 bits: stage = [kblock 8][plane 2][lane 64][8]
   std::vector<float> cst16;         // the constants block with the scaled entries of the split-half kernel
   float s2[kHeads];                 // scale of the layer-2 accumulator (K0 applies it to c2 / A2)
