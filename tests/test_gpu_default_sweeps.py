@@ -40,10 +40,11 @@ def _meshes(tag, N, samples, monkeypatch, coarse=None, fine=None, math=None):
     return out, hip
 
 
-@pytest.mark.parametrize("tag", ["nerf3", "both9", "grasp3", "grasp9"])
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "grasp3", "grasp9", "nerf9", "nerf15"])
 def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, monkeypatch):
     """N = 256 (BASELINE configs[2] / configs[4]'s decoder), all 64 synthetic samples - and all 16 scenes of the GRASP family
-    (decoders with every layer trained, hands closing on objects in contact): torch.equal on vertices and faces."""
+    (decoders with every layer trained, hands closing on objects in contact), and the NeRF-encoded decoders (their own one-plane
+    kernels, round 4): torch.equal on vertices and faces."""
     N = 256
     samples = list(range(syn.GRASP_SAMPLES if tag in syn.GRASP_TAGS else 64))
     want, _ = _meshes(tag, N, samples, monkeypatch, coarse="exact", fine="exact")
