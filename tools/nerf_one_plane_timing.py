@@ -1,4 +1,4 @@
-"""NeRF-encoded decoders (PointFeatSize 9 / 15, EncodeStyle "nerf") through the sample pipeline at N = 256: ms per sample under the
+"""NeRF-encoded decoders (PointFeatSize 9 / 15, EncodeStyle "nerf"; or the tags named on the command line, e.g. comb3) through the sample pipeline at N = 256: ms per sample under the
 product's default (audited one-plane) sweeps against ordinary sweeps, and whether every mesh is the same vertex for vertex.
     gpurun -- 'python tools/nerf_one_plane_timing.py > gpurun_out/r4/nerf_one_plane.txt'
 """
@@ -41,7 +41,7 @@ def run(tag, mode, math="f16x3"):
     return ms, meshes, dict(box=dict(hip.box_stats), band=dict(hip.band_stats)), hip.math
 
 
-for tag in ("nerf9", "nerf15"):
+for tag in ([a for a in sys.argv[1:] if not a.startswith("-")] or ["nerf9", "nerf15"]):
     ms_e, m_e, _, math = run(tag, "exact")
     ms_d, m_d, st, _ = run(tag, "default")
     same = sum(int(torch.equal(m_e[k][p][0], m_d[k][p][0]) and torch.equal(m_e[k][p][1], m_d[k][p][1])) for k in m_e for p in m_e[k])
