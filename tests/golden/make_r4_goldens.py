@@ -5,8 +5,8 @@ tests/golden/train_grasp_decoders.py) at BASELINE.json's full sizes, produced by
 VERDICT r03 missing #3: everything the default (audited one-plane) sweeps had been held against was the sphere + box family.  This
 script runs the reference's create_mesh_combined_decoder (utils/mesh.py:17-195) on
 
-    grasp3 (ObMan decoder shape, raw xyz)                  N = 128: scenes 0 1 2 3 5,   N = 256: scenes 0 1 3 5
-    grasp9 (DexYCB MANO-aligned, per-scene poses)          N = 128: scenes 0 1 2 3 5,   N = 256: scenes 0 1 3 5
+    grasp3 (ObMan decoder shape, raw xyz)                  N = 128 and N = 256: scenes 0 .. 7
+    grasp9 (DexYCB MANO-aligned, per-scene poses)          N = 128 and N = 256: scenes 0 .. 7
 
     nerf9 / nerf15 (NeRF-ENCODED decoders, utils/mesh.py:53-55; sphere + box family)   nerf9 N = 128: samples 0 1 2, N = 256: 0 1;  nerf15 N = 128: 0 1
     comb3 (CombinedDecoder)                                 N = 128: samples 1 2
@@ -32,7 +32,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 TMP = "/tmp/asdf_r4_%s_%d_s%d_%s.npy"
-PLAN = ((128, (0, 1, 2, 3, 5)), (256, (0, 1, 3, 5)))
+PLAN = ((128, (0, 1, 2, 3, 4, 5, 6, 7)), (256, (0, 1, 2, 3, 4, 5, 6, 7)))
 # "comb3": the CombinedDecoder (networks/model.py:79-188, ModelType 1encoder1decoder) of the sphere + box family at N = 128, samples
 # 1 and 2 - the pin of its narrow-band fine sweep (round 4: one list of the cells that can be active in either column)
 # "nerf9" / "nerf15": NeRF-ENCODED decoders (utils/mesh.py:53-55, PointFeatSize 9 / 15; sphere + box family) - the pin of their one-plane
