@@ -352,3 +352,60 @@ def test_grasp_family_at_other_sizes_and_single_branches(tag, N, monkeypatch):
     assert hip.band_stats["band"] >= 20, hip.band_stats
     print(tag, N, "box", {k: hip.box_stats[k] for k in ("box", "exact", "fallback", "max_candidates")},
           "band", {k: hip.band_stats[k] for k in ("band", "exact", "fallback", "max_marked", "tau_max")}, "tail", c["tail_ratio"])
+
+
+def test_grasp_decoder_on_latent_codes_it_was_not_trained_on(monkeypatch):
+    """The certificate of the default sweeps was calibrated on the 16 trained codes; a deployed decoder sees codes an ENCODER produces.
+    Stand-ins: midpoints of trained codes, extrapolations beyond them (1.6 a - 0.6 b) and trained codes with noise of the codes' own
+    scale - shapes the decoder never fitted (merged, thinned, partly dissolved surfaces).  N = 128, ObMan-shaped trained decoder: whatever
+    the ordinary sweeps deliver (a mesh, or marching cubes' refusal of a volume without a surface), the default sweeps deliver the same,
+    vertex for vertex; a sweep may be REFUSED and repeated as an ordinary one (counted, reported) but never deliver anything else."""
+    from alignsdf_amd.marching_cubes import marching_cubes_device
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    from alignsdf_amd.utils.utils import decoder_for
+    for k in ("ASDF_COARSE", "ASDF_FINE", "ASDF_MATH"):
+        monkeypatch.delenv(k, raising=False)
+    tag, N = "grasp3", 128
+    codes = np.concatenate([syn.sample_inputs(tag, s)[0] for s in range(syn.GRASP_SAMPLES)], 0)
+    scale = float(codes.std())
+    latents = []
+    for i in range(8):
+        a, b = codes[i], codes[(5 * i + 3) % syn.GRASP_SAMPLES]
+        latents += [0.5 * (a + b), 1.6 * a - 0.6 * b,
+                    a + scale * syn.uniform((codes.shape[1],), 4100 + i, -1.0, 1.0).astype(np.float32)]
+    latents = [torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(1, -1)).cuda() for v in latents]
+
+    def run(exact):
+        dec, specs = _module(tag)
+        hip = decoder_for(dec, specs, None)
+        if exact:
+            hip.coarse_mode = hip.fine_mode = "exact"
+        out = []
+        for lat in latents:
+            r = decode_two_pass(True, True, dec, lat, None, None, specs, N, mc_only=True)
+            meshes = []
+            for part in ("hand", "obj"):
+                try:
+                    meshes.append(marching_cubes_device(r["vol_" + part], 0.0))
+                except (ValueError, RuntimeError) as e:
+                    meshes.append(str(e))
+            out.append((r["origin"], float(r["voxel_size"]), meshes))
+        return out, hip
+
+    want, _ = run(True)
+    got, hip = run(False)
+    surfaces = 0
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert a[0] == b[0] and a[1] == b[1], (i, "zoom cube")
+        for ma, mb in zip(a[2], b[2]):
+            if isinstance(ma, str):
+                assert ma == mb, (i, ma, mb)
+            else:
+                surfaces += 1
+                assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1], mb[1]), i
+    assert surfaces >= len(latents)                       # (most of these codes still decode to two surfaces)
+    assert hip.box_stats["audit_flips"] == 0 and hip.band_stats["audit_flips"] == 0
+    print("unseen codes: %d, surfaces %d, one-plane coarse sweeps %d (refused %d), fine %d (refused %d), certificate %s" % (
+        len(latents), surfaces, hip.box_stats["box"], hip.box_stats["fallback"], hip.band_stats["band"], hip.band_stats["fallback"],
+        hip.certificate()))
+    hip.close()
