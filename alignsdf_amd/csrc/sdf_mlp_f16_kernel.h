@@ -137,6 +137,15 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #ifndef ASDF16_FOLD_BALLOT
 #define ASDF16_FOLD_BALLOT 1     // the negative-voxel fold of a tile is skipped when no lane of the wave has anything to fold
 #endif
+#ifndef ASDF16_MIX_SPLIT
+#define ASDF16_MIX_SPLIT 1       // split-half kernel: the plane split on v_fma_mix{lo,hi}_f16 (9 instead of 17 VALU instructions per epilogue part)
+#endif
+#ifndef ASDF16_EPI_STEPS
+#define ASDF16_EPI_STEPS 1       // split-half kernel: a deferred epilogue part is issued in three pieces, one behind each MFMA of its K-block
+#endif
+#ifndef ASDF16_DMA_PER_KB
+#define ASDF16_DMA_PER_KB 1      // split-half kernel: ONE LDS-DMA piece per K-block (behind its last MFMA) over K-blocks BARRIER_KB .. + 7, not three per K-block
+#endif
 #ifndef ASDF16_FAST_TANH
 #define ASDF16_FAST_TANH 1       // tanh as 1 - 2 / (1 + exp(2 x)) on the hardware exp / rcp (absolute error ~1e-7; the values carry ~1e-4)
 #endif
@@ -185,9 +194,9 @@ static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
 // relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
 // amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
 // (g: -1 = everything, 0 / 1 = only the first / second point group's part - the two-group kernel issues them behind different MFMAs)
-template <int PL = 2, int G = 1>
+template <int PL = 2, int G = 1, bool MIX = false>
 __device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
-                                           int e, int g = -1) {
+                                           int e, int g = -1, int step = -1, float* rr = nullptr) {
   if (PL == 1 && G == 2 && g != 0)         // the second point group: its planes live where the low planes of the split-half kernel do
     relu_mul_pack(accb[2 * e], accb[2 * e + 1], mul, e < 4 ? lo0 : lo1, e & 3, amax);
   if (PL == 1 && G == 2 && g == 1) return;
@@ -196,6 +205,67 @@ __device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb
     // one v_cvt_pk), about 5 VALU instructions - a part has to fit the shadow of the ONE MFMA of its K-block here
     relu_mul_pack(acc[2 * e], acc[2 * e + 1], mul, e < 4 ? hi0 : hi1, e & 3, amax);
     return;
+  }
+  if (MIX) {
+  // Round 5: the split on the mixed-precision FMA.  v_fma_mix{lo,hi}_f16 computes an fp32 FMA whose sources are fp32 registers or
+  // fp16 halves, rounds ONCE to fp16 and writes one half of the destination (the other half is preserved), so per element
+  //     hi = f16(r mul)                 lo = f16(r mul - hi)        (r mul is exact: mul is a power of two; r mul - hi is exact in fp32)
+  // are two instructions with no conversion back, no subtraction and no packing - the bits of the form below, which took
+  // v_mul + v_fma_mixlo + v_cvt_f32_f16 + v_sub + 2 x 1/2 v_cvt_pk per element (17 VALU instructions per epilogue part, where the
+  // part's K-block has room for ~12 next to its MFMAs, LDS reads and LDS-DMA piece).  The running maximum is taken on r and scaled
+  // by mul once per tile (max and a positive power of two commute).
+  // `step` (-1 = the whole part) issues the part in three pieces, one behind each MFMA of the part's K-block - [0] the two ReLUs (the
+  // accumulator reads), [1] the high planes and the running maximum, [2] the low planes; rr[2] carries the ReLUs across.  A K-block is
+  // three DEPENDENT MFMAs on one accumulator: an MFMA that finds more than ~5 issue slots between itself and its predecessor misses
+  // the back-to-back window and pays ~43 clocks on top of the slots (MI355X_MICROARCH.md, "one EXTRA issue slot between two MFMAs on
+  // the SAME accumulator"), which is why the instruction count of a part hardly matters while the part sits in ONE gap.
+  {
+    float r0 = rr ? rr[0] : 0.0f, r1 = rr ? rr[1] : 0.0f;
+    if (step <= 0) {
+      r0 = __int_as_float(max(__float_as_int(acc[e]), 0));
+      r1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0));
+      if (rr) { rr[0] = r0; rr[1] = r1; }
+      if (step == 0) return;
+    }
+    u32x4 H0 = __builtin_bit_cast(u32x4, hi0), L0 = __builtin_bit_cast(u32x4, lo0);
+    u32x4 H1 = __builtin_bit_cast(u32x4, hi1), L1 = __builtin_bit_cast(u32x4, lo1);
+    unsigned a = H0[e >> 1], b = L0[e >> 1], c = H1[e >> 1], d = L1[e >> 1];
+    // the two high planes, the running maximum behind them, then the low planes (a half-register write needs two wait states in
+    // front of its first read: the maximum and the sibling's instruction are those two)
+#ifndef ASDF16_NO_RANGE_CHECK
+#define ASDF16_AMAX_LINE "v_max3_f32 %2, %2, %3, %4\n\t"
+#else
+#define ASDF16_AMAX_LINE "s_nop 0\n\t"
+#endif
+    if (step != 2) {
+      if (e & 1)
+        asm("v_fma_mixhi_f16 %0, %3, %5, 0\n\t"
+            "v_fma_mixhi_f16 %1, %4, %5, 0\n\t"
+            ASDF16_AMAX_LINE
+            : "+v"(a), "+v"(c), "+v"(amax) : "v"(r0), "v"(r1), "v"(mul));
+      else        // (the even element defines the register: nothing of the previous tile's value is read)
+        asm("v_fma_mixlo_f16 %0, %3, %5, 0\n\t"
+            "v_fma_mixlo_f16 %1, %4, %5, 0\n\t"
+            ASDF16_AMAX_LINE
+            : "=&v"(a), "=&v"(c), "+v"(amax) : "v"(r0), "v"(r1), "v"(mul));
+      H0[e >> 1] = a; H1[e >> 1] = c;
+      hi0 = __builtin_bit_cast(h8, H0); hi1 = __builtin_bit_cast(h8, H1);
+    }
+    if (step != 1) {
+      if (e & 1)
+        asm("v_fma_mixhi_f16 %0, %2, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %4, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "+v"(b), "+v"(d) : "v"(r0), "v"(r1), "v"(mul), "v"(a), "v"(c));
+      else
+        asm("v_fma_mixlo_f16 %0, %2, %4, -%5 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %1, %3, %4, -%6 op_sel_hi:[0,0,1]"
+            : "=&v"(b), "=&v"(d) : "v"(r0), "v"(r1), "v"(mul), "v"(a), "v"(c));
+      L0[e >> 1] = b; L1[e >> 1] = d;
+      lo0 = __builtin_bit_cast(h8, L0); lo1 = __builtin_bit_cast(h8, L1);
+    }
+#undef ASDF16_AMAX_LINE
+    return;
+  }
   }
   const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
   const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
@@ -214,11 +284,11 @@ __device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb
 #endif
 }
 
-template <int PL = 2, int G = 1>
+template <int PL = 2, int G = 1, bool MIX = false>
 __device__ __forceinline__ void split_tile(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
                                            int g = -1) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split_part<PL, G>(acc, accb, mul, hi0, lo0, hi1, lo1, amax, e, g);
+  for (int e = 0; e < 8; ++e) split_part<PL, G, MIX>(acc, accb, mul, hi0, lo0, hi1, lo1, amax, e, g);
 }
 
 // a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
@@ -267,7 +337,7 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 // s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
 // ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, int PL, int G, class Pre, class Epi>
+template <int KB, int Q, int SLOT, int ABL, int PL, int G, bool STEPS, class Pre, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
                                         h8 (&ah)[S16<PL, G>::kPrefetch], h8 (&al)[S16<PL, G>::kPrefetch], Pre&& pre, Epi&& epi) {
@@ -312,7 +382,10 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
       // W_lo . x_hi, W_hi . x_hi, W_hi . x_lo
       acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
 #endif
-      const int m = (kb - BKB) * SG::kMfmas + j;       // one DMA piece per MFMA shadow behind the barrier (one per K-block: no difference)
+      // one DMA piece per MFMA shadow behind the barrier; split-half kernel (round 5): one per K-block, behind its LAST MFMA - the
+      // gap that carries the least of a deferred epilogue part
+      constexpr bool kDmaPerKb = STEPS && ASDF16_DMA_PER_KB && kS16Kb - BKB >= SG::kPieces;
+      const int m = kDmaPerKb ? (j == 2 ? kb - BKB : -1) : (kb - BKB) * SG::kMfmas + j;
       if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
         if (m == 0) dma_piece<0>(src, dst);
         else if (m == 1) dma_piece<1>(src, dst);
@@ -327,14 +400,15 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
 #ifdef ASDF16_FENCE_EVERY_MFMA
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (PL == 1 && G == 2) {
+      if ((PL == 1 && G == 2) || STEPS) {
         // two point groups: each group's share of the deferred epilogue goes behind ONE of the two MFMAs (left to itself the
         // scheduler issues both MFMAs back to back - the second waits a whole MFMA for the pipe - and then all the VALU work)
+        // split-half kernel (round 5): the same with the three pieces of a part behind the three MFMAs (split_part)
         epi(kb, j);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (!(PL == 1 && G == 2)) epi(kb);
+    if (!((PL == 1 && G == 2) || STEPS)) epi(kb);
     // K-block = scheduling region (hoisted, 16 K-blocks of A fragments do not fit the register file either)
     if (ASDF16_LOADS_FIRST || (kS16Kb > 8 && (kb % ASDF16_SCHED_KB) == ASDF16_SCHED_KB - 1)) __builtin_amdgcn_sched_barrier(0);
   }
@@ -361,6 +435,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   using SG = S16<PL, G>;
   static_assert(G == 1 || !TWO_OUT, "two point groups: SeparateDecoder");
   constexpr int kTilePts = kWgPts * G;           // points per workgroup tile
+  // the plane split on v_fma_mix (split_part), issued in three pieces, one behind each MFMA of the part's K-block.  SeparateDecoder
+  // forms only: the CombinedDecoder forms sit at the register limit with their second dot product - the asm blocks' simultaneous
+  // destinations cost them 20 .. 48 B of scratch, and with the pieces their unrolled layer-3 loop exceeds the compiler's full-unroll
+  // budget and comes out ROLLED, with indexed registers - and keep the round-2 form (same bits).
+  constexpr bool kMix = ASDF16_MIX_SPLIT && PL == 2 && !TWO_OUT;
+  constexpr bool kSteps = ASDF16_EPI_STEPS && kMix;
   static_assert(lds_bytes_f16(KP, PL) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;
@@ -564,7 +644,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (g != 1) acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s], accb);
         }
-        split_tile<PL, G>(acc, accb, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax, g);
+        split_tile<PL, G, kMix>(acc, accb, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax, g);
       };
       // the split of a tile is ~100 VALU instructions against 128 cycles of fp32 MFMA: layer 0 is VALU-bound when it runs
       // on its own.  Only the tiles the first stage of layer 1 consumes (K-blocks 0 .. kS16Kb-1) are computed up front;
@@ -609,7 +689,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (t + 2 < kTilesHidden) l0p_load(t + 2);
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < kTilesHidden) l0p_mfma(t + 1);
-          split_tile<PL, G>(la[t % 3], lb[t % 3], mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
+          split_tile<PL, G, kMix>(la[t % 3], lb[t % 3], mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -626,9 +706,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
-  stage16<KB, Q, SLOT, ABL, PL, G>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
+  stage16<KB, Q, SLOT, ABL, PL, G, kSteps>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       ASDF16_MARK(1);
+      // (split-half kernel: the second argument of an epilogue callback is the PIECE of the part - stage16 calls it behind each of
+      // the K-block's three MFMAs - and `er` carries a part's two ReLUs from piece to piece)
+      float er[2] = {0.0f, 0.0f};
       // ---- layer 1: 512 -> 256; epilogue of tile t-1 rides in tile t
       h8 h1h[2 * kTilesL1], h1l[2 * kTilesL1];
       if (ABL & 4) for (int t = 0; t < 2 * kTilesL1; ++t) { h1h[t] = h0h[t]; h1l[t] = h0l[t]; }
@@ -645,17 +728,30 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (t == 0) {
+            if (kSteps && kPreloadPf && kL0Front < kTilesHidden) {
+              // a whole layer-0 tile per K-block: its fp32 MFMAs behind the first MFMA, its eight parts over the three gaps (3 + 3 + 2)
+              const int T = kL0Front + c;
+              if (g == 0) {
+#pragma unroll
+                for (int s = 0; s < KP; ++s) acc0[T & 1] = ASDF_MFMA(pf0[T & 1][s], bp[s], acc0[T & 1]);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (e / 3 == g) split_part<PL, G, kMix>(acc0[T & 1], acc0[T & 1], mul0, h0h[2 * T], h0l[2 * T], h0h[2 * T + 1], h0l[2 * T + 1], amax, e);
+              return;
+            }
+            if (kSteps && g > 0) return;
             if (kL0Front < kTilesHidden) {       // layer-0 tiles 8 .. 15: consumed by the next stage
-              l0_compute(kL0Front + c, g);
+              l0_compute(kL0Front + c, kSteps ? -1 : g);
               if (!ASDF16_PRELOAD && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
             }
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          if (g != 1) pin_acc<PL>(acc1[(t - 1) & 1]);
+          if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(t - 1) & 1]);
           if (G == 2 && g != 0) pin_acc<PL>(acc1b[(t - 1) & 1]);
-          split_part<PL, G>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
-                            h1l[2 * (t - 1) + 1], amax1, c, g);
+          split_part<PL, G, kMix>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
+                            h1l[2 * (t - 1) + 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != kPreKb) return;
@@ -699,15 +795,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
-            if (g != 1) pin_acc<PL>(acc2[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(t - 1) & 1]);
             if (G == 2 && g != 0) pin_acc<PL>(acc2b[(t - 1) & 1]);
-            split_part<PL, G>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
-                              h2l[2 * (t - 1) + 1], amax2, c, g);
+            split_part<PL, G, kMix>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
+                              h2l[2 * (t - 1) + 1], amax2, c, kSteps ? -1 : g, kSteps ? g : -1, er);
           } else {
-            if (g != 1) pin_acc<PL>(acc1[(kTilesL1 - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(kTilesL1 - 1) & 1]);
             if (G == 2 && g != 0) pin_acc<PL>(acc1b[(kTilesL1 - 1) & 1]);
-            split_part<PL, G>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
-                              h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, g);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
+            split_part<PL, G, kMix>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
+                              h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
         };
         auto pre_last = [&](int c) {
@@ -748,9 +844,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // ---- layer 3 (512 -> 512) fused with layer 4 (dot with w4 / (S_w3 S_x)) and tanh
       float part = 0.0f, partb = 0.0f, partg = 0.0f;      // partg: the second point group's dot product (G == 2)
       // accumulator registers 2 c, 2 c + 1 of a finished tile into the last-layer dot product(s), weights from (w4c, w4bc)
-      auto dot_w4_part = [&](const f32x16& a, const f32x16& ab, int c, int g = -1) {
+      auto dot_w4_part = [&](const f32x16& a, const f32x16& ab, int c, int g = -1, int only = -1) {      // only: 0 / 1 = that register of the pair
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
+          if (only >= 0 && only != r) continue;
           const float w = kW4Tile ? w4t[2 * c + r] : w4c[r];
           if (PL == 1 && ASDF16_P1_FOLD) {
             // relu(a) w = a (w / 2) + |a| (w / 2): two FMAs like max + FMA, and a NaN / infinity of either sign stays one (the image's
@@ -787,15 +884,21 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) {
-            if (g != 1) pin_acc<PL>(acc3[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc3[(t - 1) & 1]);
             if (G == 2 && g != 0) pin_acc<PL>(acc3b[(t - 1) & 1]);
-            dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, g);
-            if (!kW4Tile && g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
+            if (kSteps) {        // piece 0 / 1: one register of the pair each; piece 2: the next pair's weights
+              if (g < 2) dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, -1, g);
+              if (!kW4Tile && (g == 2 || g < 0)) next_w4();
+            } else {
+              dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, g, -1);
+              if (!kW4Tile && g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
+            }
           } else {
-            if (g != 1) pin_acc<PL>(acc2[(kTilesHidden - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(kTilesHidden - 1) & 1]);
             if (G == 2 && g != 0) pin_acc<PL>(acc2b[(kTilesHidden - 1) & 1]);
-            split_part<PL, G>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
-                              h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, g);  // K-blocks 30, 31: end of this tile
+            split_part<PL, G, kMix>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
+                              h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, kSteps ? -1 : g,
+                              kSteps ? g : -1, er);  // K-blocks 30, 31: end of this tile
           }
         };
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
@@ -840,16 +943,19 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         return tanhf(x);
       };
       part += __shfl_xor(part, 32);
-      const float sdf = tanh_out(part + hc[CL::kB4]);
-      float sdfb = 1.0f;
+      const float pre = part + hc[CL::kB4];           // (pre-activations: the strict range report below looks at THESE)
+      const float sdf = tanh_out(pre);
+      float sdfb = 1.0f, preb = 0.0f, preg = 0.0f;
       if (TWO_OUT) {
         partb += __shfl_xor(partb, 32);
-        sdfb = tanh_out(partb + hc[CL::kB4 + 1]);
+        preb = partb + hc[CL::kB4 + 1];
+        sdfb = tanh_out(preb);
       }
       float sdfg = 0.0f;           // the second point group's output (G == 2)
       if (G == 2) {
         partg += __shfl_xor(partg, 32);
-        sdfg = tanh_out(partg + hc[CL::kB4]);
+        preg = partg + hc[CL::kB4];
+        sdfg = tanh_out(preg);
       }
       const bool is_hand = head == 0;
       if (SUB) {
@@ -899,12 +1005,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       // [-1, 1] (NaN / infinity downstream of an overflow).  The count goes to the decoder's status word - always, not only
       // when the caller passed a bbox buffer - and, for grid sweeps with a bbox, to word 7 / 15 of that record as well.
       // (one-plane kernels, folded image: no running maximum - every ReLU preserves a poisoned value, so an activation that left the
-      // fp16 range arrives HERE as a NaN or as exactly +-1: no decoder of a clamped SDF gets there honestly)
+      // fp16 range arrives HERE as a non-finite PRE-activation of the tanh: a NaN, or an infinity.  The check is on that value, not
+      // on the output - tanhf returns exactly +-1 for every finite argument beyond ~9, so a decoder that merely saturates in the far
+      // field must not read as a range violation: ADVICE r04, it drove such a decoder through four re-calibrations to the fp32 chain)
       constexpr bool kStrict = PL == 1 && ASDF16_P1_FOLD;
+      if (kMix) { amax *= mul0; amax1 *= mul1; amax2 *= mul2; }      // (the maxima were taken in front of the rescale)
       const bool act_over = !(fmaxf(amax, fmaxf(amax1, amax2)) < 65504.0f);
-      auto out_ok = [&](float v) { return kStrict ? fabsf(v) < 1.0f : fabsf(v) <= 1.0f; };
-      const int bad = ((valid || validb) && (act_over || !out_ok(sdf) || (TWO_OUT && !out_ok(sdfb)) ||
-                                            (G == 2 && !out_ok(sdfg)))) ? 1 : 0;
+      auto out_ok = [&](float v, float pre_v) { return kStrict ? fabsf(pre_v) < INFINITY : fabsf(v) <= 1.0f; };
+      const int bad = ((valid || validb) && (act_over || !out_ok(sdf, pre) || (TWO_OUT && !out_ok(sdfb, preb)) ||
+                                            (G == 2 && !out_ok(sdfg, preg)))) ? 1 : 0;
       if (!kStrict && (valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
         atomicMax(wrec + 16, __float_as_int(amax));
         atomicMax(wrec + 17, __float_as_int(amax1));

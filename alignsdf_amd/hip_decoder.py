@@ -39,6 +39,10 @@ TAU_ACCEPT = 0.6
 # sample of the audit's size), i.e. how far the largest error can hide from a sample, is a measured quantity that is never older
 # than that - and on the coarse pass that follows any sweep refused for its error.  A tail ratio above TAIL_MAX means the error has
 # rare large outliers a sample cannot see: the one-plane sweeps are switched off for that decoder.
+# Round 5: the comparison ALTERNATES between the coarse lattice ([-1, 1]^3) and the ZOOM lattice of the fine pass - the lattice whose
+# signs marching cubes actually consumes: another voxel pitch, other coordinates, values ten times closer to the level
+# (utils/mesh.py:82-121).  A decoder's first coarse AND first fine pass are compared; afterwards one of the two every RECAL_EVERY
+# samples, in turn.  A band sweep needs a valid fine-lattice comparison, a box sweep a valid coarse-lattice one.
 RECAL_EVERY = 64
 TAIL_MAX = 3.0
 
@@ -271,13 +275,24 @@ class HipSdfDecoder:
         self._tail_by_n = {}         # tail ratio per uniform sample size (a ladder of powers of two), from the last calibration
         self._cal_points = 0         # lattice size of the last calibration: a much larger lattice needs its own
         self._coarse_since_cal = 0
+        # the same for the zoom lattice of the fine pass: its own epoch, lattice size and tail ladder
+        self._fine_epoch = -1
+        self._fine_cal_points = 0
+        self._tail_fine = 1.0
+        self._tail_by_n_fine = {}
+        self._next_recal = "coarse"  # which lattice the next periodic whole-lattice comparison measures
         self._err_window = collections.deque(maxlen=16)
         self.audit_voxels = AUDIT_VOXELS
         # what the certificate of the one-plane sweeps rests on, as measured (bench.py prints it as the `certificate` block)
         self.cert = {"calibrations": 0, "tail_ratio": None, "tail_ratio_max": None, "lattice_max_error": None, "lattice_sigma": None,
                      "lattice_max_over_sigma": None, "neighbour_correlation": None, "audited_sweeps": 0, "shell_picks": 0,
                      "shell_population_max": 0, "uniform_picks": 0, "min_margin_tau_over_estimate": None, "min_tau_over_sigma": None,
-                     "audit_sigma_max": None, "refusals_for_error": 0}
+                     "audit_sigma_max": None, "refusals_for_error": 0,
+                     # the same whole-lattice comparison on the zoom lattice of a fine pass
+                     "fine_calibrations": 0, "fine_lattice_max_error": None, "fine_lattice_sigma": None, "fine_max_over_sigma": None,
+                     "fine_tail_ratio": None, "fine_tail_ratio_max": None, "fine_neighbour_correlation": None}
+        # what a run did, for the `sweeps.json` next to its meshes (reconstruct / dist_reconstruct): repeats and mode switches
+        self.events = {"repeated_sweeps": 0, "modes_switched_off": [], "fp32_fallback": False}
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
         self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps, plus the sweep's record tensor
 
@@ -568,17 +583,22 @@ class HipSdfDecoder:
         n = int(min(audit_voxels, max(points // 16, 64)))
         return n - n // 2, n // 2
 
-    def _tail_for(self, points):
-        """Tail ratio for the uniform half of an audit on a lattice of `points` voxels: the calibration's entry for the largest
-        sample size not above it (a smaller sample sees less of the tail: conservative)."""
+    def _tail_for(self, points, which="coarse"):
+        """Tail ratio for the uniform half of an audit on a lattice of `points` voxels: the last whole-lattice comparison's entry
+        (of the coarse lattice, or of the zoom lattice for a band sweep once one has been measured) for the largest sample size not
+        above it (a smaller sample sees less of the tail: conservative).  The ladder starts at 1, so every audit size has an entry
+        (below 32 picks the fallback used to be the stale scalar)."""
         uniform, _ = self.audit_sizes(self.audit_voxels, points)
+        ladder, scalar = (self._tail_by_n_fine, self._tail_fine) if which == "fine" and self._tail_by_n_fine else (self._tail_by_n, self._tail)
         best = None
-        for n, t in self._tail_by_n.items():
+        for n, t in ladder.items():
             if n <= max(uniform, 1) and (best is None or n > best[0]):
                 best = (n, t)
-        return best[1] if best is not None else self._tail
+        if best is None and ladder:
+            best = min(ladder.items())            # below the ladder: its smallest entry, the conservative one
+        return best[1] if best is not None else scalar
 
-    def _judge(self, r, tau, stats, cap_word, cap, points=None):
+    def _judge(self, r, tau, stats, cap_word, cap, points=None, which="coarse"):
         """Verdict on the record of one one-plane sweep launched with allowance tau: (accepted, range violations, reason).
         Accepted = no fp16 range violation, every list within its capacity, no contradiction, the largest |exact - one-plane| over
         the re-evaluated voxels AND the audit's estimate of the lattice maximum within TAU_ACCEPT x tau, and no audit voxel whose sign the
@@ -591,7 +611,7 @@ class HipSdfDecoder:
         flips, evals = int(r[36]), int(r[37])
         shell_picks, shell_pop, sumsq = int(r[39]), int(r[40]), f(41)
         listed = max(int(r[w]) for w in cap_word)
-        tail = self._tail_for(points) if points else self._tail
+        tail = self._tail_for(points, which) if points else self._tail
         est = audit * tail
         sigma = float(np.sqrt(sumsq / evals)) if evals > 0 and np.isfinite(sumsq) and sumsq >= 0 else float("nan")
         stats["max_err"] = max(stats["max_err"], err)
@@ -636,7 +656,9 @@ class HipSdfDecoder:
                 c["audit_sigma_max"] = sigma if c["audit_sigma_max"] is None else max(c["audit_sigma_max"], sigma)
         elif for_error:
             c["refusals_for_error"] += 1
-            self._box_epoch = -1          # the allowance is void until the next coarse pass has measured the whole lattice again
+            # the allowance is void until the whole lattice has been measured again - the coarse lattice by the next coarse pass, the
+            # zoom lattice by the next fine pass
+            self._box_epoch = self._fine_epoch = -1
         return reason is None, bad, near_over, reason
 
     # ---- records travel to the host behind their own sweep: an asynchronous copy into pinned memory + an event recorded right behind
@@ -685,11 +707,19 @@ class HipSdfDecoder:
         return (self._box_tau is not None and self._box_epoch == self._recalibrations and
                 (N is None or int(N) ** 3 <= 8 * self._cal_points))
 
+    def _fine_valid(self, N=None):
+        """A zoom lattice has been compared as a whole under the current activation scales, no sweep has been refused for its error
+        since, and it was not much smaller than the one to be swept."""
+        return (self._fine_epoch == self._recalibrations and (N is None or int(N) ** 3 <= 8 * self._fine_cal_points))
+
     def coarse_begin(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
         """Enqueue the coarse pass of one sample; returns a ticket for coarse_finish."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
         self._coarse_since_cal += 1
-        due = self._coarse_since_cal > RECAL_EVERY          # the periodic whole-lattice re-measurement: this pass runs both ways
+        # the periodic whole-lattice re-measurement: this pass runs both ways - when it is the coarse lattice's turn (the zoom
+        # lattice's turn is taken by this sample's fine pass: fine_begin)
+        due = self._coarse_since_cal > RECAL_EVERY and (self._next_recal == "coarse" or not self._band_usable() or
+                                                        self._coarse_since_cal > 2 * RECAL_EVERY)      # (no fine pass took its turn)
         if self._box_usable() and self._allowance_valid(N) and not self._force_f32_once and not due:
             rec, sh, so = self._box_launch(*args, self._box_tau)
             return {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": self._box_tau, "epoch": self._recalibrations,
@@ -716,6 +746,7 @@ class HipSdfDecoder:
                 self._box_failures = 0              # (three refusals IN A ROW switch the mode off)
                 return r[:16].copy()
             self.box_stats["fallback"] += 1
+            self.events["repeated_sweeps"] += 1
             if bad:
                 self._recover(bad)                  # new activation scales: the allowance is re-calibrated with them
             else:
@@ -728,11 +759,13 @@ class HipSdfDecoder:
                 if self._box_failures >= 3:
                     logging.warning("box-only coarse sweep switched off for this decoder")
                     self.coarse_mode = "exact"
+                    self.events["modes_switched_off"].append("coarse: three refusals in a row (%s)" % reason)
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
             ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
         b = self._record_of(ticket)
         keep, epoch = ticket["keep"], ticket["epoch"]
         while self.fall_back_if_overflowed(b, epoch):      # split-half planes out of fp16 range: re-calibrated, or at last fp32
+            self.events["repeated_sweeps"] += 1
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
             b, keep, epoch = bbox.cpu().numpy(), (h, o), self._recalibrations
         self.box_stats["exact"] += 1
@@ -740,6 +773,8 @@ class HipSdfDecoder:
         # calibrated here, on the coarse lattice, while the decoder is bound to this sample
         if (self._box_usable() or self._band_usable()) and calibrate_allowance and (not self._allowance_valid(N) or ticket.get("recalibrate")):
             self._calibrate_box(ticket["args"], keep)
+            if ticket.get("recalibrate") and self._band_usable():
+                self._next_recal = "fine"           # the next periodic comparison measures a zoom lattice
         b = b.copy()
         b[7] &= NEAR_OVERFLOW_BIT - 1
         b[15] &= NEAR_OVERFLOW_BIT - 1
@@ -755,14 +790,22 @@ class HipSdfDecoder:
         mc_only=True declares that the volumes go to marching cubes at level 0 and nowhere else: only then may a decoder
         set to fine_mode "band" deliver them exact next to the surface and sign-correct elsewhere."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
-        if mc_only and self._band_usable() and not self._band_skip and self._allowance_valid(N) and not self._force_f32_once:
+        band = mc_only and self._band_usable() and not self._force_f32_once
+        fine_due = self._coarse_since_cal > RECAL_EVERY and self._next_recal == "fine"
+        if band and not self._band_skip and self._allowance_valid(N) and self._fine_valid(N) and not fine_due:
             rec, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band, "asdf_decode_grid_band", N, origin3, voxel_size,
                                                  grid_mode, hand, obj, self._box_tau)
             return vh, vo, {"kind": "band", "args": args, "rec": rec, "tau": self._box_tau, "epoch": self._recalibrations,
                             "host": self._record_to_host(rec)}
         self._band_skip = False
         vh, vo, bbox2 = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj)
-        return vh, vo, {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations, "host": self._record_to_host(bbox2)}
+        ticket = {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations, "host": self._record_to_host(bbox2)}
+        if band and self.math == "f16x3" and (fine_due or not self._fine_valid(N)):
+            # the zoom lattice is compared as a whole: this ordinary sweep (whose volumes the caller gets) against a plain one-plane
+            # sweep of the same lattice, enqueued here while the decoder is bound to the sample and evaluated in fine_needs_repeat
+            ticket["compare"] = self._plain_one_plane(args) + (vh, vo)
+            ticket["periodic"] = fine_due
+        return vh, vo, ticket
 
     def fine_needs_repeat(self, ticket):
         """True when the fine pass has to be repeated (the decoder must be bound to its sample again first): its range or
@@ -777,12 +820,14 @@ class HipSdfDecoder:
                 # the SAMPLE - refine_tau is absolute - and is honoured: the repeat runs on the fp32 chain.)
                 ok, bad, near_over, reason = False, 0, self._range_words(r)[1], "launched under activation scales that have been re-calibrated since"
             else:
-                ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP, points=int(ticket["args"][0]) ** 3)
+                ok, bad, near_over, reason = self._judge(r, ticket["tau"], self.band_stats, (33, 34), BAND_CAP, points=int(ticket["args"][0]) ** 3,
+                                                         which="fine")
             if ok:
                 self.band_stats["band"] += 1
                 self._band_failures = 0
                 return False
             self.band_stats["fallback"] += 1
+            self.events["repeated_sweeps"] += 1
             if bad:
                 self._recover(bad)
             else:
@@ -794,33 +839,40 @@ class HipSdfDecoder:
                 if self._band_failures >= 3:
                     logging.warning("narrow-band fine sweep switched off for this decoder")
                     self.fine_mode = "exact"
+                    self.events["modes_switched_off"].append("fine: three refusals in a row (%s)" % reason)
             self._band_skip = True
             return True
         if ticket["rec"] is not None and self.fall_back_if_overflowed(self._record_of(ticket), ticket.get("epoch")):
+            self.events["repeated_sweeps"] += 1
             return True
         self.band_stats["exact"] += 1
+        if ticket.get("compare") is not None and ticket["epoch"] == self._recalibrations:
+            rec, sh, so, vh, vo = ticket.pop("compare")
+            self._calibrate_fine(ticket["args"], (sh, so), (vh, vo), ticket.get("periodic", False))
         return False
 
-    def _calibrate_box(self, args, exact_vols):
-        """Error allowance of the one-plane sweep for this decoder and scale set, from one whole coarse sweep run both ways: every one
-        of the 2 x N^3 one-plane values against the ordinary sweep's.  Measured: the lattice maximum of |one-plane - split-half|, its
-        rms (sigma), the correlation of the signed error between x-neighbours (noise-like = near 0), and the TAIL RATIO - lattice
-        maximum / maximum of a uniform sample - for a ladder of sample sizes, with which the audits of later sweeps estimate THEIR
-        lattice maximum.  Runs on the first coarse pass of a decoder and scale epoch, on the coarse pass after a sweep refused for
-        its error, and every RECAL_EVERY coarse passes (tail regularity is re-measured, not assumed)."""
-        import logging
+    def _plain_one_plane(self, args):
+        """One plain one-plane sweep of a lattice for a whole-lattice comparison: a tiny allowance (next to no candidates are
+        re-evaluated) and no audit (it would overwrite its picks with exact values).  Returns (record, sdf_hand, sdf_obj)."""
         audit = self.audit_voxels
-        N = int(args[0])
-        self.set_audit(0)                                      # (the audit would overwrite its picks with exact values)
-        rec, sh, so = self._box_launch(*args, 1e-7)            # (a tiny allowance: next to no candidates, plain one-plane values)
+        self.set_audit(0)
+        out = self._box_launch(*args, 1e-7)
         self._audit_restarts = getattr(self, "_audit_restarts", 0) + 1
         self.set_audit(audit, seed=0x5DF5A11D00000000 + 0x9E3779B9 * self._audit_restarts)
+        return out
+
+    LADDER = [1 << k for k in range(0, 18)]
+
+    def _compare_lattices(self, fast_vols, exact_vols, N):
+        """All 2 x N^3 one-plane values against the ordinary sweep's: lattice maximum of |one-plane - split-half|, its rms (sigma), the
+        correlation of the signed error between x-neighbours (noise-like = near 0), and the TAIL RATIO - lattice maximum / maximum
+        of a uniform sample - for a ladder of sample sizes 1 .. 2^17."""
         err, sumsq, count, corr = 0.0, 0.0, 0, 0.0
-        ladder = [1 << k for k in range(5, 18)]
+        ladder = self.LADDER
         sample_max = np.zeros(len(ladder))
         gen = torch.Generator(device=self.device)
-        gen.manual_seed(12345 + self._audit_restarts)
-        for fast, exact in zip((sh, so), exact_vols):
+        gen.manual_seed(12345 + getattr(self, "_audit_restarts", 0))
+        for fast, exact in zip(fast_vols, exact_vols):
             if fast is not None and exact is not None:
                 signed = (fast - exact).reshape(-1)
                 diff = signed.abs()
@@ -835,39 +887,77 @@ class HipSdfDecoder:
                 pick = torch.randint(0, diff.numel(), (ladder[-1],), device=self.device, generator=gen)
                 running = torch.cummax(diff[pick], 0).values
                 sample_max = np.maximum(sample_max, running[torch.tensor([n - 1 for n in ladder], device=self.device)].cpu().numpy())
-        self._coarse_since_cal = 0
-        self._box_epoch = self._recalibrations
-        self._cal_points = N ** 3
-        fresh = self.cert["calibrations"] == 0 or not self._err_window
+        sigma = float(np.sqrt(sumsq / max(count, 1)))
+        tails = {n: float(np.clip(err / m, 1.0, 1e3)) if m > 0 and np.isfinite(m) else 2.0 for n, m in zip(ladder, sample_max)}
+        return {"err": err, "sigma": sigma, "corr": corr, "tails": tails}
+
+    def _apply_comparison(self, m, N, which):
+        """Take a whole-lattice comparison (_compare_lattices) into the allowance, the tail ladder and the certificate.  `which` =
+        "coarse" | "fine".  Returns False when it switched one-plane sweeps off."""
+        import logging
+        err, sigma, corr = m["err"], m["sigma"], m["corr"]
+        c = self.cert
+        fresh = c["calibrations"] + c["fine_calibrations"] == 0 or not self._err_window
         if fresh:
             self._err_window.clear()
         if not np.isfinite(err) or TAU_FACTOR * err > 0.05:
-            logging.warning("one-plane sweeps: error %.3g too large, switched off for this decoder", err)
+            logging.warning("one-plane sweeps: error %.3g on the %s lattice too large, switched off for this decoder", err, which)
+            self.events["modes_switched_off"].append("both: %s-lattice error %.3g too large" % (which, err))
             self.coarse_mode = self.fine_mode = "exact"
             self._box_tau = None
-            return
-        tails = {n: float(np.clip(err / m, 1.0, 1e3)) if m > 0 and np.isfinite(m) else 2.0 for n, m in zip(ladder, sample_max)}
-        uniform, _ = self.audit_sizes(audit, N ** 3)
-        self._tail_by_n = tails
-        self._tail = self._tail_for(N ** 3) if uniform else 1.0
-        sigma = float(np.sqrt(sumsq / max(count, 1)))
-        c = self.cert
-        c["calibrations"] += 1
-        c["tail_ratio"] = self._tail
-        c["tail_ratio_max"] = self._tail if c["tail_ratio_max"] is None else max(c["tail_ratio_max"], self._tail)
-        c["lattice_max_error"], c["lattice_sigma"] = err, sigma
-        c["lattice_max_over_sigma"] = err / sigma if sigma > 0 else None
-        c["neighbour_correlation"] = corr
-        if self._tail > TAIL_MAX:
-            logging.warning("one-plane sweeps: the lattice maximum %.3g is %.1f x what a sample of %d sees - rare large errors a sample "
-                            "cannot certify; switched off for this decoder", err, self._tail, uniform)
+            return False
+        uniform, _ = self.audit_sizes(self.audit_voxels, N ** 3)
+        if which == "coarse":
+            self._box_epoch, self._cal_points, self._tail_by_n = self._recalibrations, N ** 3, m["tails"]
+            tail = self._tail = self._tail_for(N ** 3, "coarse") if uniform else 1.0
+            c["calibrations"] += 1
+            c["tail_ratio"] = tail
+            c["tail_ratio_max"] = tail if c["tail_ratio_max"] is None else max(c["tail_ratio_max"], tail)
+            c["lattice_max_error"], c["lattice_sigma"] = err, sigma
+            c["lattice_max_over_sigma"] = err / sigma if sigma > 0 else None
+            c["neighbour_correlation"] = corr
+        else:
+            self._fine_epoch, self._fine_cal_points, self._tail_by_n_fine = self._recalibrations, N ** 3, m["tails"]
+            tail = self._tail_fine = self._tail_for(N ** 3, "fine") if uniform else 1.0
+            c["fine_calibrations"] += 1
+            c["fine_tail_ratio"] = tail
+            c["fine_tail_ratio_max"] = tail if c["fine_tail_ratio_max"] is None else max(c["fine_tail_ratio_max"], tail)
+            c["fine_lattice_max_error"], c["fine_lattice_sigma"] = err, sigma
+            c["fine_max_over_sigma"] = err / sigma if sigma > 0 else None
+            c["fine_neighbour_correlation"] = corr
+        if tail > TAIL_MAX:
+            logging.warning("one-plane sweeps: the %s lattice's maximum %.3g is %.1f x what a sample of %d sees - rare large errors a "
+                            "sample cannot certify; switched off for this decoder", which, err, tail, uniform)
+            self.events["modes_switched_off"].append("both: %s-lattice tail ratio %.2f > %.1f" % (which, tail, TAIL_MAX))
             self.coarse_mode = self.fine_mode = "exact"
             self._box_tau = None
-            return
+            return False
         self._err_window.append(max(err, 2.5e-7))
         self._box_tau = self._tau_current()
-        logging.info("one-plane sweeps: lattice error max %.3g sigma %.3g (max / sigma %.1f, x-neighbour correlation %.3f), sample of %d "
-                     "per head: tail ratio %.2f, allowance %.3g", err, sigma, err / max(sigma, 1e-30), corr, uniform, self._tail, self._box_tau)
+        logging.info("one-plane sweeps, %s lattice: error max %.3g sigma %.3g (max / sigma %.1f, x-neighbour correlation %.3f), sample of "
+                     "%d per head: tail ratio %.2f, allowance %.3g", which, err, sigma, err / max(sigma, 1e-30), corr, uniform, tail, self._box_tau)
+        return True
+
+    def _calibrate_box(self, args, exact_vols):
+        """Error allowance of the one-plane sweep for this decoder and scale set, from one whole COARSE sweep run both ways: every one
+        of the 2 x N^3 one-plane values against the ordinary sweep's (_compare_lattices).  Runs on the first coarse pass of a decoder
+        and scale epoch, on the coarse pass after a sweep refused for its error, and - alternating with the zoom lattice
+        (_calibrate_fine) - every RECAL_EVERY samples (tail regularity is re-measured, not assumed)."""
+        N = int(args[0])
+        rec, sh, so = self._plain_one_plane(args)
+        self._coarse_since_cal = 0
+        self._apply_comparison(self._compare_lattices((sh, so), exact_vols, N), N, "coarse")
+
+    def _calibrate_fine(self, args, fast_vols, exact_vols, periodic=False):
+        """The same comparison on the ZOOM lattice of a fine pass - the lattice whose signs marching cubes consumes (utils/mesh.py:82-121,
+        :354): the pass ran as an ordinary sweep (its volumes went to the caller) with a plain one-plane sweep of the same lattice
+        enqueued behind it (fine_begin).  First fine pass of a decoder and scale epoch, the fine pass after a refusal for error, and
+        every other periodic re-measurement."""
+        N = int(args[0])
+        if periodic:
+            self._coarse_since_cal = 0
+            self._next_recal = "coarse"
+        self._apply_comparison(self._compare_lattices(fast_vols, exact_vols, N), N, "fine")
 
     def certificate(self):
         """What the default sweeps' certificate rests on, as measured so far on this decoder."""

@@ -33,6 +33,15 @@ def _bind(hip, specs, sample):
     hip.set_sample(torch.from_numpy(lat).cuda(), sample_embedding(specs, mano, obj, hip.combined))
 
 
+def _prime_fine(hip, N, origin, voxel):
+    """A decoder's FIRST fine pass (and the first after a voided allowance) runs as an ordinary sweep plus a plain one-plane sweep of
+    the same zoom lattice, compared voxel for voxel when the record is read (round 5: the whole-lattice comparison on the lattice
+    marching cubes consumes); band sweeps follow."""
+    _, _, t = hip.fine_begin(N, origin, voxel, mc_only=True)
+    assert t["kind"] == "exact" and "compare" in t and not hip.fine_needs_repeat(t)
+    assert hip._fine_valid(N) and hip.cert["fine_calibrations"] >= 1
+
+
 def _boxes(b):
     return [int(v) for v in b[0:6]] + [int(v) for v in b[8:14]] + [int(b[6] != 0), int(b[14] != 0)]
 
@@ -237,6 +246,7 @@ def test_band_refused_when_the_allowance_is_understated():
     vs = 2.0 / (N - 1)
     _bind(hip, specs, 0)
     hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+    _prime_fine(hip, N, [-0.62, -0.36, -0.37], 1.21 / (N - 1))
     honest = hip._box_tau
     hip._box_tau = honest / 64.0
     _bind(hip, specs, 1)
@@ -262,6 +272,7 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
     lattice = ([-0.62, -0.36, -0.37], 1.21 / (N - 1))
     _bind(hip, specs, 0)
     hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))
+    _prime_fine(hip, N, lattice[0], lattice[1])
     for hand, obj in ((True, False), (False, True)):
         _bind(hip, specs, 2)
         bh, bo, ticket = hip.fine_begin(N, lattice[0], lattice[1], hand=hand, obj=obj, mc_only=True)
@@ -287,7 +298,9 @@ def test_band_single_branch_and_through_the_sample_pipeline(monkeypatch):
         out[name] = {k: r for k, r in pipelined_two_pass(dec, specs, iter(samples), 64)}
         if name == "one_plane":
             hipd = decoder_for(dec, specs)
-            assert hipd.band_stats["band"] == len(samples) and hipd.band_stats["fallback"] == 0, hipd.band_stats      # (the coarse pass of sample 0 calibrated)
+            # (the coarse pass of sample 0 calibrated on the coarse lattice, its fine pass on the zoom lattice: an ordinary sweep)
+            assert hipd.band_stats["band"] == len(samples) - 1 and hipd.band_stats["exact"] == 1 and hipd.band_stats["fallback"] == 0, hipd.band_stats
+            assert hipd.cert["fine_calibrations"] == 1 and hipd.cert["calibrations"] == 1
     for k, a in out["fp32"].items():
         b = out["one_plane"][k]
         assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"])
@@ -320,7 +333,9 @@ def test_one_plane_sweeps_over_all_64_synthetic_samples():
             assert torch.equal(vb, ve) and torch.equal(fb, fe), sample
             checked += 1
     assert checked == 128 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
-    assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 64
+    assert hip.box_stats["box"] == 63 and hip.band_stats["band"] == 63 and hip.band_stats["exact"] == 1      # sample 0: both lattices compared as a whole
+    c = hip.certificate()
+    assert c["calibrations"] == 1 and c["fine_calibrations"] == 1 and c["fine_tail_ratio"] <= 3.0 and c["fine_lattice_max_error"] > 0
     hip.close()
 
 
@@ -382,7 +397,7 @@ def test_one_plane_sweeps_on_lattices_that_are_not_multiples_of_four(N):
             vb, fb = marching_cubes_device(bv, 0.0)
             ve, fe = marching_cubes_device(ev, 0.0)
             assert torch.equal(vb, ve) and torch.equal(fb, fe)
-    assert hip.box_stats["box"] == 2 and hip.band_stats["band"] == 3 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+    assert hip.box_stats["box"] == 2 and hip.band_stats["band"] == 2 and hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     hip.close()
 
 
@@ -457,4 +472,34 @@ def test_one_plane_kernel_reports_an_fp16_overflow_through_its_outputs(tag):
     hip.set_act_scales(good)
     _bind(hip, specs, 1)
     assert sweep() == 0
+    hip.close()
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "comb3"])
+def test_a_decoder_that_saturates_is_not_a_range_violation(tag):
+    """fp32 tanhf returns EXACTLY +-1 for every finite argument beyond ~9, so a decoder whose output merely
+    saturates in the far field (here: the last layer x 400 - the same zero set, a steeper field) produced `bad` on every one-plane
+    sweep while the range report looked at the tanh OUTPUT: four futile re-calibrations later the decoder sat on the fp32 chain for
+    good.  The report now looks at the pre-activation (non-finite = an fp16 overflow upstream): saturated outputs, no violation, the
+    box sweep's boxes equal the ordinary sweep's, the arithmetic in force is still the split-half one."""
+    from alignsdf_amd.hip_decoder import HipSdfDecoder
+    specs = syn.specs_for(tag)
+    sd = {k: np.array(v, copy=True) for k, v in syn.full_state_dict(tag).items()}
+    for k in list(sd):
+        if k.split(".")[0] in ("linh4", "lino4", "lin4"):
+            sd[k] = sd[k] * np.float32(400.0)
+    hip = HipSdfDecoder(sd, 256, specs["PointFeatSize"], specs["EncodeStyle"])
+    hip.coarse_mode = "box"
+    N, vs = 64, 2.0 / 63
+    for sample in range(3):
+        _bind(hip, specs, sample)
+        vh, vo, want = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)
+        assert float((vh.abs() == 1.0).float().mean()) > 0.5                    # most of the cube IS saturated
+        rec, sh, so = hip._box_launch(N, [-1.0, -1.0, -1.0], vs, 0, True, True, 0.02)
+        r = rec.cpu().numpy()
+        assert (int(r[7]) & 0x3fffffff) == 0 and (int(r[15]) & 0x3fffffff) == 0, (tag, sample, int(r[7]), int(r[15]))
+        assert float((sh.abs() == 1.0).float().mean()) > 0.5 and bool(torch.isfinite(sh).all())
+        got = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))
+        assert _boxes(got) == _boxes(want.cpu().numpy()), (tag, sample)
+    assert hip.math == "f16x3" and hip._recalibrations <= 1, (hip.math, hip._recalibrations)
     hip.close()

@@ -55,9 +55,15 @@ def test_default_meshes_are_the_ordinary_sweeps_meshes_all_64_samples_n256(tag, 
         assert a[0] == b[0] and a[1] == b[1], (s, "zoom cube")
         for k in (2, 3, 4, 5):
             assert torch.equal(a[k], b[k]), (s, k)
-    # sample 0's coarse pass calibrated the allowance on an ordinary sweep; everything else ran on the one-plane kernel
+    # sample 0's coarse pass calibrated the allowance on an ordinary sweep of the coarse lattice, its fine pass on one of the zoom
+    # lattice (round 5); everything else ran on the one-plane kernel
     n = len(samples)
-    assert hip.box_stats["box"] == n - 1 and hip.band_stats["band"] == n, (hip.box_stats, hip.band_stats)
+    assert hip.box_stats["box"] == n - 1 and hip.band_stats["band"] == n - 1, (hip.box_stats, hip.band_stats)
+    c = hip.certificate()
+    assert c["calibrations"] == 1 and c["fine_calibrations"] == 1 and c["fine_tail_ratio"] <= 3.0, c
+    print(tag, "zoom lattice: max error %.3g, sigma %.3g, max / sigma %.1f, tail ratio %.2f (TAIL_MAX 3.0: margin %.2f) | coarse: %.3g, %.1f, %.2f" % (
+        c["fine_lattice_max_error"], c["fine_lattice_sigma"], c["fine_max_over_sigma"], c["fine_tail_ratio"], 3.0 / c["fine_tail_ratio"],
+        c["lattice_max_error"], c["lattice_max_over_sigma"], c["tail_ratio"]))
     assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
     # the audit ran in every sweep (voxels x heads), found no sign contradiction, and its error stayed inside the allowance
     # (half of the 65 536 picks per head are uniform, half come from the at-risk shell - as many as it holds)
@@ -169,7 +175,9 @@ def test_python_layer_refuses_on_the_audit_alone():
     N = 96
     lat = lambda s: torch.from_numpy(syn.latent_code(s)).cuda()
     hip.set_sample(lat(0))
-    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))      # calibrates the allowance
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1)))      # calibrates the allowance on the coarse lattice
+    _, _, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)      # ... and this on the zoom lattice
+    assert ticket["kind"] == "exact" and "compare" in ticket and not hip.fine_needs_repeat(ticket) and hip._fine_valid(N)
     honest = hip._box_tau
     hip.set_sample(lat(1))
     real_judge = hip._judge
@@ -183,11 +191,14 @@ def test_python_layer_refuses_on_the_audit_alone():
     hip._box_tau = honest / 32.0
     bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
     assert ticket["kind"] == "band" and hip.fine_needs_repeat(ticket)
-    assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * hip._tail > 0.6 * honest / 32.0
+    assert hip.band_stats["fallback"] == 1 and hip.band_stats["audit_max_err"] * max(hip._tail, hip._tail_fine) > 0.6 * honest / 32.0
+    assert not hip._fine_valid(N)
     bh, bo, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
-    assert ticket["kind"] == "exact" and not hip.fine_needs_repeat(ticket)
+    # the repeat is an ordinary sweep - and, the comparison of the zoom lattice being void, it measures it again on this very lattice
+    assert ticket["kind"] == "exact" and "compare" in ticket and not hip.fine_needs_repeat(ticket)
+    assert hip._fine_valid(N) and hip.certificate()["fine_calibrations"] == 2
     # a sweep refused for its error does not inflate the allowance by itself: the allowance is VOID until the next
-    # coarse pass has compared the whole lattice again
+    # coarse pass has compared the whole coarse lattice again
     assert not hip._allowance_valid() and hip.certificate()["refusals_for_error"] == 1
     _, _, ticket = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
     assert ticket["kind"] == "exact"
@@ -202,24 +213,31 @@ def test_python_layer_refuses_on_the_audit_alone():
 
 
 def test_whole_lattice_recalibration_is_periodic(monkeypatch):
-    """the tail ratio is re-measured every RECAL_EVERY coarse passes (here 5), not once per decoder - that pass
-    runs an ordinary sweep next to a plain one-plane one and compares all 2 N^3 values; its boxes are the ordinary sweep's."""
+    """the tail ratio is re-measured every RECAL_EVERY samples (here 5), not once per decoder, in
+    turn on the coarse lattice (that coarse pass runs an ordinary sweep next to a plain one-plane one and compares all 2 N^3 values;
+    its boxes are the ordinary sweep's) and on the ZOOM lattice (the fine pass does the same; its volumes are the ordinary sweep's)."""
     from alignsdf_amd import hip_decoder as hd
     monkeypatch.setattr(hd, "RECAL_EVERY", 5)
     hip = hd.HipSdfDecoder(syn.full_state_dict("nerf3"), 256, 3, "nerf")
     N = 64
-    kinds = []
+    kinds, fine_kinds = [], []
     for s in range(13):
         hip.set_sample(torch.from_numpy(syn.latent_code(s)).cuda())
         t = hip.coarse_begin(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
         kinds.append(t["kind"])
         hip.coarse_finish(t)
-    assert kinds == ["exact"] + ["box"] * 5 + ["exact"] + ["box"] * 5 + ["exact"]
+        _, _, f = hip.fine_begin(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1), mc_only=True)
+        fine_kinds.append(f["kind"] + ("+compare" if "compare" in f else ""))
+        assert not hip.fine_needs_repeat(f)
+    assert kinds == ["exact"] + ["box"] * 5 + ["exact"] + ["box"] * 6
+    assert fine_kinds == ["exact+compare"] + ["band"] * 11 + ["exact+compare"]
     cert = hip.certificate()
-    assert cert["calibrations"] == 3 and 1.0 <= cert["tail_ratio"] <= cert["tail_ratio_max"] <= 3.0
+    assert cert["calibrations"] == 2 and 1.0 <= cert["tail_ratio"] <= cert["tail_ratio_max"] <= 3.0
+    assert cert["fine_calibrations"] == 2 and 1.0 <= cert["fine_tail_ratio"] <= cert["fine_tail_ratio_max"] <= 3.0
     assert cert["lattice_max_over_sigma"] > 1.0 and 0.0 <= cert["neighbour_correlation"] < 1.0
-    assert hip.box_stats["fallback"] == 0
-    print("certificate after 3 whole-lattice comparisons:", cert)
+    assert cert["fine_max_over_sigma"] > 1.0 and cert["fine_lattice_max_error"] > 0.0 and 0.0 <= cert["fine_neighbour_correlation"] < 1.0
+    assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0 and hip.events["repeated_sweeps"] == 0
+    print("certificate after 2 + 2 whole-lattice comparisons:", cert)
     hip.close()
 
 

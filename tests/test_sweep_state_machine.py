@@ -108,7 +108,20 @@ def machine(monkeypatch):
         calls.append("recover")
         dec._recalibrations += 1
 
-    dec._calibrate_box, dec._recover = fake_calibrate, fake_recover
+    def fake_plain(args):                           # the plain one-plane sweep of a whole-lattice comparison
+        dec._L.log.append(("plain", dec.math))
+        return (None, None, None)
+
+    def fake_calibrate_fine(args, fast, exact, periodic=False):      # the same comparison on the zoom lattice of a fine pass
+        calls.append("calibrate_fine")
+        if periodic:
+            dec._coarse_since_cal, dec._next_recal = 0, "coarse"
+        dec._fine_epoch, dec._fine_cal_points = dec._recalibrations, int(args[0]) ** 3
+        dec._err_window.append(2e-4)
+        dec._box_tau = dec._tau_current()
+        dec.cert["fine_calibrations"] += 1
+
+    dec._calibrate_box, dec._recover, dec._plain_one_plane, dec._calibrate_fine = fake_calibrate, fake_recover, fake_plain, fake_calibrate_fine
     dec._status = lambda clear: np.zeros(16, dtype=np.int32)
     dec.close = lambda: None
     # first coarse pass: ordinary sweep + calibration
@@ -116,9 +129,22 @@ def machine(monkeypatch):
     assert t["kind"] == "exact"
     dec.coarse_finish(t)
     assert calls == ["calibrate"] and dec._allowance_valid(N) and dec._L.log == [("grid", "f16x3")]
+    # first fine pass: ordinary sweep + a plain one-plane sweep of the same ZOOM lattice, compared when the record is read
+    assert not dec._fine_valid(N)
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "exact" and "compare" in t and dec._L.log[1:] == [("grid", "f16x3"), ("plain", "f16x3")]
+    assert not dec.fine_needs_repeat(t) and calls == ["calibrate", "calibrate_fine"] and dec._fine_valid(N)
     dec._L.log.clear()
     calls.clear()
+    dec.band_stats["exact"] = 0
     return dec, calls
+
+
+def prime_fine(dec, calls):
+    """The fine pass that follows a voided allowance: ordinary + whole-lattice comparison of the zoom lattice."""
+    _, _, t = dec.fine_begin(*ARGS, mc_only=True)
+    assert t["kind"] == "exact" and "compare" in t and not dec.fine_needs_repeat(t)
+    assert calls[-1] == "calibrate_fine" and dec._fine_valid(N)
 
 
 def test_accepted_sweeps_stay_on_the_one_plane_kernel(machine):
@@ -198,14 +224,17 @@ def test_fine_pass_refusals(machine, reason, stale):
     _, _, t2 = dec.fine_begin(*ARGS, mc_only=True)                        # the repeat
     assert t2["kind"] == "exact"
     near = reason in ("near", "near_bit")           # (a property of the sample, honoured for a stale ticket too)
-    assert dec._L.log == [("grid", "f32" if near else "f16x3")], (reason, stale, dec._L.log)
+    for_error = reason != "listed" and REASONS[reason][1]
+    # a repeat whose zoom-lattice comparison is void (refused for its error, or a new scale epoch) measures it again on this very lattice
+    remeasured = (stale or reason == "range" or for_error) and not near
+    assert dec._L.log == [("grid", "f32" if near else "f16x3")] + ([("plain", "f16x3")] if remeasured else []), (reason, stale, dec._L.log)
     assert dec.math == "f16x3" and not dec._force_f32_once               # ... for that one sweep only
     assert not dec.fine_needs_repeat(t2)
-    for_error = reason != "listed" and REASONS[reason][1]
+    assert (calls[-1:] == ["calibrate_fine"]) == remeasured
     if stale:
-        assert dec._band_failures == 0 and calls == []
+        assert dec._band_failures == 0 and [c for c in calls if c != "calibrate_fine"] == []
     elif reason == "range":
-        assert calls == ["recover"] and dec._band_failures == 0
+        assert [c for c in calls if c != "calibrate_fine"] == ["recover"] and dec._band_failures == 0
     elif near:
         assert dec._band_failures == 0               # a capacity of the fp32 refinement, not a failure of the band sweep
     else:
@@ -214,8 +243,11 @@ def test_fine_pass_refusals(machine, reason, stale):
     dec._L.log.clear()
     _, _, t3 = dec.fine_begin(*ARGS, mc_only=True)
     if stale or reason == "range" or (for_error and not stale):
-        # no valid allowance (new scale epoch, or voided by the refusal): ordinary sweeps until a coarse pass has calibrated again
+        # no valid allowance (new scale epoch, or voided by the refusal): the zoom lattice was measured again by the repeat, but the
+        # passes stay ordinary until the coarse lattice has been compared as a whole again too - by the next coarse pass
         assert t3["kind"] == "exact" and not dec._allowance_valid(N)
+        assert (near and not dec._fine_valid(N)) or ("compare" not in t3 and dec._fine_valid(N))
+        assert not dec.fine_needs_repeat(t3)
         t = dec.coarse_begin(*ARGS)
         assert t["kind"] == "exact"
         dec.coarse_finish(t)
@@ -316,10 +348,56 @@ def test_periodic_recalibration_and_lattice_growth(machine, monkeypatch):
         t = dec.coarse_begin(*ARGS)
         kinds.append(t["kind"])
         dec.coarse_finish(t)
-    assert kinds == ["box", "box", "box", "exact", "box", "box", "box", "exact"] and calls == ["calibrate", "calibrate"]
+    # coarse passes only: the zoom lattice's turn (the second periodic comparison) is never taken by a fine pass, so the coarse
+    # lattice takes it once the comparison is a whole period overdue
+    assert kinds == ["box", "box", "box", "exact", "box", "box", "box", "box"] and calls == ["calibrate"] and dec._next_recal == "fine"
+    dec._L.script = [good_record(tau) for _ in range(3)]
+    kinds = []
+    for _ in range(3):
+        t = dec.coarse_begin(*ARGS)
+        kinds.append(t["kind"])
+        dec.coarse_finish(t)
+    assert kinds == ["box", "box", "exact"] and calls == ["calibrate", "calibrate"]
     # a lattice more than 8 x the calibrated one needs its own whole-lattice comparison
     big = (2 * N + 8,) + ARGS[1:]
     t = dec.coarse_begin(*big)
     assert t["kind"] == "exact"
     dec.coarse_finish(t)
     assert calls[-1] == "calibrate" and dec._allowance_valid(2 * N + 8) and dec._allowance_valid(N)
+
+
+def test_periodic_comparison_alternates_between_the_coarse_and_the_zoom_lattice(machine, monkeypatch):
+    """every RECAL_EVERY samples ONE whole-lattice comparison, in turn of the coarse lattice (the coarse pass
+    runs as an ordinary sweep + a plain one-plane sweep) and of the zoom lattice (the FINE pass does) - the lattice whose signs
+    marching cubes consumes (utils/mesh.py:82-121).  The sample's meshes come from ordinary sweeps in either case."""
+    dec, calls = machine
+    monkeypatch.setattr(hd, "RECAL_EVERY", 3)
+    tau = dec._box_tau
+    dec._L.script = [good_record(tau) for _ in range(40)]
+    seq = []
+    for _ in range(13):
+        t = dec.coarse_begin(*ARGS)
+        dec.coarse_finish(t)
+        _, _, f = dec.fine_begin(*ARGS, mc_only=True)
+        assert not dec.fine_needs_repeat(f)
+        seq.append((t["kind"], f["kind"] + ("+compare" if f.get("periodic") else "")))
+    normal = ("box", "band")
+    assert seq == [normal] * 3 + [("exact", "band")] + [normal] * 3 + [("box", "exact+compare")] + [normal] * 3 + [("exact", "band")] + [normal]
+    assert calls == ["calibrate", "calibrate_fine", "calibrate"]
+    assert dec.box_stats["fallback"] == 0 and dec.band_stats["fallback"] == 0 and dec.events["repeated_sweeps"] == 0
+
+
+def test_tail_ladder_covers_small_audits(machine):
+    """an audit below 64 picks per head (a uniform half below 32) used to find no ladder entry and fell back to the
+    stale scalar 1.0; the ladder now starts at 1 and a lattice below it takes its smallest entry."""
+    dec, calls = machine
+    dec._tail_by_n = {1 << k: 3.0 - 0.1 * k for k in range(0, 18)}
+    dec._tail = 1.0
+    dec.audit_voxels = 16                            # 8 uniform picks
+    assert abs(dec._tail_for(N ** 3) - (3.0 - 0.3)) < 1e-12
+    dec.audit_voxels = 1                             # one pick in all: the uniform half holds it
+    assert abs(dec._tail_for(N ** 3) - 3.0) < 1e-12
+    dec._tail_by_n = {32: 1.5, 64: 1.4}
+    dec.audit_voxels = 16
+    assert dec._tail_for(N ** 3) == 1.5              # below the ladder: its smallest entry
+    assert len(hd.HipSdfDecoder.LADDER) == 18 and hd.HipSdfDecoder.LADDER[0] == 1
