@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 123        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 124        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -28,6 +28,7 @@ EXPORTS = (
     "asdf_icp_ts_enqueue", "asdf_icp_ts_result", "asdf_chamfer",
     "asdf_decoder_set_math", "asdf_decoder_get_math", "asdf_debug_pack_host_f16",
     "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_decoder_set_short_list", "asdf_decoder_one_plane_usable", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
+    "asdf_zoom_cube", "asdf_decode_grid_band_dev", "asdf_decode_grid_dev", "asdf_mc_emit_bounded",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -86,6 +87,10 @@ def lib():
     L.asdf_decode_grid.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, vp, vp, vp, vp]
     L.asdf_decode_grid_box.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]
     L.asdf_decode_grid_band.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]
+    L.asdf_zoom_cube.argtypes = [vp, i32, f32, i32, i32, vp, vp]
+    L.asdf_decode_grid_band_dev.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp, vp]
+    L.asdf_decode_grid_dev.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp]
+    L.asdf_mc_emit_bounded.argtypes = [vp, i32, i32, i32, ctypes.c_double, vp, ctypes.c_size_t, vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp]
     L.asdf_decode_points.argtypes = [vp, vp, i64, vp, vp, vp]
     L.asdf_decoder_set_classifier.argtypes = [vp, vp, vp, i32]
     L.asdf_decode_points_cls.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]

@@ -745,7 +745,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 123; }
+int asdf_version(void) { return 124; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -1073,16 +1073,65 @@ static int launch_decode(asdf_decoder_t* d, DecodeParams& p, hipStream_t st) {
   return ASDF_OK;
 }
 
-int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
-                     float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream) {
-  if (!d || !origin || N < 2 || N > 1024) return ASDF_EINVAL;
+// (origin / voxel_size by value, or - lattice_dev non-null - {origin0, origin1, origin2, voxel} read by the kernels from device memory)
+static int decode_grid_impl(asdf_decoder_t* d, int32_t N, const float* origin, float voxel_size, const float* lattice_dev, int32_t grid_mode,
+                            float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream) {
+  if (!d || (!origin && !lattice_dev) || N < 2 || N > 1024) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
   DecodeParams p;
   std::memset(&p, 0, sizeof(p));
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = bbox_dev;
   p.P = (long long)N * N * N; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
-  p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
+  if (lattice_dev) p.lattice = lattice_dev;
+  else { p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2]; }
   return launch_decode(d, p, (hipStream_t)stream);
+}
+
+int asdf_decode_grid(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode,
+                     float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream) {
+  if (!origin) return ASDF_EINVAL;
+  return decode_grid_impl(d, N, origin, voxel_size, nullptr, grid_mode, sdf_hand_dev, sdf_obj_dev, bbox_dev, stream);
+}
+
+int asdf_decode_grid_dev(asdf_decoder_t* d, int32_t N, const float* lattice_dev, int32_t grid_mode,
+                         float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream) {
+  if (!lattice_dev) return ASDF_EINVAL;
+  return decode_grid_impl(d, N, nullptr, 0.0f, lattice_dev, grid_mode, sdf_hand_dev, sdf_obj_dev, bbox_dev, stream);
+}
+
+// get_higher_res_cube's arithmetic (utils/mesh.py:239-254) on the boxes of a coarse pass' record, in fp32 like the reference's CPU
+// tensors: min / max over the enabled branches (an empty branch contributes zeros, :209-211, :225-227), every operation rounded
+// separately (the file is built with -ffp-contract=off; the _rn intrinsics say so again).
+__global__ void zoom_cube_kernel(const int* __restrict__ bbox, int N, float vs, int use_hand, int use_obj, float* __restrict__ lattice) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lo[3], hi[3];
+  bool first = true;
+  for (int h = 0; h < 2; ++h) {
+    if (!(h == 0 ? use_hand : use_obj)) continue;
+    const int* b = bbox + 8 * h;
+    const bool any = b[6] != 0;
+    for (int a = 0; a < 3; ++a) {
+      const float l = any ? (float)b[a] : 0.0f, u = any ? (float)b[3 + a] : 0.0f;
+      lo[a] = first ? l : fminf(lo[a], l);
+      hi[a] = first ? u : fmaxf(hi[a], u);
+    }
+    first = false;
+  }
+  if (first) { for (int a = 0; a < 3; ++a) lo[a] = hi[a] = 0.0f; }
+  float span = __fsub_rn(hi[0], lo[0]);
+  span = fmaxf(span, __fsub_rn(hi[1], lo[1]));
+  span = fmaxf(span, __fsub_rn(hi[2], lo[2]));
+  const float cube = __fmul_rn(__fadd_rn(span, 4.0f), vs);
+  lattice[3] = __fdiv_rn(cube, (float)(N - 1));
+  for (int a = 0; a < 3; ++a) lattice[a] = __fsub_rn(__fmul_rn(__fsub_rn(lo[a], 2.0f), vs), 1.0f);
+}
+
+int asdf_zoom_cube(const int32_t* bbox_dev, int32_t N, float voxel_size, int32_t hand_branch, int32_t obj_branch, float* lattice_dev,
+                   void* stream) {
+  if (!bbox_dev || !lattice_dev || N < 2 || (!hand_branch && !obj_branch)) return ASDF_EINVAL;
+  hipLaunchKernelGGL(zoom_cube_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bbox_dev, N, voxel_size, hand_branch, obj_branch, lattice_dev);
+  ASDF_HIP(hipGetLastError());
+  return ASDF_OK;
 }
 
 // the audit of a one-plane sweep: min(d->audit_n, P / 16) voxels the sweep decided by sign alone are appended to list[*count ..] -
@@ -1216,9 +1265,9 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   return ASDF_OK;
 }
 
-int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
-                          float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
-  if (!d || !origin || !rec_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
+static int decode_grid_band_impl(asdf_decoder_t* d, int32_t N, const float* origin, float voxel_size, const float* lattice_dev,
+                                 int32_t grid_mode, float tau, float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
+  if (!d || (!origin && !lattice_dev) || !rec_dev || N < 2 || N > 1024 || !(tau > 0.0f) || !(tau < 0.5f)) return ASDF_EINVAL;
   if (grid_mode != ASDF_GRID_REFERENCE && grid_mode != ASDF_GRID_INTEGER) return ASDF_EINVAL;
   if (!d->stream16_hi || !d->sample_bound || !d->p1_usable) return ASDF_EINVAL;
   const bool two_out = d->spec.num_heads == 1;       // CombinedDecoder: one MLP, both columns from every evaluation
@@ -1239,7 +1288,8 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   std::memset(&p, 0, sizeof(p));
   p.sdf0 = sdf_hand_dev; p.sdf1 = sdf_obj_dev; p.bbox = rec_dev;      // (the box words are by-products; 7 / 15 carry the range report)
   p.P = P; p.N = N; p.mode = grid_mode == ASDF_GRID_REFERENCE ? kGridReference : kGridInteger;
-  p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2];
+  if (lattice_dev) p.lattice = lattice_dev;        // (every subset launch below copies p: the listed voxels get the same lattice)
+  else { p.vs = voxel_size; p.o0 = origin[0]; p.o1 = origin[1]; p.o2 = origin[2]; }
   p.stream = d->stream16_hi; p.cst = d->cst16p1; p.a16 = d->a16; p.status = d->status;
   p.first_mlp = 0; p.num_mlps = d->spec.num_heads; p.pf = d->spec.point_feats[0];
   if (!two_out) {
@@ -1304,6 +1354,18 @@ int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], f
   hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, rec_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
+}
+
+int asdf_decode_grid_band(asdf_decoder_t* d, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
+                          float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
+  if (!origin) return ASDF_EINVAL;
+  return decode_grid_band_impl(d, N, origin, voxel_size, nullptr, grid_mode, tau, sdf_hand_dev, sdf_obj_dev, rec_dev, stream);
+}
+
+int asdf_decode_grid_band_dev(asdf_decoder_t* d, int32_t N, const float* lattice_dev, int32_t grid_mode, float tau,
+                              float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream) {
+  if (!lattice_dev) return ASDF_EINVAL;
+  return decode_grid_band_impl(d, N, nullptr, 0.0f, lattice_dev, grid_mode, tau, sdf_hand_dev, sdf_obj_dev, rec_dev, stream);
 }
 
 int asdf_decoder_one_plane_usable(const asdf_decoder_t* d) { return d && d->stream16_hi && d->p1_usable ? 1 : 0; }

@@ -440,7 +440,7 @@ __device__ __forceinline__ size_t vid_slot(const McDims& d, int e, int x, int y,
 __global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __restrict__ vol, McDims d, double level,
                                                               const unsigned* __restrict__ compact, const uint2* __restrict__ block_tot,
                                                               const uint2* __restrict__ block_seg, const uint2* __restrict__ super_base,
-                                                              unsigned* __restrict__ vid, float* __restrict__ verts) {
+                                                              unsigned* __restrict__ vid, float* __restrict__ verts, unsigned cap_verts) {
   if (block_tot[blockIdx.x].y == 0) return;             // no vertex is owned by this block's 1024 cell slots
   const uint2 seg = block_seg[blockIdx.x];
   unsigned carry = block_first_ids(d, blockIdx.x, super_base, block_tot).y;
@@ -482,10 +482,12 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __res
         fx += (double)((0x66 >> a) & 1) * wa; fy += (double)((0xCC >> a) & 1) * wa; fz += (double)((0xF0 >> a) & 1) * wa; ff += wa;
         fx += (double)((0x66 >> b) & 1) * wb; fy += (double)((0xCC >> b) & 1) * wb; fz += (double)((0xF0 >> b) & 1) * wb; ff += wb;
       }
-      float* o = verts + 3 * (size_t)id;
-      o[0] = (float)((double)z + fz / ff);      // (axis0, axis1, axis2) = (z, y, x)
-      o[1] = (float)((double)y + fy / ff);
-      o[2] = (float)((double)x + fx / ff);
+      if (id < cap_verts) {                     // (asdf_mc_emit_bounded: a buffer sized before the count was known)
+        float* o = verts + 3 * (size_t)id;
+        o[0] = (float)((double)z + fz / ff);      // (axis0, axis1, axis2) = (z, y, x)
+        o[1] = (float)((double)y + fy / ff);
+        o[2] = (float)((double)x + fx / ff);
+      }
       vid[vid_slot(d, e, x, y, z)] = id;
       ++id;
      }
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_verts(const float* __res
 __global__ __launch_bounds__(kEmitThreads) void mc_emit_faces(McDims d, const unsigned* __restrict__ compact,
                                                               const uint2* __restrict__ block_tot, const uint2* __restrict__ block_seg,
                                                               const uint2* __restrict__ super_base, const unsigned* __restrict__ vid,
-                                                              int* __restrict__ faces) {
+                                                              int* __restrict__ faces, unsigned cap_faces) {
   const uint2 seg = block_seg[blockIdx.x];
   if (seg.y == 0) return;                               // no active cell in this block's 1024 cell slots
   unsigned carry = block_first_ids(d, blockIdx.x, super_base, block_tot).x;
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(kEmitThreads) void mc_emit_faces(McDims d, const un
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (4 * g + t >= nt) break;
+        if (tri0 + 4 * g + t >= cap_faces) break;
         int* f = faces + 3 * (size_t)(tri0 + 4 * g + t);
         // 'descent' orientation: the routine reverses every face
         f[2] = (int)ids[3 * t + 0];
@@ -625,6 +628,11 @@ int asdf_mc_count(const float* vol, int32_t n0, int32_t n1, int32_t n2, double l
 
 int asdf_mc_emit(const float* vol, int32_t n0, int32_t n1, int32_t n2, double level, void* ws, size_t ws_bytes,
                  float* verts, int32_t* faces, void* stream) {
+  return asdf_mc_emit_bounded(vol, n0, n1, n2, level, ws, ws_bytes, verts, 0xffffffffu, faces, 0xffffffffu, stream);
+}
+
+int asdf_mc_emit_bounded(const float* vol, int32_t n0, int32_t n1, int32_t n2, double level, void* ws, size_t ws_bytes,
+                         float* verts, uint32_t cap_verts, int32_t* faces, uint32_t cap_faces, void* stream) {
   McLayout L;
   if (!vol || !ws || !verts || !faces || !mc_layout(n0, n1, n2, L)) return ASDF_EINVAL;
   if (ws_bytes < L.total) return ASDF_ENOSPC;
@@ -635,8 +643,8 @@ int asdf_mc_emit(const float* vol, int32_t n0, int32_t n1, int32_t n2, double le
   const uint2* seg = (const uint2*)(w + L.off_seg);
   const uint2* sbase = (const uint2*)(w + L.off_sbase);
   unsigned* vid = (unsigned*)(w + L.off_vid);
-  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, vol, L.d, level, compact, tot, seg, sbase, vid, verts);
-  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, L.d, compact, tot, seg, sbase, vid, faces);
+  hipLaunchKernelGGL(mc_emit_verts, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, vol, L.d, level, compact, tot, seg, sbase, vid, verts, cap_verts);
+  hipLaunchKernelGGL(mc_emit_faces, dim3(L.d.nblocks), dim3(kEmitThreads), 0, st, L.d, compact, tot, seg, sbase, vid, faces, cap_faces);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
 }

@@ -80,6 +80,8 @@ struct DecodeParams {
   int mode;
   float vs;                 // voxel size (fp32, as the reference rounds it)
   float o0, o1, o2;         // origin added to axis-0/1/2 coordinates
+  const float* lattice;     // when non-null: {origin0, origin1, origin2, voxel size} in DEVICE memory replace o0 .. o2 / vs - the zoom
+                            // cube of a fine pass that is enqueued right behind its coarse pass (asdf_zoom_cube writes it; round 5)
   int num_mlps;             // MLPs to evaluate: 2 = both heads of a SeparateDecoder, 1 = one head or a CombinedDecoder
   int first_mlp;            // index of the first MLP to evaluate (1 = object head only)
   int pf;                   // raw point-feature count (NeRF-feature kernels only)

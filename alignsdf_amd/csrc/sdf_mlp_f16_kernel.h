@@ -84,6 +84,16 @@ __device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8&
   dst = __builtin_bit_cast(h8, d);
 }
 
+// wave64 maximum of a signed int on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, row_bcast:15 / :31 across them);
+// the result as a wave-uniform value (lane 63 holds it)
+__device__ __forceinline__ int wave_max_i32(int v) {
+#define ASDF16_DPP_MAX(ctrl, rows) v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, (ctrl), (rows), 0xf, false))
+  ASDF16_DPP_MAX(0x111, 0xf); ASDF16_DPP_MAX(0x112, 0xf); ASDF16_DPP_MAX(0x114, 0xf); ASDF16_DPP_MAX(0x118, 0xf);
+  ASDF16_DPP_MAX(0x142, 0xa); ASDF16_DPP_MAX(0x143, 0xc);
+#undef ASDF16_DPP_MAX
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 
 // schedule knobs (tools/k1h_ablate.hip sweeps them; the values here are the shipped ones)
@@ -452,6 +462,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   const int half = lane >> 5;
 
   static_assert(!SUB || G == 1, "subset mode: one point group");
+  // the lattice: by value, or - a fine pass enqueued behind its coarse pass - from the device words asdf_zoom_cube wrote
+  float lat_vs = p.vs, lat_o0 = p.o0, lat_o1 = p.o1, lat_o2 = p.o2;
+  if (p.lattice) { lat_o0 = p.lattice[0]; lat_o1 = p.lattice[1]; lat_o2 = p.lattice[2]; lat_vs = p.lattice[3]; }
   long long npts = p.P;
   if (SUB) { const long long c = *p.count_dev; npts = c < npts ? c : npts; }
   const long long ntiles = (npts + kTilePts - 1) / kTilePts;
@@ -523,11 +536,11 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       const long long po = SUB ? (valid ? (long long)p.idx[pi] : 0) : pi;      // where the point lives in the lattice / the outputs
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
       if (SUB) {
-        grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+        grid_point(po, p.N, p.grid_mode, lat_vs, lat_o0, lat_o1, lat_o2, x0, x1, x2);
       } else if (p.mode == kPointList) {
         if (valid) { x0 = p.xyz[pi * 3 + 0]; x1 = p.xyz[pi * 3 + 1]; x2 = p.xyz[pi * 3 + 2]; }
       } else {
-        grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+        grid_point(valid ? pi : 0, p.N, p.mode, lat_vs, lat_o0, lat_o1, lat_o2, x0, x1, x2);
       }
       // second point group (G == 2): the next 32 points
       const long long pib = pi + kWavePts;
@@ -540,7 +553,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         if (p.mode == kPointList) {
           if (validb) { y0 = p.xyz[pib * 3 + 0]; y1 = p.xyz[pib * 3 + 1]; y2 = p.xyz[pib * 3 + 2]; }
         } else {
-          grid_point(validb ? pib : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, y0, y1, y2);
+          grid_point(validb ? pib : 0, p.N, p.mode, lat_vs, lat_o0, lat_o1, lat_o2, y0, y1, y2);
         }
         if (KP == 2) {
           bpb[0] = half ? y1 : y0;
@@ -1014,10 +1027,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       auto out_ok = [&](float v, float pre_v) { return kStrict ? fabsf(pre_v) < INFINITY : fabsf(v) <= 1.0f; };
       const int bad = ((valid || validb) && (act_over || !out_ok(sdf, pre) || (TWO_OUT && !out_ok(sdfb, preb)) ||
                                             (G == 2 && !out_ok(sdfg, preg)))) ? 1 : 0;
-      if (!kStrict && (valid || validb) && p.status) {          // non-negative floats order like their bit patterns; a NaN is a huge pattern and reads as overflow
-        atomicMax(wrec + 16, __float_as_int(amax));
-        atomicMax(wrec + 17, __float_as_int(amax1));
-        atomicMax(wrec + 18, __float_as_int(amax2));
+      if (!kStrict && p.status) {
+        // per-wave peaks of the three activation vectors: non-negative floats order like their bit patterns, a NaN is a huge
+        // pattern and reads as overflow.  One DPP reduction per value and a plain read-modify-write by one lane (the record is the
+        // wave's own).  Round 5: this was three LDS atomicMax by all 64 lanes on ONE word each - 14 k clocks per tile, a tenth of
+        // the kernel, and only in the product (the timing tool passed no status record: tools/k1h_ablate.hip K1H_STATUS=1).
+        const bool v_ = valid || validb;
+        const int m0 = wave_max_i32(v_ ? __float_as_int(amax) : 0), m1 = wave_max_i32(v_ ? __float_as_int(amax1) : 0),
+                  m2 = wave_max_i32(v_ ? __float_as_int(amax2) : 0);
+        if (lane == 0) { wrec[16] = max(wrec[16], m0); wrec[17] = max(wrec[17], m1); wrec[18] = max(wrec[18], m2); }
       }
       if (!SUB && p.bbox && p.mode != kPointList) {
         // with two point groups every lane folds ITS point: lanes 0..31 the first group's, lanes 32..63 the second's

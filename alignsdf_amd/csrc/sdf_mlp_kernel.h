@@ -96,6 +96,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
 
+  // the lattice: by value, or - a fine pass enqueued behind its coarse pass - from the device words asdf_zoom_cube wrote
+  float lat_vs = p.vs, lat_o0 = p.o0, lat_o1 = p.o1, lat_o2 = p.o2;
+  if (p.lattice) { lat_o0 = p.lattice[0]; lat_o1 = p.lattice[1]; lat_o2 = p.lattice[2]; lat_vs = p.lattice[3]; }
   // kGridSubset: the point count lives on the device (the list was compacted by a kernel just in front of this launch)
   long long npts = p.P;
   if (p.mode == kGridSubset) {
@@ -154,9 +157,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
       } else if (p.mode == kGridSubset) {
         // listed lattice points: the same coordinate function as the sweep, outputs scattered back into the volumes
         po = valid ? (long long)p.idx[pi] : 0;
-        grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+        grid_point(po, p.N, p.grid_mode, lat_vs, lat_o0, lat_o1, lat_o2, x0, x1, x2);
       } else {
-        grid_point(valid ? pi : 0, p.N, p.mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+        grid_point(valid ? pi : 0, p.N, p.mode, lat_vs, lat_o0, lat_o1, lat_o2, x0, x1, x2);
       }
       // B operands of the point-feature K-steps: lane half h supplies feature 2 s + h of K-step s
       float bp[KP];

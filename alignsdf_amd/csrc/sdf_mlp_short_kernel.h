@@ -84,7 +84,9 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p) {
   const bool valid = pi < npts;
   const long long po = valid ? (long long)p.idx[pi] : 0;
   float x0, x1, x2;
-  grid_point(po, p.N, p.grid_mode, p.vs, p.o0, p.o1, p.o2, x0, x1, x2);
+  float lat_vs = p.vs, lat_o0 = p.o0, lat_o1 = p.o1, lat_o2 = p.o2;          // (the lattice by value, or from the words asdf_zoom_cube wrote)
+  if (p.lattice) { lat_o0 = p.lattice[0]; lat_o1 = p.lattice[1]; lat_o2 = p.lattice[2]; lat_vs = p.lattice[3]; }
+  grid_point(po, p.N, p.grid_mode, lat_vs, lat_o0, lat_o1, lat_o2, x0, x1, x2);
   const float bp0 = half ? x1 : x0, bp1 = half ? 0.0f : x2;
 
   // ---- layer 0: tiles 4 wave .. 4 wave + 3

@@ -359,6 +359,8 @@ class HipSdfDecoder:
             import logging
             logging.warning("split-half decoder: %d activations left the fp16 range; falling back to the fp32 MFMA kernel", bad)
             self.set_math("f32")
+            self.events["fp32_fallback"] = True
+            self.events["modes_switched_off"].append("arithmetic: %d activations outside the fp16 range after %d re-calibrations - fp32 chain" % (bad, self._recalibrations))
 
     def _status(self, clear):
         out = (ctypes.c_int32 * 16)()
@@ -553,13 +555,14 @@ class HipSdfDecoder:
     def _tau_current(self):
         return float(np.clip(TAU_FACTOR * max(self._err_window), 1e-6, 0.05)) if self._err_window else None
 
-    def _one_plane_launch(self, fn, name, N, origin3, voxel_size, grid_mode, hand, obj, tau):
+    def _one_plane_launch(self, fn, name, N, origin3, voxel_size, grid_mode, hand, obj, tau, lattice=None):
+        """`lattice` (device float32[4]): the _dev form of the entry point - origin and voxel size are read on the device."""
         if self.combined:
             hand = obj = True
         sh = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
         so = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
         rec = torch.empty(REC_WORDS, dtype=torch.int32, device=self.device)
-        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
+        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3]) if lattice is None else None
         with torch.cuda.device(self.device):
             ev = None
             if self.box_event_log is not None:
@@ -568,9 +571,14 @@ class HipSdfDecoder:
                 ev[1].record()
                 _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
                                                                    ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
-            _native.check(fn(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
-                             ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
-                             so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()), name)
+            if lattice is not None:
+                _native.check(fn(self._h, int(N), lattice.data_ptr(), int(grid_mode), ctypes.c_float(float(tau)),
+                                 sh.data_ptr() if sh is not None else None, so.data_ptr() if so is not None else None, rec.data_ptr(),
+                                 self._stream()), name)
+            else:
+                _native.check(fn(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))), int(grid_mode),
+                                 ctypes.c_float(float(tau)), sh.data_ptr() if sh is not None else None,
+                                 so.data_ptr() if so is not None else None, rec.data_ptr(), self._stream()), name)
             if ev is not None:
                 self.box_event_log.append(ev + (rec,))      # (words 28..31 of the record: shader-clock stamps of the sweep kernel)
         return rec, sh, so
@@ -728,38 +736,51 @@ class HipSdfDecoder:
         return {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations, "recalibrate": due,
                 "host": self._record_to_host(bbox)}
 
-    def coarse_finish(self, ticket):
+    def coarse_judge(self, ticket):
+        """Verdict on a box-only coarse sweep WITHOUT launching anything: (accepted, int32[16] record or None, calibrate_allowance).
+        Waits for the sweep's record (and for nothing queued behind it).  A refusal is booked here - counters, failure streak, new
+        activation scales after a range violation - so that the caller only has to repeat the pass as an ordinary sweep
+        (coarse_finish(ticket, judged=...)) while the decoder is bound to the ticket's sample."""
+        import logging
+        N = ticket["args"][0]
+        r = self._record_of(ticket)
+        if ticket["epoch"] != self._recalibrations:
+            ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
+        else:
+            ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP, points=int(N) ** 3)
+        if ok:
+            self.box_stats["box"] += 1
+            self._box_failures = 0              # (three refusals IN A ROW switch the mode off)
+            return True, r[:16].copy(), False
+        calibrate_allowance = True
+        self.box_stats["fallback"] += 1
+        self.events["repeated_sweeps"] += 1
+        if bad:
+            self._recover(bad)                  # new activation scales: the allowance is re-calibrated with them
+        else:
+            logging.warning("box-only coarse sweep not accepted (%s): repeated as an ordinary sweep", reason)
+            if ticket["epoch"] == self._recalibrations:
+                self._box_failures += 1
+                # refused for its error: the allowance is void (_judge) and is measured again by the repeat, on this very lattice;
+                # refused for a capacity / list overflow: the allowance stands
+                calibrate_allowance = not self._allowance_valid(N)
+            if self._box_failures >= 3:
+                logging.warning("box-only coarse sweep switched off for this decoder")
+                self.coarse_mode = "exact"
+                self.events["modes_switched_off"].append("coarse: three refusals in a row (%s)" % reason)
+        return False, None, calibrate_allowance
+
+    def coarse_finish(self, ticket, judged=None):
         """int32[16] host record of the coarse pass (words 0..5 / 8..13: boxes of the negative voxels; 6 / 14: non-zero
         iff there is one).  Synchronises with the sweep; a sweep whose guards fired is repeated here - the decoder must
-        still be bound to the ticket's sample."""
-        import logging
+        still be bound to the ticket's sample.  `judged` = the result of an earlier coarse_judge(ticket) (the sample pipeline judges
+        a speculative coarse pass first and re-binds the sample only when it has to be repeated)."""
         N, origin3, voxel_size, grid_mode, hand, obj = ticket["args"]
         calibrate_allowance = True
         if ticket["kind"] == "box":
-            r = self._record_of(ticket)
-            if ticket["epoch"] != self._recalibrations:
-                ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
-            else:
-                ok, bad, _, reason = self._judge(r, ticket["tau"], self.box_stats, (32,), CAND_CAP, points=int(N) ** 3)
+            ok, b, calibrate_allowance = judged if judged is not None else self.coarse_judge(ticket)
             if ok:
-                self.box_stats["box"] += 1
-                self._box_failures = 0              # (three refusals IN A ROW switch the mode off)
-                return r[:16].copy()
-            self.box_stats["fallback"] += 1
-            self.events["repeated_sweeps"] += 1
-            if bad:
-                self._recover(bad)                  # new activation scales: the allowance is re-calibrated with them
-            else:
-                logging.warning("box-only coarse sweep not accepted (%s): repeated as an ordinary sweep", reason)
-                if ticket["epoch"] == self._recalibrations:
-                    self._box_failures += 1
-                    # refused for its error: the allowance is void (_judge) and is measured again below, on this very lattice;
-                    # refused for a capacity / list overflow: the allowance stands
-                    calibrate_allowance = not self._allowance_valid(N)
-                if self._box_failures >= 3:
-                    logging.warning("box-only coarse sweep switched off for this decoder")
-                    self.coarse_mode = "exact"
-                    self.events["modes_switched_off"].append("coarse: three refusals in a row (%s)" % reason)
+                return b
             h, o, bbox = self.decode_grid(N, origin3, voxel_size, grid_mode, hand=hand, obj=obj)
             ticket = {"kind": "exact", "args": ticket["args"], "rec": bbox, "keep": (h, o), "epoch": self._recalibrations}
         b = self._record_of(ticket)
@@ -779,6 +800,49 @@ class HipSdfDecoder:
         b[7] &= NEAR_OVERFLOW_BIT - 1
         b[15] &= NEAR_OVERFLOW_BIT - 1
         return b
+
+    # ---- both passes of a sample ENQUEUED in one go (round 5): the box-only coarse sweep, the zoom cube computed on
+    # the device from its boxes (asdf_zoom_cube: the six fp32 operations of utils/mesh.py:250-254, bit-equal to the host's), and the
+    # narrow-band fine sweep reading its lattice from those device words.  The host judges both records afterwards; a refused coarse
+    # sweep makes the caller repeat the sample step by step (coarse_finish(ticket, judged) -> host zoom cube -> fine_begin).
+    def can_speculate(self, N):
+        """Both passes may be enqueued back to back: both one-plane modes on and usable, both whole-lattice comparisons valid for this
+        lattice size, no comparison due, nothing that forces the next sweep onto another path."""
+        return (self._box_usable() and self._band_usable() and self._allowance_valid(N) and self._fine_valid(N) and
+                not self._force_f32_once and not self._band_skip and self._coarse_since_cal + 1 <= RECAL_EVERY)
+
+    def two_pass_begin(self, N, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
+        """Enqueue coarse pass -> device zoom cube -> fine pass (mc_only) of the bound sample.  Returns None when the sample has to go
+        step by step (can_speculate), else a ticket: `coarse` / `fine` (tickets for coarse_judge / fine_needs_repeat), `lattice` (device
+        float32[4]: origin, voxel size), `lattice_host` (pinned copy + event), `vol_hand` / `vol_obj` (the fine volumes)."""
+        if not self.can_speculate(N):
+            return None
+        if self.combined:
+            hand = obj = True
+        self._coarse_since_cal += 1
+        tau = self._box_tau
+        org = [-1.0, -1.0, -1.0]
+        args = (N, org, voxel_size, grid_mode, hand, obj)
+        rec, sh, so = self._box_launch(*args, tau)
+        coarse = {"kind": "box", "args": args, "rec": rec, "keep": (sh, so), "tau": tau, "epoch": self._recalibrations,
+                  "host": self._record_to_host(rec)}
+        lattice = torch.empty(4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._L.asdf_zoom_cube(rec.data_ptr(), int(N), ctypes.c_float(float(np.float32(voxel_size))), int(bool(hand)),
+                                                 int(bool(obj)), lattice.data_ptr(), self._stream()), "asdf_zoom_cube")
+        rec2, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band_dev, "asdf_decode_grid_band_dev", N, None, None, grid_mode,
+                                              hand, obj, tau, lattice=lattice)
+        fine = {"kind": "band", "args": (N, None, None, grid_mode, hand, obj), "rec": rec2, "tau": tau, "epoch": self._recalibrations,
+                "host": self._record_to_host(rec2)}
+        return {"coarse": coarse, "fine": fine, "lattice": lattice, "lattice_host": self._record_to_host(lattice.view(torch.int32)),
+                "vol_hand": vh, "vol_obj": vo}
+
+    @classmethod
+    def lattice_of(cls, ticket):
+        """(origin [3 python floats], voxel size as a 0-dim fp32 CPU tensor) of a two_pass_begin ticket - what
+        utils.mesh.zoom_cube_from_bboxes returns for the same boxes, bit for bit."""
+        w = cls._record_of({"host": ticket["lattice_host"]}).view(np.float32)
+        return [float(w[0]), float(w[1]), float(w[2])], torch.tensor(w[3], dtype=torch.float32)
 
     # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else
     def _band_usable(self):
@@ -965,6 +1029,50 @@ class HipSdfDecoder:
         out.update(tau_factor=TAU_FACTOR, tau_accept=TAU_ACCEPT, recalibrate_every=RECAL_EVERY, tail_max=TAIL_MAX,
                    allowance_now=self._box_tau, audit_voxels=self.audit_voxels)
         return out
+
+    # ---- what a run's sweeps did, for the `sweeps.json` a reconstruction writes next to its meshes (a refused
+    # or switched-off mode must be visible after the fact, not only in a log line)
+    _ADDITIVE_CERT = ("calibrations", "fine_calibrations", "audited_sweeps", "shell_picks", "uniform_picks", "refusals_for_error")
+
+    def sweep_snapshot(self):
+        """Counters of this decoder's sweeps now; hand it to sweep_report() for what happened since."""
+        return {"box": dict(self.box_stats), "band": dict(self.band_stats), "repeated": self.events["repeated_sweeps"],
+                "switched": len(self.events["modes_switched_off"]), "cert": {k: self.cert[k] for k in self._ADDITIVE_CERT},
+                "math": self.math, "modes": (self.coarse_mode, self.fine_mode)}
+
+    def sweep_report(self, since=None):
+        """Which sweeps produced the volumes behind a run's meshes: one-plane / ordinary / refused-and-repeated counts per pass,
+        audits, whole-lattice comparisons, the margins of the statistical certificate, and every mode switch."""
+        z = since or {"box": self._new_stats("box"), "band": self._new_stats("band"), "repeated": 0, "switched": 0,
+                      "cert": {k: 0 for k in self._ADDITIVE_CERT}, "math": self.math, "modes": (self.coarse_mode, self.fine_mode)}
+        d = lambda now, then, k: int(now[k]) - int(then[k])
+        c = self.cert
+        return {
+            "evaluator": "hip kernels (libalignsdf_hip.so)",
+            "arithmetic": {"at_start": z["math"], "now": self.math,
+                           "fell_back_to_fp32_chain": z["math"] == "f16x3" and self.math == "f32"},
+            "coarse_pass": {"mode_at_start": z["modes"][0], "mode_now": self.coarse_mode,
+                            "one_plane_box_sweeps_accepted": d(self.box_stats, z["box"], "box"),
+                            "ordinary_sweeps": d(self.box_stats, z["box"], "exact"), "refused_and_repeated": d(self.box_stats, z["box"], "fallback"),
+                            "audit_evaluations": d(self.box_stats, z["box"], "audit_evals"), "audit_sign_flips": d(self.box_stats, z["box"], "audit_flips")},
+            "fine_pass": {"mode_at_start": z["modes"][1], "mode_now": self.fine_mode,
+                          "one_plane_band_sweeps_accepted": d(self.band_stats, z["band"], "band"),
+                          "ordinary_sweeps": d(self.band_stats, z["band"], "exact"), "refused_and_repeated": d(self.band_stats, z["band"], "fallback"),
+                          "audit_evaluations": d(self.band_stats, z["band"], "audit_evals"), "audit_sign_flips": d(self.band_stats, z["band"], "audit_flips")},
+            "sweeps_audited": c["audited_sweeps"] - z["cert"]["audited_sweeps"],
+            "sweeps_refused": d(self.box_stats, z["box"], "fallback") + d(self.band_stats, z["band"], "fallback"),
+            "sweeps_repeated": self.events["repeated_sweeps"] - z["repeated"],
+            "refusals_for_error": c["refusals_for_error"] - z["cert"]["refusals_for_error"],
+            "whole_lattice_comparisons": {"coarse_lattice": c["calibrations"] - z["cert"]["calibrations"],
+                                          "zoom_lattice": c["fine_calibrations"] - z["cert"]["fine_calibrations"]},
+            "modes_switched_off": list(self.events["modes_switched_off"][z["switched"]:]),
+            # margins of the certificate over this decoder's lifetime (minima / maxima, not per run)
+            "min_tau_over_sigma": c["min_tau_over_sigma"], "min_tau_over_estimate": c["min_margin_tau_over_estimate"],
+            "tail_ratio_max": {"coarse_lattice": c["tail_ratio_max"], "zoom_lattice": c["fine_tail_ratio_max"]},
+            "lattice_max_error": {"coarse_lattice": c["lattice_max_error"], "zoom_lattice": c["fine_lattice_max_error"]},
+            "allowance_now": self._box_tau, "audit_voxels_per_sweep_and_head": self.audit_voxels,
+            "rule": {"tau_factor": TAU_FACTOR, "tau_accept": TAU_ACCEPT, "recalibrate_every": RECAL_EVERY, "tail_max": TAIL_MAX},
+        }
 
     def decode_points(self, xyz):
         """Both heads on explicit normalised points [M,3]. Returns (hand [M], obj [M]) device tensors."""

@@ -12,6 +12,8 @@ from . import _native
 
 _workspaces = {}
 _SLOTS = 2           # volumes whose count phase may be in flight at once (hand + object of one sample)
+_results = []        # ring of pinned result records (V, F, min key, max key): one per ticket, so that a count phase enqueued for
+_result_turn = 0     # the NEXT sample cannot overwrite sizes the host has not read yet (round 5: whole samples are enqueued ahead)
 
 
 def _workspace(shape, device, slot=0):
@@ -23,15 +25,28 @@ def _workspace(shape, device, slot=0):
                       "asdf_mc_workspace_bytes")
         for k in [k for k in _workspaces if k[:2] != key[:2]]:      # keep the workspaces of one shape alive (~340 MB each at 256^3)
             del _workspaces[k]
-        ws = (torch.empty(nbytes.value, dtype=torch.uint8, device=device), torch.zeros(4, dtype=torch.int32).pin_memory())
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
 
-def marching_cubes_begin(volume, level=0.0, slot=0):
+def _result_record():
+    global _result_turn
+    if not _results:
+        _results.extend(torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(16))
+    r = _results[_result_turn % len(_results)]
+    _result_turn += 1
+    return r
+
+
+def marching_cubes_begin(volume, level=0.0, slot=0, capacity=None):
     """Enqueue the count phase (classify + reduce) of one volume WITHOUT synchronising: the sizes land in pinned host memory
     behind an event.  Returns a ticket for marching_cubes_finish; `slot` (0 / 1) picks the workspace, so that the hand and
-    the object volume of a sample can both be in flight."""
+    the object volume of a sample can both be in flight.
+
+    capacity = (max vertices, max faces): the EMIT phase is enqueued right behind the count phase into buffers of that size
+    (asdf_mc_emit_bounded) - no host round trip between count and emit; marching_cubes_finish hands out the filled prefix, or runs
+    the two phases again when a capacity turned out too small."""
     if not isinstance(volume, torch.Tensor) or not volume.is_cuda:
         raise TypeError("marching cubes needs a CUDA tensor (there is no CPU fallback)")
     if volume.dim() != 3:
@@ -40,20 +55,28 @@ def marching_cubes_begin(volume, level=0.0, slot=0):
         raise ValueError("Input array must be at least 2x2x2.")
     vol = volume.detach().to(torch.float32).contiguous()
     dev = vol.device
-    ws, result = _workspace(vol.shape, dev, slot % _SLOTS)
+    ws, result = _workspace(vol.shape, dev, slot % _SLOTS), _result_record()
+    L = _native.lib()
+    bufs = None
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _native.check(_native.lib().asdf_mc_count_enqueue(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(float(level)),
-                                                          ws.data_ptr(), ws.numel(), result.data_ptr(), stream), "asdf_mc_count_enqueue")
+        _native.check(L.asdf_mc_count_enqueue(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(float(level)),
+                                              ws.data_ptr(), ws.numel(), result.data_ptr(), stream), "asdf_mc_count_enqueue")
+        if capacity is not None:
+            cv, cf = int(capacity[0]), int(capacity[1])
+            bufs = (torch.empty((cv, 3), dtype=torch.float32, device=dev), torch.empty((cf, 3), dtype=torch.int32, device=dev))
+            _native.check(L.asdf_mc_emit_bounded(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(float(level)),
+                                                 ws.data_ptr(), ws.numel(), bufs[0].data_ptr(), cv, bufs[1].data_ptr(), cf, stream),
+                          "asdf_mc_emit_bounded")
         done = torch.cuda.Event()
         done.record()
-    return vol, float(level), ws, result, done
+    return vol, float(level), ws, result, done, bufs
 
 
 def marching_cubes_finish(ticket):
     """Wait for the sizes of marching_cubes_begin (an event, not the stream), allocate, emit.  Returns (verts [V,3] fp32,
     faces [F,3] int32) device tensors; raises ValueError / RuntimeError with skimage's messages."""
-    vol, level, ws, result, done = ticket
+    vol, level, ws, result, done, bufs = ticket
     done.synchronize()
     L = _native.lib()
     r = result.numpy().view(np.uint32)
@@ -63,9 +86,15 @@ def marching_cubes_finish(ticket):
     if rc == _native.ENOSURF:
         raise RuntimeError("No surface found at the given iso value.")
     _native.check(rc, "asdf_mc_result_status")
+    V, F = int(r[0]), int(r[1])
+    if bufs is not None:
+        if V <= bufs[0].shape[0] and F <= bufs[1].shape[0]:
+            return bufs[0][:V], bufs[1][:F]          # (emitted behind the count phase: nothing left to do)
+        # a capacity was too small; the workspace may have served another volume since: both phases again, sizes known
+        return marching_cubes_finish(marching_cubes_begin(vol, level))
     dev = vol.device
-    verts = torch.empty((int(r[0]), 3), dtype=torch.float32, device=dev)
-    faces = torch.empty((int(r[1]), 3), dtype=torch.int32, device=dev)
+    verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((F, 3), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _native.check(L.asdf_mc_emit(vol.data_ptr(), vol.shape[0], vol.shape[1], vol.shape[2], ctypes.c_double(level),

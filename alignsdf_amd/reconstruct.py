@@ -51,7 +51,7 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
-def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False, midpoint=None):
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False, midpoint=None, report=None):
     """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
@@ -78,7 +78,9 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
     midpoint(key, result), if given, is called for sample k between queuing pass 2 of sample k+1 and pass 1 of sample
     k+2: GPU work it enqueues (the eval-mode ICP of sample k's hand mesh) lands between two decoder passes instead of
-    behind both, and its host part is covered by the pass that is already running."""
+    behind both, and its host part is covered by the pass that is already running.
+
+    report, if given (a dict), receives the evaluator that ran and a snapshot of its sweep counters (see write_sweeps_json)."""
     from .marching_cubes import marching_cubes_begin, marching_cubes_finish
     from .utils.mesh import GRID_MODES, zoom_cube_from_bboxes
     from .utils.utils import bind_sample, decoder_for
@@ -87,6 +89,8 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     if cur is None:
         return
     hip = decoder_for(decoder, specs, cur[2])      # the HIP kernels, or the module on PyTorch-ROCm for variants they do not cover
+    if report is not None:                         # (the caller's `sweeps.json`: which evaluator ran, and its counters at the start)
+        report["evaluator"], report["snapshot"] = hip, hip.sweep_snapshot()
     hb, ob = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
     mode = GRID_MODES[grid_mode]
     voxel = 2.0 / (N - 1)
@@ -342,8 +346,13 @@ class FileWriter:
         for path, j in self.jobs:
             if not j.done():
                 pending.append((path, j))
-            elif first is None:
-                first = j.exception()
+                continue
+            err = j.exception()
+            if err is not None:
+                import logging
+                logging.error("PLY write of %s failed: %s", path, err)      # every failed path is named, the first is raised
+                if first is None:
+                    first = err
         self.jobs = pending                        # (a failure is reported once)
         if first is not None:
             raise first
@@ -370,6 +379,44 @@ class FileWriter:
                     first = err
         if first is not None:
             raise first
+
+
+def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim):
+    """`<output_dir>/sweeps_<start>_<end>.json` - next to `meshes/`, whose listing stays the reference's (reconstruct.py:34-35) -: which
+    sweeps produced the volumes behind this shard's meshes.
+    The default sweeps of a mesh-producing run rest on a measured, statistical certificate; a run whose sweeps
+    were refused and repeated, whose modes were switched off, or which ended on the fp32 chain must say so NEXT TO ITS FILES, not only
+    in a log line.  The reference writes nothing of the kind (utils/mesh.py:82-121 evaluates every voxel in fp32)."""
+    hip = report.get("evaluator")
+    body = {"range": [int(start_point), int(end_point)], "samples": int(samples), "cube_dim": int(cube_dim),
+            "sweeps": hip.sweep_report(report.get("snapshot")) if hip is not None else None}
+    path = os.path.join(out_dir, "sweeps_%d_%d.json" % (int(start_point), int(end_point)))
+    with open(path, "w") as f:
+        json.dump(body, f, indent=1)
+    return path
+
+
+def merge_sweeps_json(out_dir, out_name="sweeps.json"):
+    """One `sweeps.json` for the whole run from the per-shard files (dist_reconstruct: rank 0, behind the gather): the per-shard
+    records side by side plus the totals a reader looks for first."""
+    shards = []
+    for name in sorted(os.listdir(out_dir)):
+        if name.startswith("sweeps_") and name.endswith(".json"):
+            with open(os.path.join(out_dir, name)) as f:
+                shards.append(json.load(f))
+    shards.sort(key=lambda b: b["range"][0])
+    tot = {"samples": sum(b["samples"] for b in shards), "sweeps_audited": 0, "sweeps_refused": 0, "sweeps_repeated": 0,
+           "modes_switched_off": [], "fell_back_to_fp32_chain": False}
+    for b in shards:
+        sw = b.get("sweeps") or {}
+        for k in ("sweeps_audited", "sweeps_refused", "sweeps_repeated"):
+            tot[k] += int(sw.get(k, 0))
+        tot["modes_switched_off"] += ["samples %d..%d: %s" % (b["range"][0], b["range"][1], m) for m in sw.get("modes_switched_off", [])]
+        tot["fell_back_to_fp32_chain"] = tot["fell_back_to_fp32_chain"] or bool(sw.get("arithmetic", {}).get("fell_back_to_fp32_chain"))
+    path = os.path.join(out_dir, out_name)
+    with open(path, "w") as f:
+        json.dump({"totals": tot, "shards": shards}, f, indent=1)
+    return path
 
 
 def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
@@ -441,6 +488,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
             yield (int(start_point) + k, name), latent, mano_results, obj_results
 
     records = []
+    sweeps = {}
     try:
         with torch.no_grad():
             t_prev = time.perf_counter()
@@ -465,7 +513,8 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                     gt.discard(hand_path(key[1]) + ".ply")          # no hand surface: the prefetched ground truth is not needed
 
             for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
-                                                        label_out=label_out and hand_on, midpoint=begin_hand if gt is not None else None):
+                                                        label_out=label_out and hand_on, midpoint=begin_hand if gt is not None else None,
+                                                        report=sweeps):
                 rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
                        "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
                 # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
@@ -508,12 +557,18 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
     except BaseException:
         # unwinding: the helpers are closed without letting THEIR errors replace the one in flight
         if gt is not None:
-            gt.close()
+            try:
+                gt.close()
+            except Exception as e:          # (a failing close must not mask the error being raised)
+                import logging
+                logging.error("closing the ground-truth prefetcher failed: %s", e)
         writer.close(failing=True)
         raise
     if gt is not None:
         gt.close()
     writer.close()                      # every file is on disk (or its error raised) before reconstruct() returns
+    if sweeps:
+        write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim)
     return records
 
 

@@ -233,6 +233,14 @@ class TorchModuleDecoder:
     def fine_needs_repeat(self, ticket):
         return False
 
+    def sweep_snapshot(self):
+        return None
+
+    def sweep_report(self, since=None):
+        """The module path runs ordinary fp32 sweeps only (same interface as HipSdfDecoder.sweep_report)."""
+        return {"evaluator": "module on PyTorch-ROCm (%s)" % self.reason, "arithmetic": {"at_start": "f32 (torch)", "now": "f32 (torch)",
+                "fell_back_to_fp32_chain": False}, "sweeps_audited": 0, "sweeps_refused": 0, "sweeps_repeated": 0, "modes_switched_off": []}
+
     def decode_points(self, xyz):
         h, o, _ = self._decode(xyz.detach().to(self.device, torch.float32).contiguous())
         return h, o

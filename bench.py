@@ -432,8 +432,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    from alignsdf_amd.dist_reconstruct import limit_host_threads
-    host_threads = limit_host_threads(world, local_rank=local_rank)      # each rank's host tail on its share of the cores (no 8 x 256 thread pools)
+    from alignsdf_amd.dist_reconstruct import device_pci_address, gpu_numa_node, limit_host_threads
+    # each rank's host tail on its share of the cores (no 8 x 256 thread pools): the cores of ITS GPU's NUMA node where sysfs says
+    # which one that is, package-major blocks otherwise
+    host_threads = limit_host_threads(world, local_rank=local_rank, device_index=None if share else dev_index)
     n_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -545,7 +547,30 @@ def main():
     main_coarse, main_fine, main_math = main_sweeps["coarse"], main_sweeps["fine"], dec.math
     records = [dict(index=rank * args.steps + k, V_hand=d["V_hand"], F_hand=d["F_hand"], V_obj=d.get("V_obj", 0), F_obj=d.get("F_obj", 0),
                     milliseconds=0.0) for k, d in enumerate(done)]
+    ranks_report = None
     if world > 1:
+        # ---- the first contact with a multi-GPU node verifies itself: every rank contributes the identity of the
+        # device it actually drives (PCI address, UUID, NUMA node) and its OWN elapsed time; rank 0 prints how many distinct devices
+        # the ranks sat on and the spread of the per-rank times, not just the MAX the contract asks for
+        props = torch.cuda.get_device_properties(dev_index)
+        pci = device_pci_address(dev_index)
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = []
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "pci": pci, "uuid": str(getattr(props, "uuid", "")),
+                "name": props.name, "numa_node": gpu_numa_node(pci), "host": socket.gethostname(), "elapsed_s": elapsed,
+                "host_cpus": "%d (%s..%s)" % (len(cpus), cpus[0], cpus[-1]) if cpus else None}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        per_rank_ms = [1e3 * e["elapsed_s"] / args.steps for e in everyone]
+        ranks_report = {"rccl_ranks_seen": n_seen, "backend": backend,
+                        "devices_distinct": len({(e["host"], e["pci"] or e["uuid"] or e["device_index"]) for e in everyone}),
+                        "hosts": len({e["host"] for e in everyone}),
+                        "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms),
+                                                 "spread": (max(per_rank_ms) - min(per_rank_ms)) / max(min(per_rank_ms), 1e-9),
+                                                 "all": [round(v, 3) for v in per_rank_ms]},
+                        "rank_devices": [{k: e[k] for k in ("rank", "device_index", "pci", "numa_node", "host_cpus")} for e in everyone]}
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -797,6 +822,7 @@ def main():
                 "records_gathered": len(merged) if merged else 0,
                 "ranks_in_records": sorted({int(m.get("rank", 0)) for m in merged}) if merged else [],
                 "coarse_pass": main_coarse, "fine_pass": main_fine, "math": main_math,
+                **(ranks_report or {}),
             },
             "sweeps": main_sweeps,
             "roofline": roofline,

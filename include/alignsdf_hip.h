@@ -156,6 +156,26 @@ int asdf_decode_grid_box(asdf_decoder_t* dec, int32_t N, const float origin[3], 
 int asdf_decode_grid_band(asdf_decoder_t* dec, int32_t N, const float origin[3], float voxel_size, int32_t grid_mode, float tau,
                           float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
 
+/* The zoom cube of get_higher_res_cube (utils/mesh.py:239-254) ON THE DEVICE, from the boxes a coarse pass left in bbox_dev (the
+ * int32[16] / [48] record of asdf_decode_grid / asdf_decode_grid_box): per enabled branch the box of its negative voxels, zeros for a
+ * branch without one (utils/mesh.py:209-211); min / max over the enabled branches; then, in fp32 with separately rounded operations
+ * like the reference's CPU tensors,
+ *     new_cube_size = (max(max_index - min_index) + 4) * voxel_size;   new_voxel_size = new_cube_size / (N - 1);
+ *     new_origin    = (min_index - 2) * voxel_size - 1
+ * written to lattice_dev[4] = {origin0, origin1, origin2, new_voxel_size} (bit-equal to the host arithmetic the reference runs;
+ * tests/test_gpu_zoom_handoff.py).  With it the fine pass can be ENQUEUED right behind the coarse pass - asdf_decode_grid_band_dev /
+ * asdf_decode_grid_dev read their lattice from these words - and the host judges the coarse pass' record afterwards instead of
+ * standing between the two passes (round 5; the reference synchronises twice per chunk, utils/mesh.py:46-63). */
+int asdf_zoom_cube(const int32_t* bbox_dev, int32_t N, float voxel_size, int32_t hand_branch, int32_t obj_branch, float* lattice_dev,
+                   void* stream);
+
+/* asdf_decode_grid_band / asdf_decode_grid with the lattice {origin0, origin1, origin2, voxel_size} taken from DEVICE memory at
+ * kernel run time (asdf_zoom_cube's output) instead of from the host arguments.  Everything else as the host-argument forms. */
+int asdf_decode_grid_band_dev(asdf_decoder_t* dec, int32_t N, const float* lattice_dev, int32_t grid_mode, float tau,
+                              float* sdf_hand_dev, float* sdf_obj_dev, int32_t* rec_dev, void* stream);
+int asdf_decode_grid_dev(asdf_decoder_t* dec, int32_t N, const float* lattice_dev, int32_t grid_mode,
+                         float* sdf_hand_dev, float* sdf_obj_dev, int32_t* bbox_dev, void* stream);
+
 /* 1 when asdf_decode_grid_box / asdf_decode_grid_band are available for this decoder under its current activation scales.  The
  * one-plane kernels keep their own weight image, scaled so that every accumulator already carries its activation's plane scale
  * (no rescale in the epilogue); a decoder whose consecutive layers differ by more than 2^15 in activation magnitude cannot be
@@ -266,6 +286,11 @@ int asdf_mc_count(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, doub
                   size_t workspace_bytes, uint32_t* num_verts, uint32_t* num_faces, void* stream);
 int asdf_mc_emit(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
                  size_t workspace_bytes, float* verts_dev, int32_t* faces_dev, void* stream);
+/* asdf_mc_emit into buffers sized BEFORE the counts are known (verts_dev [cap_verts][3], faces_dev [cap_faces][3]): entries beyond a
+ * capacity are not written.  With it the emit phase is enqueued right behind asdf_mc_count_enqueue, the host reads V / F afterwards
+ * and repeats the emit (or calls asdf_mc_emit) only when a capacity was too small - no host round trip between count and emit. */
+int asdf_mc_emit_bounded(const float* vol_dev, int32_t n0, int32_t n1, int32_t n2, double level, void* workspace_dev,
+                         size_t workspace_bytes, float* verts_dev, uint32_t cap_verts, int32_t* faces_dev, uint32_t cap_faces, void* stream);
 /* The count phase without any host synchronisation: classify + reduce are enqueued and the last kernel writes
  * result[0] = V, result[1] = F, result[2..3] = order-preserving keys of the volume's min / max into result_mapped -
  * device-accessible HOST memory (hipHostMalloc / a pinned torch tensor; NULL = header only).  The caller records an event,

@@ -62,6 +62,16 @@ def test_gpus_8_on_one_device():
     assert abs(line["value"] - 8 * 2 * 2 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"]
     assert line["config"]["records_gathered"] == 16 and line["config"]["ranks_in_records"] == list(range(8))
     assert line["config"]["host_threads_per_rank"] >= 1
+    # round 5: the first multi-rank contact verifies itself - ranks seen over the collective, DISTINCT devices
+    # behind them (here: eight ranks folded onto one device, and the line says so), every rank's own time and the spread
+    c = line["config"]
+    assert c["rccl_ranks_seen"] == 8 and c["backend"] == "gloo" and c["devices_distinct"] == 1 and c["hosts"] == 1
+    t = c["per_rank_ms_per_step"]
+    assert len(t["all"]) == 8 and 0 < t["min"] <= t["max"] and abs(t["max"] - line["ms_per_step"]) < 1e-6 * t["max"] + 1e-3
+    assert t["spread"] >= 0.0 and [d["rank"] for d in c["rank_devices"]] == list(range(8))
+    assert all(d["device_index"] == 0 and d["pci"] for d in c["rank_devices"])
+    masks = [d["host_cpus"] for d in c["rank_devices"]]
+    assert len(set(masks)) == 8                     # eight disjoint blocks of host cores
 
 
 @pytest.mark.gpu

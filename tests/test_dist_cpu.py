@@ -157,3 +157,103 @@ def test_eight_ranks_do_not_oversubscribe_the_host(tmp_path):
     assert len(seen) == len(set(seen))                                  # disjoint
     print("host tail: 1 rank %.0f ms, slowest of 8 ranks %.0f ms" % (single, eight))
     assert eight <= 1.5 * single + 50.0, (single, eight)
+
+
+# ---- round 5: NUMA-aware core binding, LOCAL_WORLD_SIZE and the mask's lifetime ----------
+def _fake_sysfs(root, gpus, nodes):
+    """A sysfs tree with `gpus` = {pci address: numa node} and `nodes` = {node: cpulist string}."""
+    for addr, node in gpus.items():
+        d = root / "bus" / "pci" / "devices" / addr
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cpulist in nodes.items():
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpulist + "\n")
+    return str(root)
+
+
+def test_gpu_numa_node_and_cpulist_parsing(tmp_path):
+    from alignsdf_amd.dist_reconstruct import gpu_numa_node, numa_node_cpus
+    sysfs = _fake_sysfs(tmp_path, {"0000:05:00.0": 0, "0000:85:00.0": 1, "0000:c5:00.0": -1}, {0: "0-3,8-11", 1: "4-7,12-15"})
+    assert gpu_numa_node("0000:05:00.0", sysfs) == 0 and gpu_numa_node("0000:85:00.0", sysfs) == 1
+    assert gpu_numa_node("0000:C5:00.0", sysfs) is None          # -1: the platform does not say
+    assert gpu_numa_node("0000:ff:00.0", sysfs) is None and gpu_numa_node(None, sysfs) is None
+    assert numa_node_cpus(0, sysfs) == [0, 1, 2, 3, 8, 9, 10, 11] and numa_node_cpus(1, sysfs) == [4, 5, 6, 7, 12, 13, 14, 15]
+    assert numa_node_cpus(7, sysfs) is None
+
+
+def test_numa_core_blocks_follow_the_gpus(tmp_path):
+    """8 GPUs, 4 per socket; 2 sockets x 8 cores x 2 threads (CPU c and c + 16 are siblings).  Every rank gets a quarter of the
+    cores of ITS GPU's node, whole cores (both threads), disjoint, and the blocks of one node cover that node."""
+    from alignsdf_amd.dist_reconstruct import numa_core_block
+    sysfs = _fake_sysfs(tmp_path, {}, {0: "0-7,16-23", 1: "8-15,24-31"})
+    siblings = {c: (c // 8 % 2, c % 8) for c in range(32)}             # (package, core id): CPUs c and c + 16 share a core
+    nodes = [0, 0, 1, 1, 0, 0, 1, 1]                                   # a rank order that does NOT follow the sockets
+    allowed = set(range(32))
+    blocks = [numa_core_block(8, r, nodes, sysfs, allowed, siblings) for r in range(8)]
+    assert all(len(b) == 4 for b in blocks)                            # 2 cores x 2 threads
+    for r, b in enumerate(blocks):
+        want = set(range(0, 8)) | set(range(16, 24)) if nodes[r] == 0 else set(range(8, 16)) | set(range(24, 32))
+        assert set(b) <= want, (r, b)
+        assert {c % 16 for c in b} == {c % 16 for c in b if c < 16}    # whole cores: each core's two threads together
+    flat = [c for b in blocks for c in b]
+    assert len(flat) == len(set(flat)) == 32
+    assert sorted(c for r in (0, 1, 4, 5) for c in blocks[r]) == sorted(list(range(0, 8)) + list(range(16, 24)))
+    # incomplete information -> None (the caller falls back to the package-major blocks)
+    assert numa_core_block(8, 0, [0, 0, 1, 1, 0, None, 1, 1], sysfs, allowed, siblings) is None
+    assert numa_core_block(8, 0, [0] * 7, sysfs, allowed, siblings) is None
+    assert numa_core_block(2, 0, [3, 3], sysfs, allowed, siblings) is None      # a node sysfs does not list
+
+
+def test_core_binding_uses_the_local_world_and_is_undone(monkeypatch):
+    """A 2-node x 4-rank launch cuts each HOST into 4 blocks (LOCAL_WORLD_SIZE), not 8; restore_host_cores puts the mask back."""
+    import os
+    from alignsdf_amd import dist_reconstruct as dr
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    before = os.sched_getaffinity(0)
+    if len(before) < 4:
+        pytest.skip("needs 4 CPUs")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    monkeypatch.delenv("ASDF_NO_CORE_BINDING", raising=False)
+    assert dr.local_world_size(8) == 4
+    blocks = dr.core_blocks(4)
+    try:
+        cpus = dr.bind_host_cores(8, 5)                                # global world 8, local rank 5 % 4 == 1
+        assert cpus == blocks[1] and os.sched_getaffinity(0) == set(blocks[1])
+        assert len(cpus) >= len(before) // 4 - 1                       # a quarter of the host, not an eighth
+    finally:
+        dr.restore_host_cores()
+    assert os.sched_getaffinity(0) == before
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert dr.local_world_size(8) == 8
+
+
+def test_sweeps_json_is_written_and_merged(tmp_path):
+    """each shard's sweeps_<start>_<end>.json + rank 0's merged sweeps.json with the totals a reader wants first
+    (refused / repeated sweeps, mode switches) - here with stand-in evaluators, one of which reports a refusal and a switched-off mode."""
+    from alignsdf_amd import reconstruct as rc
+
+    class Ev:
+        def __init__(self, rep):
+            self.rep = rep
+
+        def sweep_report(self, since):
+            assert since == "snap"
+            return self.rep
+
+    clean = {"arithmetic": {"fell_back_to_fp32_chain": False}, "sweeps_audited": 20, "sweeps_refused": 0, "sweeps_repeated": 0, "modes_switched_off": []}
+    rough = {"arithmetic": {"fell_back_to_fp32_chain": True}, "sweeps_audited": 12, "sweeps_refused": 3, "sweeps_repeated": 4,
+             "modes_switched_off": ["fine: three refusals in a row (error 0.002 on the re-evaluated voxels against allowance 0.001)"]}
+    d = str(tmp_path)
+    p0 = rc.write_sweeps_json(d, 10, 20, {"evaluator": Ev(rough), "snapshot": "snap"}, 10, 256)
+    p1 = rc.write_sweeps_json(d, 0, 10, {"evaluator": Ev(clean), "snapshot": "snap"}, 10, 256)
+    assert os.path.basename(p0) == "sweeps_10_20.json" and os.path.basename(p1) == "sweeps_0_10.json"
+    m = json.load(open(rc.merge_sweeps_json(d)))
+    assert [s["range"] for s in m["shards"]] == [[0, 10], [10, 20]]
+    t = m["totals"]
+    assert t["samples"] == 20 and t["sweeps_audited"] == 32 and t["sweeps_refused"] == 3 and t["sweeps_repeated"] == 4
+    assert t["fell_back_to_fp32_chain"] is True and len(t["modes_switched_off"]) == 1 and t["modes_switched_off"][0].startswith("samples 10..20: fine")
+    m2 = json.load(open(rc.merge_sweeps_json(d)))                      # idempotent: the merged file is not taken for a shard
+    assert m2["totals"] == t and len(m2["shards"]) == 2

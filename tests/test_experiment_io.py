@@ -61,6 +61,17 @@ def test_reconstruct_cli_writes_reference_layout(tmp_path):
     for r in recs:
         v, f = read_ply(os.path.join(mesh_dir, r["name"] + "_hand.ply"))
         assert len(f) > 100 and f.max() < len(v) and r["F_hand"] >= len(f)
+    # round 5: next to meshes/ the run says which sweeps produced the volumes behind its files
+    import json
+    rep = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "sweeps_1_3.json")))
+    assert rep["range"] == [1, 3] and rep["samples"] == 2 and rep["cube_dim"] == 32
+    sw = rep["sweeps"]
+    assert sw["evaluator"].startswith("hip kernels") and sw["arithmetic"] == {"at_start": "f16x3", "now": "f16x3", "fell_back_to_fp32_chain": False}
+    assert sw["sweeps_refused"] == 0 and sw["sweeps_repeated"] == 0 and sw["modes_switched_off"] == []
+    # sample 1: both lattices compared as a whole (ordinary sweeps); sample 2: the audited one-plane sweeps
+    assert sw["whole_lattice_comparisons"] == {"coarse_lattice": 1, "zoom_lattice": 1}
+    assert sw["coarse_pass"]["one_plane_box_sweeps_accepted"] == 1 and sw["fine_pass"]["one_plane_band_sweeps_accepted"] == 1
+    assert sw["sweeps_audited"] == 2 and sw["coarse_pass"]["mode_now"] == "box" and sw["fine_pass"]["mode_now"] == "band"
 
 
 @pytest.mark.gpu
@@ -83,6 +94,59 @@ def test_dist_reconstruct_cli_two_ranks(tmp_path):
     assert meshes == sorted(["%s_%s.ply" % (n, p) for n in names for p in ("hand", "obj")])
     assert all(r["F_hand"] > 100 and r["F_obj"] > 100 for r in summary)
     assert all(r["icp_skipped"] == 1 for r in summary)          # eval mode without ground-truth meshes is visible in the records
+    # each shard's sweeps_<start>_<end>.json and rank 0's merged sweeps.json, next to meshes/
+    out = os.path.join(str(tmp_path), "Eval_obman")
+    assert os.path.exists(os.path.join(out, "sweeps_0_2.json")) and os.path.exists(os.path.join(out, "sweeps_2_5.json"))
+    merged = json.load(open(os.path.join(out, "sweeps.json")))
+    assert [s["range"] for s in merged["shards"]] == [[0, 2], [2, 5]] and merged["totals"]["samples"] == 5
+    assert merged["totals"]["sweeps_refused"] == 0 and merged["totals"]["modes_switched_off"] == [] and not merged["totals"]["fell_back_to_fp32_chain"]
+    assert merged["totals"]["sweeps_audited"] == 2 * (1 + 2)            # every sample but each shard's first runs two audited sweeps
+
+
+@pytest.mark.gpu
+def test_sweeps_json_counts_a_provoked_refusal(tmp_path, monkeypatch):
+    """a sweep that was refused and repeated is visible AFTER the run, next to the meshes - not only in a log
+    line.  Six samples at N = 64; while samples 1 / 2 are in flight the capacity of the narrow-band list is set to 10 voxels, so
+    the band sweep that is judged then is refused ("voxels listed, capacity") and repeated as an ordinary sweep; the run carries on
+    with the audited sweeps.  The meshes are those of a run that never heard of the one-plane sweeps."""
+    from alignsdf_amd import hip_decoder as hd
+    from alignsdf_amd import reconstruct as rc
+    from alignsdf_amd.ply import read_ply
+    from alignsdf_amd.utils.utils import decoder_for
+    names = ["%08d" % i for i in range(6)]
+    specs, split = make_experiment(str(tmp_path), "nerf3", names)
+    specs, decoder = rc.load_experiment(str(tmp_path))
+    hip = decoder_for(decoder, specs)
+    base = rc.synthetic_code_source("nerf3")
+    real_cap = hd.BAND_CAP
+
+    def sabotaging_source(name, index):          # (the pipeline fetches sample k + 2 while sample k is being finished)
+        monkeypatch.setattr(hd, "BAND_CAP", 10 if index in (3, 4) else real_cap)
+        return base(name, index)
+
+    out = str(tmp_path / "Eval_obman")
+    recs = rc.reconstruct(decoder, specs, split, out, 0, 6, cube_dim=64, code_source=sabotaging_source)
+    monkeypatch.setattr(hd, "BAND_CAP", real_cap)
+    rep = json.load(open(os.path.join(out, "sweeps_0_6.json")))["sweeps"]
+    assert 1 <= rep["sweeps_refused"] <= 2 and rep["sweeps_repeated"] >= rep["sweeps_refused"], rep
+    assert rep["fine_pass"]["refused_and_repeated"] == rep["sweeps_refused"] and rep["coarse_pass"]["refused_and_repeated"] == 0
+    assert rep["refusals_for_error"] == 0 and rep["whole_lattice_comparisons"] == {"coarse_lattice": 1, "zoom_lattice": 1}, rep
+    assert rep["modes_switched_off"] == [] and rep["coarse_pass"]["mode_now"] == "box" and rep["fine_pass"]["mode_now"] == "band"
+    assert rep["fine_pass"]["one_plane_band_sweeps_accepted"] >= 2 and rep["arithmetic"]["fell_back_to_fp32_chain"] is False
+    # the files are the ordinary sweeps' files
+    hip.coarse_mode = hip.fine_mode = "exact"
+    out2 = str(tmp_path / "Eval_plain")
+    recs2 = rc.reconstruct(decoder, specs, split, out2, 0, 6, cube_dim=64, code_source=base)
+    rep2 = json.load(open(os.path.join(out2, "sweeps_0_6.json")))["sweeps"]
+    assert rep2["sweeps_audited"] == 0 and rep2["coarse_pass"]["ordinary_sweeps"] == 6 and rep2["fine_pass"]["ordinary_sweeps"] == 6
+    assert rep2["coarse_pass"]["mode_now"] == "exact"
+    for a, b in zip(recs, recs2):
+        assert (a["V_hand"], a["F_hand"], a["V_obj"], a["F_obj"]) == (b["V_hand"], b["F_hand"], b["V_obj"], b["F_obj"])
+        for part in ("hand", "obj"):
+            va, fa = read_ply(os.path.join(out, "meshes", "%s_%s.ply" % (a["name"], part)))
+            vb, fb = read_ply(os.path.join(out2, "meshes", "%s_%s.ply" % (a["name"], part)))
+            assert np.array_equal(va, vb) and np.array_equal(fa, fb)
+    hip.coarse_mode, hip.fine_mode = "box", "band"
 
 
 def test_reconstruct_requires_a_code_source(tmp_path):

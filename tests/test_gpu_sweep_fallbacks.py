@@ -76,7 +76,9 @@ def test_near_level_overflow_in_a_band_sweep(monkeypatch):
     want = _two_pass(dec, specs, 3, N, mc_only=True)
     hip.set_math("f16x3")
     hip.coarse_mode, hip.fine_mode = "box", "band"
-    _two_pass(dec, specs, 1, N, mc_only=True)                       # calibrates the allowance; band sweeps from here on
+    _two_pass(dec, specs, 1, N, mc_only=True)                       # compares the coarse and the zoom lattice as a whole (ordinary sweeps)
+    assert hip.band_stats["band"] == 0 and hip.cert["fine_calibrations"] == 1
+    _two_pass(dec, specs, 2, N, mc_only=True)                       # band sweeps from here on
     assert hip.band_stats["band"] == 1
     hip.set_refine(0.03)
     hip.coarse_mode = "exact"                                       # (pass 1 is not under test here; it would overflow as well)

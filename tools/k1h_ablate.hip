@@ -74,13 +74,16 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&cst, c.size() * 4); (void)hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
   (void)hipMalloc(&o0, P * 4); (void)hipMalloc(&o1, P * 4);
   int* bbox; (void)hipMalloc(&bbox, 64); (void)hipMemset(bbox, 0, 64);
+  // K1H_STATUS=1: the decoder's status record as the product passes it (peak words, range report, clock stamps); K1H_NOBBOX=1: no box fold
+  int* status = nullptr;
+  if (getenv("K1H_STATUS")) { (void)hipMalloc(&status, 64); (void)hipMemset(status, 0, 64); }
   // one-plane kernels: the fp16 point-feature / bias operands (timing only: small values, T = 1)
   std::vector<uint16_t> a16h((size_t)kHeads * kA16Floats * 2);
   for (size_t i = 0; i < a16h.size(); ++i) { _Float16 v = strcmp(data, "zero") ? (_Float16)((float)((int)((i * 2654435761u) >> 20) % 201 - 100) * 1e-2f) : (_Float16)0.0f; a16h[i] = *(uint16_t*)&v; }
   for (int h = 0; h < kHeads; ++h) { float one = 1.0f; memcpy(&a16h[((size_t)h * kA16Floats + 2 * kA16LayerFloats) * 2], &one, 4); memcpy(&a16h[((size_t)h * kA16Floats + 2 * kA16LayerFloats + 1) * 2], &one, 4); }
   float* a16; (void)hipMalloc(&a16, a16h.size() * 2); (void)hipMemcpy(a16, a16h.data(), a16h.size() * 2, hipMemcpyHostToDevice);
   DecodeParams p{}; p.stream = stream; p.cst = cst; p.sdf0 = o0; p.sdf1 = o1; p.P = P; p.N = N; p.mode = kGridReference;
-  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0; p.bbox = bbox; p.a16 = a16;
+  p.vs = 2.0f / (N - 1); p.o0 = p.o1 = p.o2 = -1.f; p.num_mlps = 2; p.first_mlp = 0; p.bbox = getenv("K1H_NOBBOX") ? nullptr : bbox; p.a16 = a16; p.status = status;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const double flop = (double)P * 2 * 3145728.0 / (PLANES == 1 ? 3 : 1);
   printf("GROUPS %d  PLANES %d  PREFETCH %d  BARRIER_KB %d  data %s\n", GROUPS, PLANES, ASDF16_PREFETCH, ASDF16_BARRIER_KB, data);
