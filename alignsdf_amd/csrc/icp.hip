@@ -451,7 +451,15 @@ bool use_grid(int ns, int nt) { return g_icp_search == 2 || (g_icp_search == 0 &
 // asdf_icp_set_search has been told in between (the process-wide setting used to be re-read on every attach).
 std::mutex g_run_mu;
 std::unordered_map<const void*, bool> g_run_grid;
-void remember_run(const void* ws, bool grid) { std::lock_guard<std::mutex> g(g_run_mu); g_run_grid[ws] = grid; }
+// An entry lives from icp_begin until the run's outcome is read (asdf_icp_ts_result / the end of asdf_icp_ts / asdf_chamfer) - it does
+// not outlive the run, so a recycled workspace address cannot inherit a stale mode and the map does not grow with every address the
+// caching allocator hands out; a run that is never read is dropped when the map passes 4096 entries.
+void remember_run(const void* ws, bool grid) {
+  std::lock_guard<std::mutex> g(g_run_mu);
+  if (g_run_grid.size() > 4096) g_run_grid.clear();
+  g_run_grid[ws] = grid;
+}
+void forget_run(const void* ws) { std::lock_guard<std::mutex> g(g_run_mu); g_run_grid.erase(ws); }
 bool run_uses_grid(const void* ws, int ns, int nt) {
   std::lock_guard<std::mutex> g(g_run_mu);
   auto it = g_run_grid.find(ws);
@@ -602,6 +610,7 @@ int asdf_icp_ts(const double* src_dev, int32_t ns, const double* tgt_dev, int32_
     ASDF_HIP(hipStreamSynchronize(st));
   }
   icp_unpack(h, result);
+  forget_run(workspace_dev);
   return ASDF_OK;
 }
 
@@ -640,6 +649,7 @@ int asdf_icp_ts_result(const void* workspace_dev, double* result, void* stream) 
   ASDF_HIP(hipMemcpyAsync(&h, workspace_dev, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
   ASDF_HIP(hipStreamSynchronize((hipStream_t)stream));
   icp_unpack(h, result);
+  if (h.done) forget_run(workspace_dev);        // the run is over: a continuation (first_iter > 0) is only ever enqueued for an unfinished one
   return ASDF_OK;
 }
 
@@ -657,6 +667,7 @@ int asdf_chamfer(const double* a_dev, int32_t na, const double* b_dev, int32_t n
   ASDF_HIP(hipGetLastError());
   ASDF_HIP(hipMemcpyAsync(result, out, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   ASDF_HIP(hipStreamSynchronize(st));
+  forget_run(workspace_dev);
   return ASDF_OK;
 }
 

@@ -410,10 +410,18 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
 #ifdef ASDF16_FENCE_EVERY_MFMA
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if ((PL == 1 && G == 2) || STEPS) {
+      if (PL == 1 && G == 2) {
         // two point groups: each group's share of the deferred epilogue goes behind ONE of the two MFMAs (left to itself the
         // scheduler issues both MFMAs back to back - the second waits a whole MFMA for the pipe - and then all the VALU work)
-        // split-half kernel (round 5): the same with the three pieces of a part behind the three MFMAs (split_part)
+        epi(kb, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (STEPS) {
+        // split-half kernel (round 5): the three pieces of a part behind the three MFMAs (split_part).  (The fence sits BEHIND the piece,
+        // so a scheduling region is {MFMA j, piece j} and the scheduler puts the dependency-free piece in front of an MFMA that waits for
+        // its LDS read now and then - every odd element: pieces 0 + 1 in one gap of 7 VALU instructions, still inside the MFMA's 32
+        // clocks.  A fence on BOTH sides gives exactly 4 / 3 / 2 per gap, needs -pragma-unroll-threshold raised for the extra IR, and
+        // measured the same: pipe busy 0.788 against 0.785 - not kept.)
         epi(kb, j);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1042,7 +1050,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         const long long pf_ = (G == 2 && half == 1) ? pib : pi;
         auto fold = [&](bool neg, int* rec, int extra) {
 #if ASDF16_FOLD_BALLOT
-          if (PL == 1 && !__any(neg || extra != 0)) return;      // (wave-uniform: most tiles of a sweep hold no negative voxel)
+          if ((PL == 1 || kMix) && !__any(neg || extra != 0)) return;      // (wave-uniform: most tiles of a sweep hold no negative voxel; round 5: the split-half SeparateDecoder forms too)
 #endif
           int i0, i1, i2;                                        // (behind the early return: two integer divisions per lane)
           lattice_ijk(pf_, p.N, i0, i1, i2);

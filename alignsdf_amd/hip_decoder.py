@@ -292,7 +292,7 @@ class HipSdfDecoder:
                      "fine_calibrations": 0, "fine_lattice_max_error": None, "fine_lattice_sigma": None, "fine_max_over_sigma": None,
                      "fine_tail_ratio": None, "fine_tail_ratio_max": None, "fine_neighbour_correlation": None}
         # what a run did, for the `sweeps.json` next to its meshes (reconstruct / dist_reconstruct): repeats and mode switches
-        self.events = {"repeated_sweeps": 0, "modes_switched_off": [], "fp32_fallback": False}
+        self.events = {"repeated_sweeps": 0, "modes_switched_off": [], "fp32_fallback": False, "samples_in_one_go": 0}
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
         self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps, plus the sweep's record tensor
 
@@ -820,6 +820,7 @@ class HipSdfDecoder:
         if self.combined:
             hand = obj = True
         self._coarse_since_cal += 1
+        self.events["samples_in_one_go"] += 1
         tau = self._box_tau
         org = [-1.0, -1.0, -1.0]
         args = (N, org, voxel_size, grid_mode, hand, obj)
@@ -1037,13 +1038,14 @@ class HipSdfDecoder:
     def sweep_snapshot(self):
         """Counters of this decoder's sweeps now; hand it to sweep_report() for what happened since."""
         return {"box": dict(self.box_stats), "band": dict(self.band_stats), "repeated": self.events["repeated_sweeps"],
+                "one_go": self.events["samples_in_one_go"],
                 "switched": len(self.events["modes_switched_off"]), "cert": {k: self.cert[k] for k in self._ADDITIVE_CERT},
                 "math": self.math, "modes": (self.coarse_mode, self.fine_mode)}
 
     def sweep_report(self, since=None):
         """Which sweeps produced the volumes behind a run's meshes: one-plane / ordinary / refused-and-repeated counts per pass,
         audits, whole-lattice comparisons, the margins of the statistical certificate, and every mode switch."""
-        z = since or {"box": self._new_stats("box"), "band": self._new_stats("band"), "repeated": 0, "switched": 0,
+        z = since or {"box": self._new_stats("box"), "band": self._new_stats("band"), "repeated": 0, "switched": 0, "one_go": 0,
                       "cert": {k: 0 for k in self._ADDITIVE_CERT}, "math": self.math, "modes": (self.coarse_mode, self.fine_mode)}
         d = lambda now, then, k: int(now[k]) - int(then[k])
         c = self.cert
@@ -1062,6 +1064,7 @@ class HipSdfDecoder:
             "sweeps_audited": c["audited_sweeps"] - z["cert"]["audited_sweeps"],
             "sweeps_refused": d(self.box_stats, z["box"], "fallback") + d(self.band_stats, z["band"], "fallback"),
             "sweeps_repeated": self.events["repeated_sweeps"] - z["repeated"],
+            "samples_enqueued_in_one_go": self.events["samples_in_one_go"] - z.get("one_go", 0),
             "refusals_for_error": c["refusals_for_error"] - z["cert"]["refusals_for_error"],
             "whole_lattice_comparisons": {"coarse_lattice": c["calibrations"] - z["cert"]["calibrations"],
                                           "zoom_lattice": c["fine_calibrations"] - z["cert"]["fine_calibrations"]},

@@ -6,6 +6,22 @@ number of faces other than two are dropped; with fewer than two remaining compon
 otherwise the one of largest area, its vertices in ascending original order.  trimesh itself is an un-vendored dependency
 that cannot be installed here, so these semantics are PARITY UNPINNED (trimesh 3.x additionally tries `fill_holes` on open
 components; not reproduced).  The host restatement used as this kernel's checker lives in oracle/mesh_oracle.py.
+
+The trimesh call path this restates, as documented for trimesh 3.x (the reference pins no version: requirements.txt):
+  utils/mesh.py:371   trimesh.graph.split(mesh)                       defaults only_watertight=True, adjacency=None, engine=None
+    -> adjacency = mesh.face_adjacency                                pairs of faces sharing an edge; built by
+       graph.face_adjacency(faces, return_edges=False)                  grouping.group_rows(edges_sorted, require_count=2):
+                                                                        an edge listed by exactly TWO faces joins them, an edge
+                                                                        listed once (boundary) or 3+ times (non-manifold) joins none
+    -> min_len = 4 if only_watertight else 1                          "the smallest watertight mesh has 4 faces"
+    -> components = graph.connected_components(adjacency, min_len=min_len, nodes=arange(len(faces)), engine=engine)
+    -> mesh.submesh(components, only_watertight=True, repair=True)    per component: a sub-mesh; not watertight -> fill_holes
+                                                                        (closes triangular / quadrilateral holes) -> still not
+                                                                        watertight -> dropped
+  utils/mesh.py:374-381   if len(split) > 1: keep the sub-mesh of largest .area (first one on ties: `>` in the loop)
+K8 reproduces every step but `fill_holes` (DESIGN section 4 lists when that could matter: it cannot on marching-cubes output,
+whose open components are clipped by the cube along loops of dozens of edges).  tests/test_gpu_mesh_cc.py checks K8 against the
+oracle on hand-built meshes AND on the trained grasp decoders' multi-component surfaces (scenes with detached pieces).
 """
 import ctypes
 

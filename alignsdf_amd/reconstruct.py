@@ -113,14 +113,45 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         r["host_" + key] = h
         return done
 
+    # Round 5: wherever the decoder's state allows it (HipSdfDecoder.can_speculate: both one-plane modes on, both
+    # whole-lattice comparisons valid, none due) a sample is ENQUEUED IN ONE GO - coarse box sweep, zoom cube on the device, narrow-band
+    # fine sweep on that lattice, marching-cubes counts and a capacity-bounded emit - and the host only reads records afterwards: no
+    # host round trip between the coarse and the fine pass, none between count and emit.  A refused sweep is repeated step by step, as
+    # before.  ASDF_SPECULATE=0 keeps every sample on the step-by-step path.
+    speculate = os.environ.get("ASDF_SPECULATE", "1") != "0" and hasattr(hip, "two_pass_begin")
+    seen = {}            # part -> (most vertices, most faces) of the surfaces so far: sizes the next sample's emit buffers
+
+    def capacity(part):
+        c = seen.get(part)
+        return None if c is None else (int(1.5 * c[0]) + 4096, int(1.5 * c[1]) + 8192)
+
     def first_pass(sample):
         bind(sample)
-        return hip.coarse_begin(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)
+        t = hip.two_pass_begin(N, voxel, mode, hand=hb, obj=ob) if speculate else None
+        if t is None:
+            return hip.coarse_begin(N, [-1.0, -1.0, -1.0], voxel, mode, hand=hb, obj=ob)
+        # marching cubes right behind the fine pass - count AND capacity-bounded emit - once the sizes of earlier surfaces are known.
+        # (Never the count alone: its emit would run when the sample is finished, after the NEXT sample's count phase has reused the
+        # workspace - found as a memory fault at N = 128.  Without sizes to go by the sample's marching cubes waits for surfaces().)
+        parts = [(slot, part) for slot, (part, on) in enumerate((("hand", hb), ("obj", ob))) if on]
+        t["mc"] = ({part: marching_cubes_begin(t["vol_" + part], 0.0, slot, capacity=capacity(part)) for slot, part in parts}
+                   if all(capacity(part) is not None for _, part in parts) else None)
+        return t
 
     def second_pass(ticket):
-        # waits for pass 1 (the zoom cube is data dependent); a coarse sweep whose guards fired (fp16 range, or the error
-        # check of the box-only sweep) is repeated in there - the decoder is still bound to this sample
-        b = hip.coarse_finish(ticket)
+        if "coarse" in ticket:
+            # both passes are in flight already: judge the coarse record (waits for that sweep alone); accepted - the usual case -
+            # means the fine pass ran on exactly the lattice the host arithmetic gives for these boxes (asdf_zoom_cube)
+            judged = hip.coarse_judge(ticket["coarse"])
+            if judged[0]:
+                origin, nvs = hip.lattice_of(ticket)
+                return {"vol_hand": ticket["vol_hand"], "vol_obj": ticket["vol_obj"], "voxel_size": nvs, "origin": origin, "bbox": judged[1],
+                        "fine_ticket": ticket["fine"], "mc_tickets": ticket["mc"]}
+            b = hip.coarse_finish(ticket["coarse"], judged=judged)      # refused: an ordinary sweep now (the decoder is bound to this sample)
+        else:
+            # waits for pass 1 (the zoom cube is data dependent); a coarse sweep whose guards fired (fp16 range, or the error
+            # check of the box-only sweep) is repeated in there - the decoder is still bound to this sample
+            b = hip.coarse_finish(ticket)
         boxes = ([(b[0:3], b[3:6], int(b[6]))] if hb else []) + ([(b[8:11], b[11:14], int(b[14]))] if ob else [])
         nvs, norg = zoom_cube_from_bboxes(boxes, N, voxel)
         # the fine pass carries a guard record (fp16 range report; error check of the narrow-band sweep): read behind the
@@ -143,7 +174,8 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
 
         # the count phases are queued BEFORE the fine pass's guard record is read (it is accepted all but never refused): one
         # host wait then covers the record and the sizes, instead of record -> launch -> sizes with the GPU idle in between
-        tickets = begin_counts()
+        # (a sample enqueued in one go brings its marching-cubes tickets along: counted, and usually emitted, behind its fine pass)
+        tickets = r.pop("mc_tickets", None) or begin_counts()
         while hip.fine_needs_repeat(ticket):
             # pass 2 left the fp16 range (the decoder has been re-calibrated, or switched to the fp32 kernel) or its
             # narrow-band form was not accepted: repeat this sample's pass 2 - and its count phases
@@ -161,6 +193,8 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                     continue
                 r["verts_" + part], r["faces_" + part] = v, f
                 r["V_" + part], r["F_" + part] = v.shape[0], f.shape[0]
+                c = seen.get(part, (0, 0))
+                seen[part] = (max(c[0], v.shape[0]), max(c[1], f.shape[0]))
         if between is not None:
             between(rebound)
         for part, on in (("hand", hb), ("obj", ob)):

@@ -298,7 +298,10 @@ def short_line(full, details_path):
                          "tail_ratio_max": c.get("tail_ratio_max"), "lattice_max_error": c.get("lattice_max_error"),
                          "lattice_max_over_sigma": c.get("lattice_max_over_sigma"), "min_tau_over_sigma": c.get("min_tau_over_sigma"),
                          "min_tau_over_estimate": c.get("min_margin_tau_over_estimate"),
-                         "fine_lattice": c.get("fine_lattice")}
+                         # the same whole-lattice comparison on the ZOOM lattice of a fine pass (what marching cubes consumes)
+                         "zoom_lattice_comparisons": c.get("fine_calibrations"), "zoom_lattice_max_error": c.get("fine_lattice_max_error"),
+                         "zoom_lattice_max_over_sigma": c.get("fine_max_over_sigma"), "zoom_lattice_tail_ratio_max": c.get("fine_tail_ratio_max"),
+                         "samples_enqueued_in_one_go": sw.get("samples_enqueued_in_one_go")}
     o = full.get("other_sweeps")
     if o:
         cfg["meshes_per_s_every_voxel_f16x3"] = o["value"]
@@ -525,6 +528,7 @@ def main():
             return {"coarse": d.coarse_mode if d._box_usable() else "exact", "fine": d.fine_mode if d._band_usable() else "exact",
                     "coarse_sweeps": dict(d.box_stats), "fine_sweeps": dict(d.band_stats),
                     "refused_sweeps": d.box_stats["fallback"] + d.band_stats["fallback"],
+                    "samples_enqueued_in_one_go": d.events["samples_in_one_go"],
                     "audit_voxels_per_sweep_and_head": d.audit_voxels, "allowance_now": d._box_tau, "tail_ratio": d._tail,
                     "certificate": d.certificate()}
 

@@ -85,6 +85,34 @@ def test_full_size_decoder_surface(golden_dir):
         _check(r["vol_" + part].cpu().numpy(), float(r["voxel_size"]), r["origin"])
 
 
+@pytest.mark.parametrize("tag", ["grasp3", "grasp9"])
+def test_grasp_scenes_with_detached_pieces(tag):
+    """K8's kept component against the oracle on REAL multi-component decoder output, not only on hand-built
+    meshes - the trained grasp decoders, scenes 1 / 5 (a detached blob in the hand volume) and 3 / 7 (a detached piece of the object),
+    at N = 128 through the two-pass flow.  Per surface: the number of qualifying components, the kept faces and the kept vertices are
+    the oracle's; where a volume has a detached piece the filter actually removes something, and what it keeps is the larger part."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.utils.mesh import decode_two_pass
+    specs = syn.specs_for(tag)
+    dec = build_decoder(specs, {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()})
+    removed = {}
+    for scene in (1, 3, 5, 7, 0):
+        lat, m, o = syn.sample_inputs(tag, scene)
+        mano = {k: torch.from_numpy(v).cuda() for k, v in m.items()} if m is not None else None
+        obj = {k: torch.from_numpy(v).cuda() for k, v in o.items()} if o is not None else None
+        r = decode_two_pass(True, True, dec, torch.from_numpy(lat).cuda(), mano, obj, specs, 128)
+        for part in ("hand", "obj"):
+            c, V, F = _check(r["vol_" + part].cpu().numpy(), float(r["voxel_size"]), r["origin"])
+            removed[(scene, part)] = (int(c[2]), F - int(c[1]))
+            if c[2] >= 2:
+                assert 0 < F - c[1] < c[1], (scene, part, c, F)           # something was removed, and it was the smaller part
+    print(tag, "qualifying components / faces removed per (scene, part):", removed)
+    # the scenes built with a detached blob / piece have at least two closed components in that volume, and the filter acts on them
+    assert removed[(1, "hand")][0] >= 2 and removed[(5, "hand")][0] >= 2, removed
+    assert removed[(3, "obj")][0] >= 2 and removed[(7, "obj")][0] >= 2, removed
+    assert removed[(0, "hand")][1] == 0 or removed[(0, "hand")][0] >= 2
+
+
 def _compare_raw(verts, faces, vs=1.0, origin=(0.0, 0.0, 0.0)):
     """Hand-built meshes (not marching-cubes output): device filter vs the host restatement, in lattice units."""
     v = torch.tensor(verts, dtype=torch.float32).cuda()

@@ -104,3 +104,44 @@ def test_no_scratch_traffic_inside_the_mfma_stream(compiled):
     # round 4: built with MFMA accumulators in VGPRs (build_native.TU_FLAGS) the epilogues read them in place - the default form read
     # every accumulator back out of the AGPRs (1 862 v_accvgpr_read per tile body, 4.6 % of the kernel's time)
     assert len([l for l in body if "v_accvgpr_read" in l]) <= 200 and not scratch
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_split_half_kernel_round5_form(compiled):
+    """VERDICT r04 item 1, pinned in the ISA of sdf_mlp_f16_kernel (K1h):
+    * the plane split runs on v_fma_mix{lo,hi}_f16 - 2 instructions per element (640 elements per tile body) - with no conversion
+      back (v_cvt_f32_f16), no subtraction and no packing (v_cvt_pk_f16_f32) left: 17 -> 9 VALU instructions per epilogue part;
+    * a part's pieces sit behind DIFFERENT MFMAs of its K-block: at most 7 VALU instructions (28 clocks) between two consecutive MFMAs of
+      the three hidden layers' K-blocks - the guide's ~5 fillers per 32-cycle MFMA gap; one part in ONE gap was 17 and cost ~43 clocks
+      on top of the issue slots whenever it made the next MFMA miss the back-to-back window of the same accumulator;
+    * one LDS-DMA piece per K-block: no two global_load_lds between two consecutive MFMAs;
+    * the per-wave activation peaks are folded by DPP + one lane: NO LDS atomic in the kernel (three ds_max by 64 lanes on one word
+      each cost 14 k clocks per tile - a tenth of the kernel - in round 4);
+    * every loop of the CombinedDecoder forms is still fully unrolled (3072 MFMAs in the body, no indexed registers)."""
+    text = compiled[1]
+    body = text[text.index("_ZN4asdf18sdf_mlp_f16_kernelENS_12DecodeParamsE:"):]
+    body = [l.strip() for l in body[:body.index("s_endpgm")].splitlines()]
+    ins = [l.split()[0] for l in body if l and not l.startswith((";", ".", "_")) and not l.endswith(":")]
+    count = lambda name: sum(1 for i in ins if i == name)
+    assert count("v_mfma_f32_32x32x16_f16") == 3072 and count("v_mfma_f32_32x32x2_f32") == 64
+    assert count("v_fma_mixlo_f16") == 640 and count("v_fma_mixhi_f16") == 640
+    assert count("v_cvt_pk_f16_f32") == 0 and count("v_cvt_f32_f16_e32") + count("v_cvt_f32_f16_sdwa") == 0
+    assert not [i for i in ins if i.startswith("ds_max") or i.startswith("ds_add") or i.startswith("ds_min")], "LDS atomics in K1h"
+    assert [i for i in ins if i.endswith("_dpp")], "the DPP reduction of the activation peaks"
+    # gaps between consecutive f16 MFMAs: VALU fillers and LDS-DMA pieces
+    at = [k for k, i in enumerate(ins) if i == "v_mfma_f32_32x32x16_f16"]
+    worst_valu, worst_dma, over = 0, 0, 0
+    for a, b in zip(at, at[1:]):
+        gap = ins[a + 1:b]
+        if any(g.startswith("v_mfma") or g in ("s_barrier", "s_cbranch_scc1", "s_cbranch_vccnz") for g in gap):
+            continue                                   # (layer boundaries: fp32 MFMAs of the point features, the stage barrier)
+        valu = sum(1 for g in gap if g.startswith("v_"))
+        worst_valu, worst_dma = max(worst_valu, valu), max(worst_dma, sum(1 for g in gap if g.startswith("global_load_lds")))
+        over += valu > 7
+    # (the K-blocks of layer 1's first stage carry a whole layer-0 tile each - up to 34 instructions per gap: 24 gaps per tile body -
+    # and a tile's first K-block carries the bias preloads: 10 - 11)
+    assert worst_dma <= 1 and over <= 48 and worst_valu <= 40, (worst_valu, worst_dma, over)
+    for mangled in ("_ZN4asdf27sdf_mlp_f16_combined_kernelENS_12DecodeParamsE", "_ZN4asdf34sdf_mlp_f16_subset_combined_kernelENS_12DecodeParamsE"):
+        b = text[text.index(mangled + ":"):]
+        b = b[:b.index("s_endpgm")]
+        assert b.count("v_mfma_f32_32x32x16_f16") == 3072 and "s_set_gpr_idx_on" not in b, mangled

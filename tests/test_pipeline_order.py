@@ -47,14 +47,15 @@ def harness(monkeypatch):
     log = []
     state = {}
 
-    def install(refuse=()):
-        dec = RecordingDecoder(log, refuse)
+    def install(refuse=(), cls=RecordingDecoder, **kw):
+        dec = cls(log, refuse, **kw)
         state["dec"] = dec
         import alignsdf_amd.marching_cubes as mc
         import alignsdf_amd.utils.utils as uu
         monkeypatch.setattr(uu, "decoder_for", lambda decoder, specs, mano: dec)
         monkeypatch.setattr(uu, "bind_sample", lambda hip, specs, latent, mano, obj: setattr(hip, "bound", int(latent)))
-        monkeypatch.setattr(mc, "marching_cubes_begin", lambda vol, level, slot: (log.append(("mc_count", vol[1], vol[0])), vol)[1])
+        monkeypatch.setattr(mc, "marching_cubes_begin", lambda vol, level, slot, capacity=None: (
+            log.append(("mc_count", vol[1], vol[0])), log.append(("mc_emit_bounded", vol[1], vol[0], capacity)) if capacity else None, vol)[2])
         monkeypatch.setattr(mc, "marching_cubes_finish", lambda t: (log.append(("mc_emit", t[1], t[0])),
                                                                    (torch.zeros(6, 3), torch.zeros(8, 3, dtype=torch.int32)))[1])
         return dec
@@ -122,3 +123,105 @@ def test_single_sample_and_empty_stream(harness):
     out = list(rc.pipelined_two_pass(object(), SPECS, samples(1), 16, midpoint=lambda key, r: log.append(("hook", key))))
     assert [k for k, _ in out] == [0]
     assert [e[0] for e in log] == ["pass1", "boxes", "pass2", "mc_count", "mc_count", "mc_emit", "mc_emit", "hook"]
+
+
+# ---- round 5: a sample enqueued in one go (HipSdfDecoder.two_pass_begin) ---------------------------------------------------------------
+class SpeculatingDecoder(RecordingDecoder):
+    """two_pass_begin enqueues pass 1 -> device zoom cube -> pass 2; coarse_judge reads the coarse record afterwards."""
+
+    def __init__(self, log, refuse_fine_of=(), stepwise=(), refuse_coarse_of=()):
+        super().__init__(log, refuse_fine_of)
+        self.stepwise, self.refuse_coarse = set(stepwise), set(refuse_coarse_of)
+
+    def two_pass_begin(self, N, voxel, mode, hand=True, obj=True):
+        k = self.bound
+        if k in self.stepwise:
+            return None
+        self.fine_count[k] = self.fine_count.get(k, 0) + 1
+        self.log.extend([("pass1", k), ("zoom_dev", k), ("pass2", k)])
+        return {"coarse": {"key": k}, "fine": {"key": k, "nth": self.fine_count[k]}, "vol_hand": ("vol_hand", k), "vol_obj": ("vol_obj", k)}
+
+    def coarse_judge(self, ticket):
+        k = ticket["key"]
+        self.log.append(("judge", k))
+        if k in self.refuse_coarse:
+            return False, None, True
+        b = np.zeros(16, dtype=np.int64)
+        b[0:3], b[3:6], b[6] = (3, 4, 5), (9, 11, 12), 100
+        b[8:11], b[11:14], b[14] = (2, 6, 5), (8, 10, 13), 50
+        return True, b, False
+
+    def coarse_finish(self, ticket, judged=None):
+        if judged is not None:
+            assert not judged[0] and self.bound == ticket["key"]       # repeated while the decoder is bound to THAT sample
+            self.log.append(("pass1_again", ticket["key"]))
+        return super().coarse_finish(ticket)
+
+    @staticmethod
+    def lattice_of(ticket):
+        from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
+        nvs, norg = zoom_cube_from_bboxes([((3, 4, 5), (9, 11, 12), 100), ((2, 6, 5), (8, 10, 13), 50)], 16, 2.0 / 15)
+        return norg.tolist(), nvs
+
+
+def test_a_sample_is_enqueued_in_one_go_and_judged_afterwards(harness):
+    """pass 1, the zoom cube (on the device), pass 2 and the marching-cubes counts of sample k + 1 are all enqueued
+    BEFORE the host reads anything of sample k + 1 - and before it finishes sample k; from the second surface on the emit is enqueued
+    with the counts (capacity = 1.5 x the largest surface so far).  The results are those of the step-by-step path."""
+    log, install = harness
+    install(cls=SpeculatingDecoder, stepwise=(0,))
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(4), 16, label_out=True, midpoint=lambda key, r: log.append(("hook", key))))
+    assert [k for k, _ in out] == [0, 1, 2, 3]
+    # sample 0 (the decoder's first: whole-lattice comparisons) goes step by step
+    assert first(log, ("pass1", 0)) < first(log, ("boxes", 0)) < first(log, ("pass2", 0)) < first(log, ("mc_count", 0, "vol_hand"))
+    assert ("zoom_dev", 0) not in log and ("judge", 0) not in log
+    for k in (1, 2, 3):
+        i = first(log, ("pass1", k))
+        assert log[i:i + 3] == [("pass1", k), ("zoom_dev", k), ("pass2", k)] and ("boxes", k) not in log
+        assert first(log, ("judge", k)) < first(log, ("mc_emit", k, "vol_hand")) < first(log, ("labels", k)) < first(log, ("hook", k))
+    # sample 1 is queued before any surface has been seen: no sizes for its emit buffers, so its marching cubes waits for surfaces()
+    # (a count phase must never be left alone across the next sample's count phase: they share the workspace)
+    assert first(log, ("judge", 1)) < first(log, ("mc_count", 1, "vol_hand"))
+    assert not [e for e in log if e[0] == "mc_emit_bounded" and e[1] == 1]
+    for k in (2, 3):
+        # ... from then on the counts AND the bounded emits of both volumes ride right behind pass 2, before anything of k is read
+        i = first(log, ("pass2", k))
+        cap = (int(1.5 * 6) + 4096, int(1.5 * 8) + 8192)                 # 1.5 x the largest surface so far + the floor
+        assert log[i + 1:i + 5] == [("mc_count", k, "vol_hand"), ("mc_emit_bounded", k, "vol_hand", cap), ("mc_count", k, "vol_obj"),
+                                    ("mc_emit_bounded", k, "vol_obj", cap)]
+        assert i + 4 < first(log, ("judge", k))
+    for k in (1, 2):
+        # all of sample k + 1 is in the queue before the host waits for the surfaces of sample k
+        assert first(log, ("mc_emit_bounded", k + 1, "vol_obj", cap)) < first(log, ("mc_emit", k, "vol_hand"))
+    assert first(log, ("pass2", 1)) < first(log, ("mc_emit", 0, "vol_hand"))
+    from alignsdf_amd.utils.mesh import zoom_cube_from_bboxes
+    nvs, norg = zoom_cube_from_bboxes([((3, 4, 5), (9, 11, 12), 100), ((2, 6, 5), (8, 10, 13), 50)], 16, 2.0 / 15)
+    for _, r in out:
+        assert float(r["voxel_size"]) == float(nvs) and r["origin"] == norg.tolist() and r["V_hand"] == 6 and r["F_obj"] == 8
+
+
+def test_refusals_of_a_speculative_sample(harness):
+    """A refused coarse sweep: pass 1 again as an ordinary sweep while the decoder is bound to that sample, the zoom cube on the host,
+    pass 2 and the counts again.  A refused fine sweep: re-bound, pass 2 and the counts again (as on the step-by-step path)."""
+    log, install = harness
+    dec = install(cls=SpeculatingDecoder, refuse=(3,), refuse_coarse_of=(2,))
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(5), 16))
+    assert [k for k, _ in out] == [0, 1, 2, 3, 4]
+    j = first(log, ("judge", 2))
+    assert log[j:j + 4] == [("judge", 2), ("pass1_again", 2), ("boxes", 2), ("pass2", 2)]
+    assert dec.fine_count == {0: 1, 1: 1, 2: 2, 3: 2, 4: 1}
+    # (samples 2 .. 4 had their marching cubes enqueued behind their speculative fine pass: counted there, and counted AGAIN on the repeat)
+    counts = [i for i, e in enumerate(log) if e == ("mc_count", 2, "vol_hand")]
+    assert len(counts) == 2 and counts[0] < j < counts[1] < first(log, ("mc_emit", 2, "vol_hand"))
+    counts = [i for i, e in enumerate(log) if e == ("mc_count", 3, "vol_hand")]
+    second = [i for i, e in enumerate(log) if e == ("pass2", 3)][1]
+    assert len(counts) == 2 and counts[0] < second < counts[1] < first(log, ("mc_emit", 3, "vol_hand"))
+    assert len([e for e in log if e == ("mc_count", 4, "vol_hand")]) == 1
+
+
+def test_speculation_can_be_switched_off(harness, monkeypatch):
+    log, install = harness
+    install(cls=SpeculatingDecoder)
+    monkeypatch.setenv("ASDF_SPECULATE", "0")
+    out = list(rc.pipelined_two_pass(object(), SPECS, samples(3), 16))
+    assert [k for k, _ in out] == [0, 1, 2] and not [e for e in log if e[0] in ("zoom_dev", "judge")]

@@ -5,6 +5,10 @@
 //                            constants), "zero" (all-zero operands: the DVFS upper bound) or "small" (default: small
 //                            pseudo-random weights that keep every ablation finite)
 // Besides the launch time the tool reports the shader clock the kernel ran at (s_memtime ticks of workgroup 0 / wall).
+// Environment: K1H_STATUS=1 passes a status record like the product does (round 5: that is where three 64-lane LDS atomics per tile
+// hid - 14 k clocks the tool never saw), K1H_NOBBOX=1 drops the negative-voxel fold.  Round 5: builds with -DASDF16_SEGMENT_TIMES
+// fault in the fold's early return (the stamps keep an 8-entry array live across it; only this timing build, the product's kernel
+// has no stamps and is covered by the parity tests) - run them with K1H_NOBBOX=1.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
