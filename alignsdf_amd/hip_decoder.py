@@ -831,12 +831,12 @@ class HipSdfDecoder:
         with torch.cuda.device(self.device):
             _native.check(self._L.asdf_zoom_cube(rec.data_ptr(), int(N), ctypes.c_float(float(np.float32(voxel_size))), int(bool(hand)),
                                                  int(bool(obj)), lattice.data_ptr(), self._stream()), "asdf_zoom_cube")
+        lattice_host = self._record_to_host(lattice.view(torch.int32))      # (behind the zoom kernel, IN FRONT of the fine sweep: its reader must not wait for that)
         rec2, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band_dev, "asdf_decode_grid_band_dev", N, None, None, grid_mode,
                                               hand, obj, tau, lattice=lattice)
         fine = {"kind": "band", "args": (N, None, None, grid_mode, hand, obj), "rec": rec2, "tau": tau, "epoch": self._recalibrations,
                 "host": self._record_to_host(rec2)}
-        return {"coarse": coarse, "fine": fine, "lattice": lattice, "lattice_host": self._record_to_host(lattice.view(torch.int32)),
-                "vol_hand": vh, "vol_obj": vo}
+        return {"coarse": coarse, "fine": fine, "lattice": lattice, "lattice_host": lattice_host, "vol_hand": vh, "vol_obj": vo}
 
     @classmethod
     def lattice_of(cls, ticket):

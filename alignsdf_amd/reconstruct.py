@@ -138,15 +138,12 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
                    if all(capacity(part) is not None for _, part in parts) else None)
         return t
 
-    def second_pass(ticket):
+    def second_pass(ticket, judged=None):
+        if "coarse" in ticket and judged is None:
+            # both passes are in flight already: nothing to launch, and nothing is READ here either - the records are judged when the
+            # sample is finished (surfaces), so the host never waits in the middle of the previous sample's post-processing
+            return {"pending": ticket}
         if "coarse" in ticket:
-            # both passes are in flight already: judge the coarse record (waits for that sweep alone); accepted - the usual case -
-            # means the fine pass ran on exactly the lattice the host arithmetic gives for these boxes (asdf_zoom_cube)
-            judged = hip.coarse_judge(ticket["coarse"])
-            if judged[0]:
-                origin, nvs = hip.lattice_of(ticket)
-                return {"vol_hand": ticket["vol_hand"], "vol_obj": ticket["vol_obj"], "voxel_size": nvs, "origin": origin, "bbox": judged[1],
-                        "fine_ticket": ticket["fine"], "mc_tickets": ticket["mc"]}
             b = hip.coarse_finish(ticket["coarse"], judged=judged)      # refused: an ordinary sweep now (the decoder is bound to this sample)
         else:
             # waits for pass 1 (the zoom cube is data dependent); a coarse sweep whose guards fired (fp16 range, or the error
@@ -166,6 +163,19 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
         never sit between a pass-1 read-back and the pass-2 launch (eval-mode trace: 1.3 ms of idle GPU per sample).  `rebound`
         tells it whether the decoder was re-bound to this sample."""
         rebound = False
+        spec = r.pop("pending", None)
+        if spec is not None:
+            # a sample that was enqueued in one go: judge its coarse record now (everything of it has long run).  Accepted - the usual
+            # case - means the fine pass ran on exactly the lattice the host arithmetic gives for these boxes (asdf_zoom_cube).
+            judged = hip.coarse_judge(spec["coarse"])
+            if judged[0]:
+                origin, nvs = hip.lattice_of(spec)
+                r.update({"vol_hand": spec["vol_hand"], "vol_obj": spec["vol_obj"], "voxel_size": nvs, "origin": origin, "bbox": judged[1],
+                          "fine_ticket": spec["fine"], "mc_tickets": spec["mc"]})
+            else:
+                bind(sample)                       # refused: this sample again, step by step
+                rebound = True
+                r.update(second_pass(spec, judged=judged))
         ticket = r.pop("fine_ticket", None)
 
         def begin_counts():

@@ -152,7 +152,9 @@ def test_three_refused_band_sweeps_in_a_row_switch_the_mode_off_and_lists_beyond
         for part in ("hand", "obj"):
             assert torch.equal(got[s]["verts_" + part], want[s]["verts_" + part]) and torch.equal(got[s]["faces_" + part], want[s]["faces_" + part])
     assert hip.band_stats["max_marked"] > hd.BAND_CAP and hip.box_stats["max_candidates"] > hd.CAND_CAP
-    assert hip.band_stats["fallback"] == 3 and hip.fine_mode == "exact"
-    assert hip.box_stats["fallback"] == 3 and hip.coarse_mode == "exact"
+    # three refusals IN A ROW switch a mode off; a sample that was already enqueued in one go when the third refusal was judged
+    # (round 5: a sample is judged when it is finished) adds one more refused sweep - never a delivered one
+    assert 3 <= hip.band_stats["fallback"] <= 4 and hip.fine_mode == "exact"
+    assert 3 <= hip.box_stats["fallback"] <= 4 and hip.coarse_mode == "exact"
     assert hip.band_stats["band"] == 0 and hip.box_stats["box"] == 0
     hip.close()

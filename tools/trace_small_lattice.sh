@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 N=${1:-64}; BR=${2:-hand}; S=${3:-64}
 O=$GRAFT_REPO_ROOT/gpurun_out/${R:-r3}/trace_small_${TAG:-nerf3}_$N; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/t -- python bench.py --tag ${TAG:-nerf3} --grid $N --branches $BR --steps $S --warmup 4 --no-cpu-baseline --no-other-math --no-other-sweeps --no-other-configs > $O/bench.json 2> $O/run.err
+rocprofv3 --kernel-trace --output-format csv -d $O/t -- python bench.py --tag ${TAG:-nerf3} --grid $N --branches $BR --steps $S --warmup 4 --no-cpu-baseline --no-other-math --no-other-sweeps --no-other-configs --sustained 0 > $O/bench.json 2> $O/run.err
 python3 - <<PY | tee $O/summary.txt
 import csv, glob, collections, json
 S = $S
