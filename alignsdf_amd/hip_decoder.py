@@ -842,7 +842,8 @@ class HipSdfDecoder:
     def lattice_of(cls, ticket):
         """(origin [3 python floats], voxel size as a 0-dim fp32 CPU tensor) of a two_pass_begin ticket - what
         utils.mesh.zoom_cube_from_bboxes returns for the same boxes, bit for bit."""
-        w = cls._record_of({"host": ticket["lattice_host"]}).view(np.float32)
+        host = ticket.get("lattice_host")
+        w = (cls._record_of({"host": host}) if host is not None else ticket["lattice"].view(torch.int32).cpu().numpy()).view(np.float32)
         return [float(w[0]), float(w[1]), float(w[2])], torch.tensor(w[3], dtype=torch.float32)
 
     # ---- the fine pass of the two-pass flow when its volumes go to marching cubes and nowhere else

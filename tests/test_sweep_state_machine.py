@@ -76,6 +76,14 @@ class FakeLib:
     def asdf_decode_grid_band(self, h, n, org, vs, mode, tau, sh, so, rec, stream):
         return self._one_plane("band", rec)
 
+    def asdf_decode_grid_band_dev(self, h, n, lattice, mode, tau, sh, so, rec, stream):
+        return self._one_plane("band_dev", rec)
+
+    def asdf_zoom_cube(self, bbox, n, vs, hand, obj, lattice, stream):
+        self.log.append(("zoom", self.dec.math))
+        (ctypes.c_float * 4).from_address(lattice)[:] = [-0.5, -0.25, -0.125, 0.0078125]
+        return 0
+
     def asdf_decoder_set_math(self, h, code):
         return 0
 
@@ -401,3 +409,79 @@ def test_tail_ladder_covers_small_audits(machine):
     dec.audit_voxels = 16
     assert dec._tail_for(N ** 3) == 1.5              # below the ladder: its smallest entry
     assert len(hd.HipSdfDecoder.LADDER) == 18 and hd.HipSdfDecoder.LADDER[0] == 1
+
+
+# ---- round 5: both passes of a sample enqueued in one go (two_pass_begin), judged afterwards -----------------------------------------------
+def test_two_pass_begin_enqueues_both_passes_and_is_judged_afterwards(machine):
+    dec, calls = machine
+    tau = dec._box_tau
+    assert dec.can_speculate(N)
+    dec._L.script = [good_record(tau), good_record(tau)]
+    since = dec._coarse_since_cal
+    t = dec.two_pass_begin(N, ARGS[2])
+    assert dec._L.log == [("box", "f16x3"), ("zoom", "f16x3"), ("band_dev", "f16x3")] and dec._coarse_since_cal == since + 1
+    assert t["coarse"]["kind"] == "box" and t["fine"]["kind"] == "band" and t["coarse"]["tau"] == t["fine"]["tau"] == tau
+    ok, b, _ = dec.coarse_judge(t["coarse"])
+    assert ok and b[:6].tolist() == [3, 4, 5, 20, 21, 22] and dec._L.log[3:] == []          # judging launches nothing
+    origin, nvs = dec.lattice_of(t)
+    assert origin == [-0.5, -0.25, -0.125] and float(nvs) == 0.0078125 and nvs.dtype == torch.float32
+    assert not dec.fine_needs_repeat(t["fine"])
+    assert dec.box_stats["box"] == 1 and dec.band_stats["band"] == 1 and dec.events["samples_in_one_go"] == 1
+    rep = dec.sweep_report()
+    assert rep["samples_enqueued_in_one_go"] == 1 and rep["sweeps_refused"] == 0 and rep["sweeps_audited"] == 2
+
+
+def test_a_refused_speculative_coarse_sweep_is_repeated_step_by_step(machine):
+    dec, calls = machine
+    tau = dec._box_tau
+    bad = good_record(tau)
+    _err(bad, tau)                                        # refused for its error: the allowance is void
+    dec._L.script = [bad, good_record(tau)]
+    t = dec.two_pass_begin(N, ARGS[2])
+    judged = dec.coarse_judge(t["coarse"])
+    assert judged[0] is False and judged[1] is None and dec.box_stats["fallback"] == 1 and dec.events["repeated_sweeps"] == 1
+    assert dec._L.log == [("box", "f16x3"), ("zoom", "f16x3"), ("band_dev", "f16x3")]          # still nothing launched by the verdict
+    b = dec.coarse_finish(t["coarse"], judged=judged)     # the caller has re-bound the sample: the ordinary repeat + a new comparison
+    assert dec._L.log[3:] == [("grid", "f16x3")] and calls == ["calibrate"] and b[:6].tolist() == [3, 4, 5, 20, 21, 22]
+    # the speculative fine sweep ran on a lattice nobody vouches for: its ticket is dropped unjudged, the fine pass goes step by step -
+    # and, the refusal having voided both comparisons, measures the zoom lattice again
+    assert not dec.can_speculate(N)
+    _, _, f = dec.fine_begin(*ARGS, mc_only=True)
+    assert f["kind"] == "exact" and "compare" in f and not dec.fine_needs_repeat(f) and calls[-1] == "calibrate_fine"
+    assert dec.can_speculate(N) and dec.band_stats["band"] == 0
+
+
+def test_no_speculation_while_a_comparison_is_due_or_a_mode_is_off(machine, monkeypatch):
+    dec, calls = machine
+    monkeypatch.setattr(hd, "RECAL_EVERY", 3)
+    tau = dec._box_tau
+    dec._L.script = [good_record(tau) for _ in range(12)]
+    took = []
+    for _ in range(5):
+        t = dec.two_pass_begin(N, ARGS[2])
+        took.append(t is not None)
+        if t is None:                                     # the step-by-step path takes the sample (and runs the comparison that is due)
+            c = dec.coarse_begin(*ARGS)
+            dec.coarse_finish(c)
+            _, _, f = dec.fine_begin(*ARGS, mc_only=True)
+            assert not dec.fine_needs_repeat(f)
+        else:
+            assert dec.coarse_judge(t["coarse"])[0] and not dec.fine_needs_repeat(t["fine"])
+    assert took == [True, True, True, False, True] and calls == ["calibrate"]      # (RECAL_EVERY = 3: the fourth sample runs the coarse comparison)
+    for attr, val in (("coarse_mode", "exact"), ("fine_mode", "exact"), ("_band_skip", True), ("_force_f32_once", True)):
+        keep = getattr(dec, attr)
+        setattr(dec, attr, val)
+        assert not dec.can_speculate(N) and dec.two_pass_begin(N, ARGS[2]) is None, attr
+        setattr(dec, attr, keep)
+    assert dec.can_speculate(N) and not dec.can_speculate(4 * N)          # a lattice 64 x the compared ones needs its own comparisons
+
+
+def test_a_speculative_ticket_launched_under_old_scales_is_not_judged(machine):
+    dec, calls = machine
+    tau = dec._box_tau
+    dec._L.script = [good_record(tau), good_record(tau)]
+    t = dec.two_pass_begin(N, ARGS[2])
+    dec._recalibrations += 1                              # the activation scales were re-calibrated while the sample was in flight
+    ok, b, cal = dec.coarse_judge(t["coarse"])
+    assert not ok and cal and dec._box_failures == 0 and dec.cert["refusals_for_error"] == 0
+    assert dec.fine_needs_repeat(t["fine"]) and dec._band_failures == 0
