@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 124        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 125        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -27,7 +27,7 @@ EXPORTS = (
     "asdf_debug_pack_host", "asdf_decoder_set_classifier", "asdf_decode_points_cls",
     "asdf_icp_ts_enqueue", "asdf_icp_ts_result", "asdf_chamfer",
     "asdf_decoder_set_math", "asdf_decoder_get_math", "asdf_debug_pack_host_f16",
-    "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_decoder_set_short_list", "asdf_decoder_one_plane_usable", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
+    "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_decoder_set_short_list", "asdf_decoder_set_cluster_list", "asdf_decoder_one_plane_usable", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
     "asdf_zoom_cube", "asdf_decode_grid_band_dev", "asdf_decode_grid_dev", "asdf_mc_emit_bounded",
 )
 MATH_F32, MATH_F16X3 = 0, 1
@@ -113,6 +113,7 @@ def lib():
     L.asdf_decoder_set_refine.argtypes = [vp, f32]
     L.asdf_decoder_set_audit.argtypes = [vp, i32, ctypes.c_uint64]
     L.asdf_decoder_set_short_list.argtypes = [vp, i32]
+    L.asdf_decoder_set_cluster_list.argtypes = [vp, i32]
     L.asdf_decoder_one_plane_usable.argtypes = [vp]
     L.asdf_decoder_time_next_sweep.argtypes = [vp, vp, vp]
     L.asdf_decoder_set_act_scales.argtypes = [vp, ctypes.POINTER(f32), vp]

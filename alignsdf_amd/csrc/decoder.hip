@@ -30,11 +30,13 @@ struct FoldParams {
   const float* bias02;   // [heads][2][512]
   const float* embed;    // [heads][ASDF_MAX_POINT_FEATS][4]
   const float* latent;   // [256]
-  float* cst;            // [heads][cst_offsets(kp).floats]
+  // up to three constants images are folded by ONE launch (blockIdx.y picks the image): the fp32 image, the split-half image and
+  // the one-plane image differ in the scales only (they were three launches per sample)
+  float* cst[3];         // [heads][cst_offsets(kp).floats]
   int pf[ASDF_MAX_HEADS];
   int kp;                // point-feature K-steps (2 = affine xyz: the A fragments are folded here; > 2 = NeRF: static)
-  float s2[ASDF_MAX_HEADS];   // scale of the layer-2 constants: 1 for the fp32 image, S_w2 S_x for the split-half image
-  float s0[ASDF_MAX_HEADS];   // scale of the layer-0 constants: 1, except in the one-plane image (S_x of h0: its accumulators need no rescale)
+  float s2[3][ASDF_MAX_HEADS];   // scale of the layer-2 constants: 1 for the fp32 image, S_w2 S_x for the split-half image
+  float s0[3][ASDF_MAX_HEADS];   // scale of the layer-0 constants: 1, except in the one-plane image (S_x of h0: its accumulators need no rescale)
 };
 
 __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
@@ -60,9 +62,10 @@ __global__ __launch_bounds__(256) void fold_sample_kernel(const FoldParams p) {
   const float a3 = __shfl(a, 3);
 
   const CstOffsets co = cst_offsets(p.kp);
-  float* cst = p.cst + (size_t)head * co.floats;
+  const int img = blockIdx.y;
+  float* cst = p.cst[img] + (size_t)head * co.floats;
   const int t = row >> 5, rr = row & 31;
-  const float sc = layer ? p.s2[head] : p.s0[head];      // a power of two: the scaled values are exact
+  const float sc = layer ? p.s2[img][head] : p.s0[img][head];      // a power of two: the scaled values are exact
   if (lane == 0) {
     const float c = (dot + p.bias02[(head * 2 + layer) * kHidden + row]) + (p.kp == 2 ? a3 : 0.0f);
     const int hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
@@ -410,7 +413,11 @@ __global__ __launch_bounds__(256) void band_mark_kernel(const float* __restrict_
 
 // marked voxels -> index list (order arbitrary); *count counts all of them, also those beyond cap.  One reservation on the count
 // word per WORKGROUP and round (wave scans + an LDS hand-over): half a million marked voxels used to be ~1e5 same-address atomics.
-__global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* __restrict__ mark, long long n, int* idx, int* count, int cap) {
+// `done` / `count_copy` (optional): the last workgroup to finish copies the final count to *count_copy - the first audit position of the
+// list (the audit picks are appended behind the marked voxels); *done must be zero at launch (sweep_init_kernel).  Was a separate
+// 4-byte device-to-device copy per head.
+__global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* __restrict__ mark, long long n, int* idx, int* count, int cap,
+                                                           int* done, int* count_copy) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long items = (n + 15) / 16;
   const long long rounds = (items + stride - 1) / stride;
@@ -453,6 +460,10 @@ __global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* 
     }
     __syncthreads();
   }
+  if (done && threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(done, 1) == (int)gridDim.x - 1) *count_copy = atomicAdd(count, 0);
+  }
 }
 
 // near-level voxels among the LISTED ones of one volume (the narrow-band sweep refines only where it re-evaluated)
@@ -483,8 +494,24 @@ __device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long 
 }
 __global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const unsigned char* __restrict__ mark, long long P, float tau,
-                                                         unsigned long long seed, int n, int* list, int* count, int cap) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+                                                         unsigned long long seed, int n, int* list, int* count, int cap);
+
+// The AT-RISK SHELL of a one-plane sweep (round 4): of the voxels a sweep decides by sign alone, only those whose one-plane value
+// lies close to the decision threshold can be decided wrongly by an error of the allowance's order - tau <= |v| < 2 tau.  A uniform
+// draw spends a fraction of a percent of its picks there; half of the audit is therefore drawn FROM the shell: it is counted
+// (shell_count_kernel) and then listed - every shell voxel while the shell is smaller than the budget (an exhaustive check), a
+// hash-thinned uniform subset of expected size `budget` otherwise (shell_pick_kernel).  Band sweep: unmarked voxels of one head's
+// volume (unmarked implies |v| >= tau); box sweep: voxels every evaluated head leaves outside [-tau, tau), some head inside 2 tau.
+__device__ __forceinline__ bool in_audit_shell(const float* __restrict__ a, const float* __restrict__ b,
+                                               const unsigned char* __restrict__ mark, long long v, float tau) {
+  if (mark) return mark[v] == 0 && (fabsf(a[v]) < 2.0f * tau || (b && fabsf(b[v]) < 2.0f * tau));      // (b: a CombinedDecoder's second column)
+  bool decided = true, close = false;
+  if (a) { const float t = a[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
+  if (b) { const float t = b[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
+  return decided && close;
+}
+__device__ __forceinline__ void audit_pick_block(int k, const float* __restrict__ a, const float* __restrict__ b, const unsigned char* __restrict__ mark,
+                                                 long long P, float tau, unsigned long long seed, int n, int* list, int* count, int cap) {
   bool ok = k < n;
   long long v = 0;
   if (ok) {
@@ -504,24 +531,21 @@ __global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict
   const int at = base + __popcll(m & ((1ull << lane) - 1));
   if (ok && at < cap) list[at] = (int)v;
 }
-
-// The AT-RISK SHELL of a one-plane sweep (round 4): of the voxels a sweep decides by sign alone, only those whose one-plane value
-// lies close to the decision threshold can be decided wrongly by an error of the allowance's order - tau <= |v| < 2 tau.  A uniform
-// draw spends a fraction of a percent of its picks there; half of the audit is therefore drawn FROM the shell: it is counted
-// (shell_count_kernel) and then listed - every shell voxel while the shell is smaller than the budget (an exhaustive check), a
-// hash-thinned uniform subset of expected size `budget` otherwise (shell_pick_kernel).  Band sweep: unmarked voxels of one head's
-// volume (unmarked implies |v| >= tau); box sweep: voxels every evaluated head leaves outside [-tau, tau), some head inside 2 tau.
-__device__ __forceinline__ bool in_audit_shell(const float* __restrict__ a, const float* __restrict__ b,
-                                               const unsigned char* __restrict__ mark, long long v, float tau) {
-  if (mark) return mark[v] == 0 && (fabsf(a[v]) < 2.0f * tau || (b && fabsf(b[v]) < 2.0f * tau));      // (b: a CombinedDecoder's second column)
-  bool decided = true, close = false;
-  if (a) { const float t = a[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
-  if (b) { const float t = b[v]; decided = decided && !(t >= -tau && t < tau); close = close || fabsf(t) < 2.0f * tau; }
-  return decided && close;
+__global__ __launch_bounds__(256) void audit_pick_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const unsigned char* __restrict__ mark, long long P, float tau,
+                                                         unsigned long long seed, int n, int* list, int* count, int cap) {
+  audit_pick_block(blockIdx.x * blockDim.x + threadIdx.x, a, b, mark, P, tau, seed, n, list, count, cap);
 }
+// workgroups 0 .. shell_blocks - 1 count the shell; the ones behind them draw the `uniform_n` uniform picks (audit_pick_kernel's draw:
+// the two were separate launches - the small lattices notice every launch)
 __global__ __launch_bounds__(256) void shell_count_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          const unsigned char* __restrict__ mark, long long P, float tau, int* shell_n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
+                                                          const unsigned char* __restrict__ mark, long long P, float tau, int* shell_n,
+                                                          int shell_blocks, unsigned long long seed, int uniform_n, int* list, int* count, int cap) {
+  if ((int)blockIdx.x >= shell_blocks) {
+    audit_pick_block(((int)blockIdx.x - shell_blocks) * blockDim.x + threadIdx.x, a, b, mark, P, tau, seed, uniform_n, list, count, cap);
+    return;
+  }
+  const long long stride = (long long)shell_blocks * blockDim.x;
   int c = 0;
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < P; v += stride) c += in_audit_shell(a, b, mark, v, tau) ? 1 : 0;
 #pragma unroll
@@ -660,12 +684,18 @@ struct asdf_decoder {
   // lists), and the voxel list of the box sweep's audit
   int audit_n;
   unsigned long long audit_seed;
-  int* audit_rec;   // [8]
+  int* audit_rec;   // [12]: [0..7] the record, [8] / [9] shell population per use, [10] / [11] band compaction done-counters
   int* audit_idx;   // [kAuditCap]
   int* audit_count;
-  int* shell_count; // device word: population of the at-risk shell of the sweep being audited
   int short_max;    // voxel lists of up to this many points are re-evaluated by the short-list form of the fp32 chain (0 = never)
+  // ... and the shortest ones by its cluster form (four workgroups per 32 points): exchange buffers and arrival counters of
+  // kShortClusters clusters (asdf_decoder_set_cluster_list)
+  ShortParams shortp;
+  // the audit of a box sweep runs beside the exact re-evaluation of its candidates (round 5)
+  hipStream_t audit_side;
+  hipEvent_t ev_audit_fork, ev_audit_join;
 };
+static constexpr int kShortClusters = kClusterCap / kWavePts * kHeads;      // 128
 static constexpr int kNearCap = 1 << 16;      // near-level refinement list of a split-half sweep
 static constexpr int kCandCap = 1 << 21;      // box candidates of asdf_decode_grid_box (a head without a certainly negative voxel - a thin
                                               // or tiny shape - lists its whole surface shell); shares near_idx
@@ -745,7 +775,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 124; }
+int asdf_version(void) { return 125; }
 
 const char* asdf_strerror(int code) {
   switch (code) {
@@ -778,6 +808,11 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   if (!d) return;
   float* bufs[] = {d->stream, d->wlat, d->wpt, d->bias02, d->cst, d->embed, d->cls, d->stream16, d->cst16, d->stream16_hi, d->a16, d->cst16p1};
   if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
+  if (d->audit_side) { (void)hipStreamSynchronize(d->audit_side); (void)hipStreamDestroy(d->audit_side); }
+  if (d->ev_audit_fork) (void)hipEventDestroy(d->ev_audit_fork);
+  if (d->ev_audit_join) (void)hipEventDestroy(d->ev_audit_join);
+  if (d->shortp.xchg) (void)hipFree(d->shortp.xchg);
+  if (d->shortp.arrivals) (void)hipFree(d->shortp.arrivals);
   if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
   if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   if (d->band_mark) (void)hipFree(d->band_mark);
@@ -791,7 +826,6 @@ void asdf_decoder_destroy(asdf_decoder_t* d) {
   (void)hipFree(d->audit_rec);
   (void)hipFree(d->audit_idx);
   (void)hipFree(d->audit_count);
-  (void)hipFree(d->shell_count);
   std::free(d->cst_host);
   std::free(d->cst16_host);
   std::free(d->cst16p1_host);
@@ -878,13 +912,19 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) e = hipMemset(d->status, 0, 16 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_idx, kCandCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->near_count, sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void**)&d->audit_rec, 8 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->audit_rec, 12 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->audit_idx, kAuditCap * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&d->audit_count, sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void**)&d->shell_count, sizeof(int));
   d->audit_n = 1 << 16;
   d->audit_seed = 0x5DF5A11D00000000ull;
   d->short_max = 8192;
+  d->shortp.cluster_max = kClusterCap;
+  if (e == hipSuccess) e = hipMalloc((void**)&d->shortp.xchg, (size_t)kShortClusters * kXchgFloats * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->shortp.arrivals, (size_t)kShortClusters * 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(d->shortp.arrivals, 0, (size_t)kShortClusters * 4 * sizeof(int));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->audit_side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_audit_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_audit_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
@@ -941,23 +981,28 @@ int asdf_decoder_set_sample(asdf_decoder_t* d, const float* latent_dev, const fl
                             hipMemcpyHostToDevice, st));
   }
   FoldParams fp;
-  fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev; fp.cst = d->cst;
-  for (int h = 0; h < kHeads; ++h) { fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0; fp.s2[h] = 1.0f; fp.s0[h] = 1.0f; }
+  fp.wlat = d->wlat; fp.wpt = d->wpt; fp.bias02 = d->bias02; fp.embed = d->embed; fp.latent = latent_dev;
   fp.kp = d->kp;
-  hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+  int images = 1;
+  fp.cst[0] = d->cst; fp.cst[1] = fp.cst[2] = nullptr;
+  for (int h = 0; h < kHeads; ++h) {
+    fp.pf[h] = h < d->spec.num_heads ? d->spec.point_feats[h] : 0;
+    for (int i = 0; i < 3; ++i) { fp.s2[i][h] = 1.0f; fp.s0[i][h] = 1.0f; }
+  }
   if (d->cst16) {      // the same fold into the split-half image, layer-2 constants scaled
-    fp.cst = d->cst16;
-    for (int h = 0; h < kHeads; ++h) fp.s2[h] = d->s2[h];
-    hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
+    fp.cst[1] = d->cst16;
+    for (int h = 0; h < kHeads; ++h) fp.s2[1][h] = d->s2[h];
+    images = 2;
     if (d->cst16p1) {
       // ... and into the one-plane image (its own scales), whose layer-0 constants then become the kernels' fp16 point-feature /
       // bias operands (affine features; the NeRF-encoded kernels read them from the constants block as they are)
-      fp.cst = d->cst16p1;
-      for (int h = 0; h < kHeads; ++h) { fp.s2[h] = d->s2p[h]; fp.s0[h] = d->s0p[h]; }
-      hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4), dim3(256), 0, st, fp);
-      if (d->a16) hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16p1, d->a16, d->status);
+      fp.cst[2] = d->cst16p1;
+      for (int h = 0; h < kHeads; ++h) { fp.s2[2][h] = d->s2p[h]; fp.s0[2][h] = d->s0p[h]; }
+      images = 3;
     }
   }
+  hipLaunchKernelGGL(fold_sample_kernel, dim3(d->spec.num_heads * 2 * kHidden / 4, images), dim3(256), 0, st, fp);
+  if (images == 3 && d->a16) hipLaunchKernelGGL(fold_points_f16_kernel, dim3(d->spec.num_heads * 2), dim3(512), 0, st, d->cst16p1, d->a16, d->status);
   ASDF_HIP(hipGetLastError());
   d->sample_bound = true;
   return ASDF_OK;
@@ -970,7 +1015,9 @@ static int launch_subset(asdf_decoder* d, const DecodeParams& q_in, bool two_out
     // short lists (the usual case of a near-level refinement: a few dozen to a few hundred voxels) take the short-list form - a
     // quarter of the tile form's latency; both are enqueued, the device-side count decides which one runs (bit-identical results)
     q.short_max = d->short_max;
-    k1_short_launch(two_out, q, st);
+    ShortParams sp = d->shortp;
+    if (sp.cluster_max > d->short_max) sp.cluster_max = d->short_max;
+    k1_short_launch(two_out, q, sp, st);
   }
   if (two_out || q.num_mlps != 2 || !q.sdf0 || !q.sdf1 || !d->side) {
     k1_launch(d->kp, two_out, q, grid, st);
@@ -1143,18 +1190,22 @@ static int audit_size(const asdf_decoder* d, long long P) {
   return (long long)d->audit_n < cap ? d->audit_n : (int)cap;
 }
 static int enqueue_audit_picks(asdf_decoder* d, const float* a, const float* b, const unsigned char* mark, long long P, float tau,
-                               int* list, int* count, int cap, hipStream_t st) {
+                               int* list, int* count, int cap, int use, hipStream_t st) {
   const int n = audit_size(d, P);
   if (n <= 0) return ASDF_OK;
   const int uniform = n - n / 2, budget = n / 2;
-  hipLaunchKernelGGL(audit_pick_kernel, dim3((uniform + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed, uniform,
-                     list, count, cap);
   if (budget > 0) {
-    ASDF_HIP(hipMemsetAsync(d->shell_count, 0, sizeof(int), st));
+    // (the shell population of this use - head `use` of a band sweep, 0 for a box sweep - is audit_rec[8 + use]: cleared with the
+    // record by sweep_init_kernel)
+    int* shell_n = d->audit_rec + 8 + use;
     const int sgrid = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
-    hipLaunchKernelGGL(shell_count_kernel, dim3(sgrid), dim3(256), 0, st, a, b, mark, P, tau, d->shell_count);
+    hipLaunchKernelGGL(shell_count_kernel, dim3(sgrid + (uniform + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, shell_n, sgrid,
+                       d->audit_seed, uniform, list, count, cap);
     hipLaunchKernelGGL(shell_pick_kernel, dim3(sgrid), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed ^ 0xA5A5A5A55A5A5A5Aull, budget,
-                       d->shell_count, list, count, cap, d->audit_rec);
+                       shell_n, list, count, cap, d->audit_rec);
+  } else {
+    hipLaunchKernelGGL(audit_pick_kernel, dim3((uniform + 255) / 256), dim3(256), 0, st, a, b, mark, P, tau, d->audit_seed, uniform,
+                       list, count, cap);
   }
   ASDF_HIP(hipGetLastError());
   d->audit_seed = d->audit_seed * 6364136223846793005ull + 1442695040888963407ull;
@@ -1201,7 +1252,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   // the box record, the candidate count, status [1] candidates beyond the list / [2] contradiction flag / [3] largest
   // |exact - one-plane|, the audit record and the audit pick count (none of them is touched by the sweep kernel itself)
   hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, st, p.bbox, ClearRange{d->near_count, 1}, ClearRange{d->status + 1, 3},
-                     ClearRange{d->audit_rec, 8}, ClearRange{d->audit_count, 1});
+                     ClearRange{d->audit_rec, 12}, ClearRange{d->audit_count, 1});
   const long long ntiles = (p.P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
@@ -1210,15 +1261,27 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   if (d->ev_stop) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_stop, st));
   d->ev_start = d->ev_stop = nullptr;
   // audit: voxels both heads decided by sign alone, drawn at random, through the split-half kernel (the arithmetic of the
-  // ordinary sweep) - they report the error of the one-plane values where nothing else looks
+  // ordinary sweep) - they report the error of the one-plane values where nothing else looks.  The picks are drawn here, in
+  // order; their evaluation (a latency-bound launch on the small lattices: one 128-point tile per compute unit or less) runs on
+  // the decoder's audit stream beside the candidates below - it reads the volume at the picks (never candidates: |v| >= tau) and
+  // writes only the audit record, which nothing reads before the join in front of sweep_record_kernel
+  bool audit_forked = false;
   if (d->audit_n > 0) {
-    { const int rc = enqueue_audit_picks(d, p.sdf0, p.sdf1, nullptr, p.P, tau, d->audit_idx, d->audit_count, kAuditCap, st); if (rc != ASDF_OK) return rc; }
+    { const int rc = enqueue_audit_picks(d, p.sdf0, p.sdf1, nullptr, p.P, tau, d->audit_idx, d->audit_count, kAuditCap, 0, st); if (rc != ASDF_OK) return rc; }
     DecodeParams a = p;
     a.stream = d->stream16; a.cst = d->cst16; a.bbox = nullptr; a.neg_thr = 0.0f;
     a.mode = kGridSubset; a.grid_mode = p.mode; a.idx = d->audit_idx; a.count_dev = d->audit_count; a.P = kAuditCap;
     a.audit = d->audit_rec; a.audit_from = nullptr;
     const int agrid = kAuditCap / kWgPts < d->num_cus ? kAuditCap / kWgPts : d->num_cus;
-    k1h_subset_launch(d->kp, two_out, a, agrid, st);
+    hipStream_t as = st;
+    if (d->audit_side && !std::getenv("ASDF_AUDIT_INLINE")) {
+      ASDF_HIP(hipEventRecord(d->ev_audit_fork, st));
+      ASDF_HIP(hipStreamWaitEvent(d->audit_side, d->ev_audit_fork, 0));
+      as = d->audit_side;
+      audit_forked = true;
+    }
+    k1h_subset_launch(d->kp, two_out, a, agrid, as);
+    if (audit_forked) ASDF_HIP(hipEventRecord(d->ev_audit_join, d->audit_side));
   }
   // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
   const long long items = (N & 3) == 0 ? p.P / 4 : p.P;
@@ -1260,6 +1323,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
     hipLaunchKernelGGL(extend_box_from_list_kernel, dim3(256), dim3(256), 0, st, p.sdf0, p.sdf1, d->near_idx, twostep_count, N, p.bbox);
   }
   // the record of this call travels with the boxes: one read-back for the caller
+  if (audit_forked) ASDF_HIP(hipStreamWaitEvent(st, d->ev_audit_join, 0));
   hipLaunchKernelGGL(sweep_record_kernel, dim3(1), dim3(64), 0, st, bbox_dev, d->status, d->near_count, d->audit_rec);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;
@@ -1299,7 +1363,7 @@ static int decode_grid_band_impl(asdf_decoder_t* d, int32_t N, const float* orig
   // the record, the two band counts, status [1] near-level voxels beyond the list / [3] largest |exact - one-plane| of this call,
   // the audit record and the near-level count
   hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, st, p.bbox, ClearRange{d->band_count, 2}, ClearRange{d->status + 1, 3},
-                     ClearRange{d->audit_rec, 8}, ClearRange{d->near_count, 1});
+                     ClearRange{d->audit_rec, 12}, ClearRange{d->near_count, 1});
   const long long ntiles = (P + kWgPts - 1) / kWgPts;
   const int grid = (int)(ntiles < d->num_cus ? ntiles : d->num_cus);
   if (d->ev_start) ASDF_HIP(hipEventRecord((hipEvent_t)d->ev_start, st));
@@ -1321,11 +1385,11 @@ static int decode_grid_band_impl(asdf_decoder_t* d, int32_t N, const float* orig
     const long long items = (P + 15) / 16;
     const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     int* list = d->band_idx + (size_t)h * kBandCap;
-    hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, list, d->band_count + h, kBandCap);
     // the audit picks of this head - unmarked voxels, i.e. voxels marching cubes will read the SIGN of and nothing else - ride
-    // behind the marked ones in the same list (positions >= audit_rec[4 + h])
-    ASDF_HIP(hipMemcpyAsync(d->audit_rec + 4 + h, d->band_count + h, sizeof(int), hipMemcpyDeviceToDevice, st));
-    { const int rc = enqueue_audit_picks(d, vols[h], two_out ? vols[1] : nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, st); if (rc != ASDF_OK) return rc; }
+    // behind the marked ones in the same list (positions >= audit_rec[4 + h]: the compaction's last workgroup writes that word)
+    hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, list, d->band_count + h, kBandCap,
+                       d->audit_rec + 10 + h, d->audit_rec + 4 + h);
+    { const int rc = enqueue_audit_picks(d, vols[h], two_out ? vols[1] : nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, h, st); if (rc != ASDF_OK) return rc; }
     // the values of the ordinary sweep at the listed voxels of this head: the split-half kernel over the list ...
     DecodeParams q = p;
     q.stream = d->stream16; q.cst = d->cst16; q.bbox = nullptr; q.neg_thr = 0.0f;
@@ -1373,6 +1437,12 @@ int asdf_decoder_one_plane_usable(const asdf_decoder_t* d) { return d && d->stre
 int asdf_decoder_set_short_list(asdf_decoder_t* d, int32_t max_points) {
   if (!d || max_points < 0 || max_points > (1 << 16)) return ASDF_EINVAL;
   d->short_max = max_points;
+  return ASDF_OK;
+}
+
+int asdf_decoder_set_cluster_list(asdf_decoder_t* d, int32_t max_points) {
+  if (!d || max_points < 0 || max_points > kClusterCap) return ASDF_EINVAL;
+  d->shortp.cluster_max = max_points;
   return ASDF_OK;
 }
 

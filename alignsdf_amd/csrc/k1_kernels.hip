@@ -12,8 +12,8 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_nerf15_kernel(const DecodePara
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf9_kernel(const DecodeParams p) { sdf_mlp_body<0, 5, true>(p); }
 __global__ __launch_bounds__(256, 1) void sdf_mlp_combined_nerf15_kernel(const DecodeParams p) { sdf_mlp_body<0, 8, true>(p); }
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_short_kernel(const DecodeParams p) { sdf_mlp_short_body<false>(p); }
-__global__ __launch_bounds__(256, 1) void sdf_mlp_short_combined_kernel(const DecodeParams p) { sdf_mlp_short_body<true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_short_kernel(const DecodeParams p, const ShortParams sp) { sdf_mlp_short_body<false>(p, sp); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_short_combined_kernel(const DecodeParams p, const ShortParams sp) { sdf_mlp_short_body<true>(p, sp); }
 
 hipError_t k1_prepare() {
   hipError_t e = hipSuccess;
@@ -40,11 +40,14 @@ void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_
   }
 }
 
-// the short-list form: one workgroup per 32 listed points and MLP, p.short_max / 32 of them per MLP (those beyond the list return)
-void k1_short_launch(bool two_out, const DecodeParams& p, hipStream_t st) {
-  const dim3 grid((p.short_max + kWavePts - 1) / kWavePts, p.num_mlps);
-  if (two_out) hipLaunchKernelGGL(sdf_mlp_short_combined_kernel, grid, dim3(256), kLdsBytesShort, st, p);
-  else hipLaunchKernelGGL(sdf_mlp_short_kernel, grid, dim3(256), kLdsBytesShort, st, p);
+// the short-list form: one workgroup per 32 listed points and MLP, p.short_max / 32 of them per MLP - or, for lists of up to
+// sp.cluster_max points, four per block (sdf_mlp_short_kernel.h); workgroups beyond the list return
+void k1_short_launch(bool two_out, const DecodeParams& p, const ShortParams& sp, hipStream_t st) {
+  const int units = (p.short_max + kWavePts - 1) / kWavePts * p.num_mlps;
+  const int clusters = ((sp.cluster_max + kWavePts - 1) / kWavePts * p.num_mlps + 7) / 8 * 8;
+  const dim3 grid(units > clusters * kClusterWgs ? units : clusters * kClusterWgs);
+  if (two_out) hipLaunchKernelGGL(sdf_mlp_short_combined_kernel, grid, dim3(256), kLdsBytesShort, st, p, sp);
+  else hipLaunchKernelGGL(sdf_mlp_short_kernel, grid, dim3(256), kLdsBytesShort, st, p, sp);
 }
 
 }  // namespace asdf

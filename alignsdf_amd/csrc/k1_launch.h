@@ -7,6 +7,17 @@
 
 namespace asdf {
 
+// the cluster form of the short-list kernel (sdf_mlp_short_kernel.h)
+constexpr int kClusterWgs = 4;                                                 // workgroups per 32-point block in the cluster form
+constexpr int kClusterCap = 2048;                                              // longest list the cluster form takes (64 blocks per MLP)
+constexpr int kXchgTiles = kTilesL1 + 2 * kTilesHidden;                        // h1 (8 tiles), h2 (16), raw layer-3 accumulators (16)
+constexpr int kXchgFloats = kXchgTiles * 64 * 16;                              // 160 KiB per cluster
+struct ShortParams {
+  float* xchg;          // [clusters][kXchgFloats]
+  int* arrivals;        // [clusters][4] (three in use): multiples of 4 between launches
+  int cluster_max;      // lists of up to this many points take the cluster form (0 = never)
+};
+
 // raise the dynamic-LDS limit of the family's kernels (once per process; cheap)
 hipError_t k1_prepare();
 hipError_t k1_cls_prepare();
@@ -18,8 +29,8 @@ hipError_t k1s_nerf_prepare();      // the one-plane kernels of the NeRF-encoded
 // kp = point-feature K-steps (2 affine xyz, 5 / 8 NeRF encoding of 9 / 15 features); two_out = CombinedDecoder
 void k1_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 // the fp32 chain over a SHORT voxel list (kGridSubset, kp == 2): one workgroup per 32 points and MLP, output tiles spread over its
-// waves (sdf_mlp_short_kernel.h); returns at once for lists longer than p.short_max
-void k1_short_launch(bool two_out, const DecodeParams& p, hipStream_t st);
+// waves - or, for the shortest lists, four workgroups per block (sdf_mlp_short_kernel.h); returns at once for lists longer than p.short_max
+void k1_short_launch(bool two_out, const DecodeParams& p, const ShortParams& sp, hipStream_t st);
 void k1_cls_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);
 void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel (k1s_kernels.hip), kp == 2 only; p.stream = high planes

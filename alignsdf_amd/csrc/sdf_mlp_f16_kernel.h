@@ -993,7 +993,9 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             const int d = __float_as_int(fabsf(now - before));
             if (aud) { da = max(da, d); flips += ((before < 0.0f) != (now < 0.0f)) ? 1 : 0; ++na; sq += (now - before) * (now - before); }
             else dm = max(dm, d);
-            vol[po] = now;
+            // (a list of audit picks alone - the box sweep's - leaves the scratch volume as the one-plane kernel wrote it: that audit
+            // runs BESIDE the collection of the sweep's candidates, which reads the same volume; round 5)
+            if (!aud || p.audit_from) vol[po] = now;
           };
           float* out = is_hand ? p.sdf0 : p.sdf1;
           if (out) replace(out, sdf);

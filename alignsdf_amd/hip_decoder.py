@@ -295,6 +295,8 @@ class HipSdfDecoder:
         self.events = {"repeated_sweeps": 0, "modes_switched_off": [], "fp32_fallback": False, "samples_in_one_go": 0}
         self.event_log = None      # set to a list to collect (start, end) torch.cuda.Event pairs around every K1 launch
         self.box_event_log = None  # the same for the one-plane kernel of the box / band sweeps, plus the sweep's record tensor
+        self.box_event_stride = 1  # ... around every box_event_stride-th of them (four event records per sweep are a few percent of a 64^3 sample)
+        self._box_event_tick = 0
 
     @staticmethod
     def _new_stats(kind):
@@ -565,7 +567,8 @@ class HipSdfDecoder:
         org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3]) if lattice is None else None
         with torch.cuda.device(self.device):
             ev = None
-            if self.box_event_log is not None:
+            self._box_event_tick += 1
+            if self.box_event_log is not None and self._box_event_tick % self.box_event_stride == 0:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
                 ev[1].record()

@@ -508,6 +508,8 @@ def main():
             if world > 1:
                 dist.barrier()
             dec.event_log, dec.box_event_log = [], []
+            # (N < 256: the one-plane kernel is timed on every 8th sweep - the two event pairs per sweep cost 0.1 ms of a 1 ms sample)
+            dec.box_event_stride = 1 if n >= 256 else 8
             t0 = time.perf_counter()
             done = self.run(first, count, n, keep_meshes)
             torch.cuda.synchronize(dev)
@@ -542,7 +544,10 @@ def main():
         dec.fine_mode = args.fine
 
     # ---- the timed region: K whole samples under the product's defaults
-    elapsed, k1_ms, done, p1_ms = cfg.timed(args.warmup, args.steps, args.warmup, N, keep_meshes=(world == 1))
+    # (the meshes of the timed samples are kept only when a later leg compares them vertex for vertex: every kept surface pins its
+    # allocator block, the next sample's buffers are then fresh device allocations - 0.3 ms per sample at N = 64, a third of the step)
+    keep = world == 1 and not (args.no_other_math and args.no_other_sweeps)
+    elapsed, k1_ms, done, p1_ms = cfg.timed(args.warmup, args.steps, args.warmup, N, keep_meshes=keep)
     p1_ticks = list(getattr(cfg, "p1_ticks", []))
     # (ordinary sweeps in the timed region: the split-half kernel's own clock stamps, read before any other leg launches it again)
     main_clocks = (kernel_clocks(dec, k1_ms, N, meshes_per_sample, EXEC_F16_FLOP_PER_POINT_HEAD, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD)
@@ -586,7 +591,7 @@ def main():
     # ---- dominant kernel of the timed region: timed with HIP events recorded by the library around that kernel on the launch
     # stream.  Under the default sweeps it is the one-plane kernel (2 launches per sample); with --coarse exact --fine exact the
     # split-half kernel (or the fp32 one with --math f32).
-    one_plane_main = bool(p1_ms) and len(p1_ms) >= len(k1_ms)
+    one_plane_main = bool(p1_ms) and len(p1_ms) * dec.box_event_stride >= len(k1_ms)
     alg_flop = N ** 3 * meshes_per_sample * FLOP_PER_POINT_HEAD
     split = dec.math == "f16x3"
     if one_plane_main:

@@ -234,6 +234,13 @@ int asdf_decoder_set_refine(asdf_decoder_t* dec, float tau);
  * with affine point features. */
 int asdf_decoder_set_short_list(asdf_decoder_t* dec, int32_t max_points);
 
+/* ... and the SHORTEST lists (up to max_points voxels, default and at most 2048; 0 = never; effective limit min(max_points, the
+ * short-list limit above)): the same launch gives each block of 32 points to a cluster of four workgroups on one XCD - one output
+ * tile per wave and layer, the layers' activations exchanged through device memory behind agent-scope release / acquire - so the
+ * longest dependent chain is 642 MFMAs instead of 2064 (0.10 -> about 0.04 ms per launch; two launches per sample, which is a
+ * sixth of a 64^3 sample).  Bit-identical to the other two forms (per-tile instruction sequence unchanged). */
+int asdf_decoder_set_cluster_list(asdf_decoder_t* dec, int32_t max_points);
+
 /* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed
  * as void*, created by the caller with timing enabled) immediately before and after the launch of its dominant kernel
  * (sdf_mlp_f16_kernel or sdf_mlp_kernel) on the call's stream - not around the small kernels next to it (bbox

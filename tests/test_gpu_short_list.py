@@ -27,8 +27,10 @@ def _bound(tag, sample=0):
     return hip
 
 
-def _short(hip, n):
+def _short(hip, n, cluster=0):
+    """Lists of up to `n` voxels take the short-list form, of up to `cluster` its cluster form (four workgroups per 32 voxels)."""
     _native.check(hip._L.asdf_decoder_set_short_list(hip._h, int(n)), "asdf_decoder_set_short_list")
+    _native.check(hip._L.asdf_decoder_set_cluster_list(hip._h, int(cluster)), "asdf_decoder_set_cluster_list")
 
 
 @pytest.mark.parametrize("tag", ["nerf3", "both9", "grasp3", "comb3"])
@@ -41,15 +43,16 @@ def test_near_level_refinement_is_bit_identical_in_both_forms(tag, refine):
     origin, vs = [-0.62, -0.36, -0.37], 1.21 / (N - 1)
     hip.set_refine(refine)
     out = {}
-    for form, limit in (("tile", 0), ("short", 4096)):
-        _short(hip, limit)
+    for form, limit, cluster in (("tile", 0, 0), ("short", 4096, 0), ("cluster", 4096, 2048)):
+        _short(hip, limit, cluster)
         out[form] = hip.decode_grid(N, origin, vs)
-    for k in (0, 1):
-        a, b = out["tile"][k], out["short"][k]
-        listed = int((a.abs() < refine).sum())
-        assert listed > 0, "nothing within %g of the level: the test does not exercise the refinement" % refine
-        assert torch.equal(a, b), (tag, refine, k, float((a - b).abs().max()))
-    assert torch.equal(out["tile"][2], out["short"][2])
+    for form in ("short", "cluster"):
+        for k in (0, 1):
+            a, b = out["tile"][k], out[form][k]
+            listed = int((a.abs() < refine).sum())
+            assert listed > 0, "nothing within %g of the level: the test does not exercise the refinement" % refine
+            assert torch.equal(a, b), (tag, refine, form, k, float((a - b).abs().max()))
+        assert torch.equal(out["tile"][2], out[form][2])
     # and the values ARE the fp32 chain's wherever the list reaches (an fp32 sweep of the same lattice)
     hip.set_math("f32")
     f32 = hip.decode_grid(N, origin, vs)
@@ -59,7 +62,7 @@ def test_near_level_refinement_is_bit_identical_in_both_forms(tag, refine):
     hip.close()
 
 
-@pytest.mark.parametrize("count", [1, 31, 32, 33, 100, 1000, 4096, 4097])
+@pytest.mark.parametrize("count", [1, 31, 32, 33, 100, 1000, 2048, 2049, 4096, 4097])
 def test_explicit_lists_around_the_block_size_and_the_limit(count):
     """The box-only coarse sweep re-evaluates its candidates on the fp32 chain: with a tiny allowance the candidate list is short -
     here its length is steered through tau - and lists of exactly 4096 voxels (the limit) take the short form, 4097 the tile form;
@@ -73,8 +76,8 @@ def test_explicit_lists_around_the_block_size_and_the_limit(count):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     org = (ctypes.c_float * 3)(*origin)
 
-    def box(tau, limit):
-        _short(hip, limit)
+    def box(tau, limit, cluster=0):
+        _short(hip, limit, cluster)
         vh = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
         vo = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
         rec = torch.zeros(48, dtype=torch.int32, device="cuda")
@@ -93,11 +96,59 @@ def test_explicit_lists_around_the_block_size_and_the_limit(count):
         if n >= count and n - count <= max(0, count // 20):
             break
     tau = tau if n >= count else hi                      # the smallest allowance found that lists at least `count` voxels
-    a, b = box(tau, 0), box(tau, 4096)
-    assert int(a[2][32]) == int(b[2][32]) >= count
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert np.array_equal(a[2][:16], b[2][:16]) and int(a[2][19]) == int(b[2][19])
+    a = box(tau, 0)
+    for b in (box(tau, 4096), box(tau, 4096, 2048), box(tau, 4096, 2048)):      # (the cluster form twice: its arrival counters carry over)
+        assert int(a[2][32]) == int(b[2][32]) >= count
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert np.array_equal(a[2][:16], b[2][:16]) and int(a[2][19]) == int(b[2][19])
     print("candidates", int(a[2][32]), "tau", tau)
+    hip.close()
+
+
+def test_cluster_form_over_changing_list_lengths():
+    """The cluster form's arrival counters are never reset: a member waits for the next multiple of four above the value it saw.  Forty
+    box sweeps whose candidate lists grow and shrink (so that clusters come and go between launches), each compared with the tile
+    form's volumes and record; the audit runs beside the candidates on its own stream as in the product."""
+    hip = _bound("nerf3", 3)
+    N = 64
+    origin, vs = [-1.0, -1.0, -1.0], 2.0 / (N - 1)
+    hip.decode_grid(N, origin, vs)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    org = (ctypes.c_float * 3)(*origin)
+
+    def box(tau, limit, cluster):
+        _short(hip, limit, cluster)
+        hip.set_audit(4096, seed=7)
+        vh = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        vo = torch.empty((N, N, N), dtype=torch.float32, device="cuda")
+        rec = torch.zeros(48, dtype=torch.int32, device="cuda")
+        _native.check(hip._L.asdf_decode_grid_box(hip._h, N, org, ctypes.c_float(vs), 0, ctypes.c_float(tau), vh.data_ptr(), vo.data_ptr(),
+                                                  rec.data_ptr(), st), "asdf_decode_grid_box")
+        return vh, vo, rec.cpu().numpy()
+
+    taus = [3e-5, 2e-3, 1e-4, 6e-4, 1e-5, 4e-3, 3e-4, 5e-5] * 5
+    lengths = set()
+    for tau in taus:
+        a, b = box(tau, 0, 0), box(tau, 8192, 2048)
+        lengths.add(int(a[2][32]))
+        assert int(a[2][32]) == int(b[2][32])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tau
+        assert np.array_equal(a[2][:16], b[2][:16]) and np.array_equal(a[2][32:41], b[2][32:41]), (tau, a[2][32:42], b[2][32:42])
+    assert min(lengths) <= 2048 < max(lengths) or max(lengths) <= 2048, sorted(lengths)
+    print("candidate list lengths", sorted(lengths))
+    # the audit beside the candidates (its own stream) against the audit in line (ASDF_AUDIT_INLINE=1): same picks, same record - the
+    # largest error, the contradictions, the evaluations, the shell words ([41], a float sum in arrival order, to rounding)
+    import os
+    side = box(3e-4, 8192, 2048)
+    os.environ["ASDF_AUDIT_INLINE"] = "1"
+    try:
+        inline = box(3e-4, 8192, 2048)
+    finally:
+        del os.environ["ASDF_AUDIT_INLINE"]
+    assert int(side[2][37]) > 0 and np.array_equal(side[2][:16], inline[2][:16]) and np.array_equal(side[2][32:41], inline[2][32:41])
+    assert torch.equal(side[0], inline[0]) and torch.equal(side[1], inline[1])
+    sq = [float(np.array([r[2][41]], dtype=np.int32).view(np.float32)[0]) for r in (side, inline)]
+    assert sq[0] > 0 and abs(sq[0] - sq[1]) <= 1e-5 * sq[0], sq
     hip.close()
 
 
@@ -113,7 +164,7 @@ def test_single_head_and_the_pipeline_default():
     hip = decoder_for(dec, specs, None)
     out = {}
     for limit in (4096, 0):
-        _short(hip, limit)
+        _short(hip, limit, 2048 if limit else 0)
         for hand, obj in ((True, True), (True, False), (False, True)):
             r = decode_two_pass(hand, obj, dec, lat, None, None, specs, 64)
             out[(limit, hand, obj)] = r
@@ -123,4 +174,4 @@ def test_single_head_and_the_pipeline_default():
         for part, on in (("hand", hand), ("obj", obj)):
             if on:
                 assert torch.equal(a["vol_" + part], b["vol_" + part])
-    _short(hip, 4096)
+    _short(hip, 4096, 2048)
