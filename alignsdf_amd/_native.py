@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 125        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 126        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -29,6 +29,7 @@ EXPORTS = (
     "asdf_decoder_set_math", "asdf_decoder_get_math", "asdf_debug_pack_host_f16",
     "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_decoder_set_short_list", "asdf_decoder_set_cluster_list", "asdf_decoder_one_plane_usable", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
     "asdf_zoom_cube", "asdf_decode_grid_band_dev", "asdf_decode_grid_dev", "asdf_mc_emit_bounded",
+    "asdf_sample_surface_workspace_bytes", "asdf_sample_surface", "asdf_icp_normalise",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -123,6 +124,9 @@ def lib():
     L.asdf_mesh_cc_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.asdf_mesh_largest_component.argtypes = [vp, i32, vp, i32, f32, ctypes.POINTER(f32), vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.asdf_chamfer.argtypes = [vp, i32, vp, i32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), vp]
+    L.asdf_sample_surface_workspace_bytes.argtypes = [i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.asdf_sample_surface.argtypes = [vp, vp, i32, vp, i32, f32, ctypes.POINTER(f32), vp, vp, i32, vp, vp, ctypes.c_size_t, vp]
+    L.asdf_icp_normalise.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.asdf_debug_pack_host_f16.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams), vp, vp, vp]
     L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
     _lib = L

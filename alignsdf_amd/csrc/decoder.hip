@@ -775,7 +775,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 125; }
+int asdf_version(void) { return 126; }
 
 const char* asdf_strerror(int code) {
   switch (code) {

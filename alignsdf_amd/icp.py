@@ -21,12 +21,57 @@ from .surface_sampling import _AREA_QUANTUM, _uniforms, load_obj, sample_surface
 _uniform_cache = {}
 
 
+def _draws(count, seed, dev):
+    key = (count, seed, str(dev))
+    if key not in _uniform_cache:
+        u, r = _uniforms(count, seed)
+        _uniform_cache[key] = (torch.from_numpy(u).to(dev), torch.from_numpy(np.ascontiguousarray(r)).to(dev))
+    return _uniform_cache[key]
+
+
+def sample_surface_native(verts_d, faces_d, count, seed=0, num_faces_dev=None, placement=None):
+    """sample_surface on the device through K9 (csrc/surface_sample.hip: asdf_sample_surface - four launches, nothing waited for):
+    verts_d [V,3] float32, faces_d [F,3] int32, both contiguous device tensors; `placement` = (voxel size, origin[3]) when the
+    vertices are in lattice units (marching cubes' / K8's output: placed on the fly in the exporter's fp32 arithmetic), None when
+    they are positions.  Returns [count,3] fp64, bit for bit the host sampler's points."""
+    dev = verts_d.device
+    assert verts_d.dtype == torch.float32 and faces_d.dtype == torch.int32 and verts_d.is_contiguous() and faces_d.is_contiguous()
+    u, r = _draws(count, seed, dev)
+    L = _native.lib()
+    F = int(faces_d.shape[0])
+    nbytes = ctypes.c_size_t()
+    _native.check(L.asdf_sample_surface_workspace_bytes(F, ctypes.byref(nbytes)), "asdf_sample_surface_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out = torch.empty((count, 3), dtype=torch.float64, device=dev)
+    nf = None
+    if num_faces_dev is not None:
+        nf = num_faces_dev.reshape(-1)[:1]
+        nf = nf if nf.dtype == torch.int32 else nf.to(torch.int32)
+    vs, org = (np.float32(placement[0]), (ctypes.c_float * 3)(*[float(np.float32(o)) for o in placement[1]])) if placement is not None else (np.float32(0), None)
+    with torch.cuda.device(dev):
+        _native.check(L.asdf_sample_surface(verts_d.data_ptr(), faces_d.data_ptr(), F, nf.data_ptr() if nf is not None else None,
+                                            1 if placement is not None else 0, ctypes.c_float(float(vs)), org, u.data_ptr(), r.data_ptr(), int(count),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                      "asdf_sample_surface")
+    return out
+
+
 def sample_surface_device(verts_d, faces_d, count, seed=0, num_faces_dev=None):
     """sample_surface on the device, bit for bit: verts_d [V,3] (any float dtype, converted to fp64 exactly), faces_d [F,3] integer
     device tensors -> [count,3] fp64 device tensor.  `num_faces_dev` (optional 0-dim / 1-element device tensor): only the first
     that many rows of faces_d are faces - the others get area zero and can never be picked - so a mesh whose size is known only on
-    the device (the largest-component filter's output) is sampled without a host synchronisation.  Elementwise fp64 products and
-    sums in the host sampler's order (torch does not contract them), integer cumulative sums: same picks, same points."""
+    the device (the largest-component filter's output) is sampled without a host synchronisation.  float32 vertices with int32
+    faces (what marching cubes and K8 produce) go through K9 (sample_surface_native); other types through the elementwise torch form
+    below - fp64 products and sums in the host sampler's order (torch does not contract them), integer cumulative sums: same picks,
+    same points (tests/test_gpu_icp.py compares the two and the host sampler)."""
+    if (verts_d.dtype == torch.float32 and faces_d.dtype == torch.int32 and verts_d.is_contiguous() and faces_d.is_contiguous()
+            and faces_d.shape[0] > 0):
+        return sample_surface_native(verts_d, faces_d, count, seed, num_faces_dev)
+    return sample_surface_torch(verts_d, faces_d, count, seed, num_faces_dev)
+
+
+def sample_surface_torch(verts_d, faces_d, count, seed=0, num_faces_dev=None):
+    """The elementwise torch form of sample_surface_device (about fifty launches)."""
     dev = verts_d.device
     v = verts_d.to(torch.float64)
     f = faces_d.to(torch.int64)
@@ -42,11 +87,7 @@ def sample_surface_device(verts_d, faces_d, count, seed=0, num_faces_dev=None):
     area = 0.5 * torch.sqrt(cx * cx + cy * cy + cz * cz)
     q = torch.round(area / area.max() * _AREA_QUANTUM).to(torch.int64)       # torch.round = rint (half to even)
     cum = torch.cumsum(q, 0)
-    key = (count, seed, str(dev))
-    if key not in _uniform_cache:
-        u, r = _uniforms(count, seed)
-        _uniform_cache[key] = (torch.from_numpy(u).to(dev), torch.from_numpy(r).to(dev))
-    u, r = _uniform_cache[key]
+    u, r = _draws(count, seed, dev)
     target = torch.floor(u * cum[-1].to(torch.float64)).to(torch.int64)
     pick = torch.clamp(torch.searchsorted(cum, target, right=True), max=f.shape[0] - 1)
     a = torch.stack([vx[i0[pick]], vy[i0[pick]], vz[i0[pick]]], 1)
@@ -139,21 +180,20 @@ def start_icp_device(points_source_dev, points_target_dev, max_iter=100, stop_er
     ICP_T_S.sample_mesh (icp_trans_scale.py:25-31) runs there too (fp64 reductions; the sums are associated differently from
     numpy's, a 1e-16-class difference in the statistics), its four statistics travel to pinned host memory behind the run, and
     nothing here waits for the device.  Both inputs [n,3] fp64 on the same device."""
-    ps, pt = points_source_dev, points_target_dev
+    ps, pt = points_source_dev.contiguous(), points_target_dev.contiguous()
     dev = ps.device
-    offset_s = ps.mean(0)
-    scale_s = torch.sqrt(((ps - offset_s) ** 2).sum() / ps.shape[0])
-    offset_t = pt.mean(0)
-    scale_t = torch.sqrt(((pt - offset_t) ** 2).sum() / pt.shape[0])
     job = IcpJob()
     job.device = dev
     job.stream = torch.cuda.current_stream(dev)
-    job.src = ((ps - offset_s) / scale_s * scale_t + offset_t).contiguous()
-    job.tgt = pt.contiguous()
+    job.src = torch.empty_like(ps)
+    job.tgt = pt
+    # the four statistics go straight into pinned (device-accessible) host memory from the kernel that computes them (K9:
+    # asdf_icp_normalise, one launch - it was about 25 elementwise / reduction launches and a copy); finish_icp reads them behind the run
     job.host = [torch.zeros(8, dtype=torch.float64).pin_memory()]
-    # (an in-order copy on the stream the ICP is enqueued on, AHEAD of its kernels: finish_icp waits for the event behind them and
-    # reads this afterwards - no copy engine has to get in between decoder passes on its own, which is what start_icp avoids)
-    job.host[0].copy_(torch.cat([offset_s, scale_s.reshape(1), offset_t, scale_t.reshape(1)]), non_blocking=True)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().asdf_icp_normalise(ps.data_ptr(), ps.shape[0], pt.data_ptr(), pt.shape[0], job.src.data_ptr(),
+                                                       job.host[0].data_ptr(), ctypes.c_void_p(job.stream.cuda_stream)), "asdf_icp_normalise")
+    job.host.append(ps)               # (keeps the un-normalised samples alive until the kernel has run)
     job.norm = None                   # read from job.host[0] once the run is done (finish_icp)
     L = _native.lib()
     nbytes = ctypes.c_size_t()
@@ -222,9 +262,13 @@ def start_alignment_device(kept_verts_dev, kept_faces_dev, counts_dev, origin, v
     tensor; sampled with seed + 1 like start_alignment does)."""
     dev = kept_verts_dev.device
     vs = np.float32(voxel_size.item() if hasattr(voxel_size, "item") else voxel_size)
-    org = torch.tensor([np.float32(o) for o in origin], dtype=torch.float32, device=dev)
-    placed = kept_verts_dev * float(vs) + org                       # fp32 multiply, fp32 add: place_vertices on the device
-    ps = sample_surface_device(placed, kept_faces_dev, samples, seed, counts_dev[1:2])
+    if kept_verts_dev.dtype == torch.float32 and kept_faces_dev.dtype == torch.int32 and kept_verts_dev.is_contiguous() and kept_faces_dev.is_contiguous():
+        # K9 places the vertices itself (fp32 multiply, fp32 add: place_vertices) as it reads them
+        ps = sample_surface_native(kept_verts_dev, kept_faces_dev, samples, seed, counts_dev[1:2], placement=(vs, [np.float32(o) for o in origin]))
+    else:
+        org = torch.tensor([np.float32(o) for o in origin], dtype=torch.float32, device=dev)
+        placed = kept_verts_dev * float(vs) + org                       # fp32 multiply, fp32 add: place_vertices on the device
+        ps = sample_surface_device(placed, kept_faces_dev, samples, seed, counts_dev[1:2])
     pt = target_points if torch.is_tensor(target_points) else torch.from_numpy(np.ascontiguousarray(target_points, dtype=np.float64)).pin_memory()
     job = start_icp_device(ps, pt.to(dev, non_blocking=True), max_iter)
     job.host.append(pt)               # keep the pinned staging buffer alive until the run is done

@@ -11,6 +11,8 @@ import torch
 from . import _native
 
 _workspaces = {}
+_generation = {}     # workspace key -> count phases enqueued into it so far: a ticket whose workspace has served another volume since
+                     # its own count phase is counted again before it is emitted (its scan results are gone)
 _SLOTS = 2           # volumes whose count phase may be in flight at once (hand + object of one sample)
 _results = []        # ring of pinned result records (V, F, min key, max key): one per ticket, so that a count phase enqueued for
 _result_turn = 0     # the NEXT sample cannot overwrite sizes the host has not read yet (round 5: whole samples are enqueued ahead)
@@ -56,6 +58,8 @@ def marching_cubes_begin(volume, level=0.0, slot=0, capacity=None):
     vol = volume.detach().to(torch.float32).contiguous()
     dev = vol.device
     ws, result = _workspace(vol.shape, dev, slot % _SLOTS), _result_record()
+    key = (tuple(vol.shape), str(dev), slot % _SLOTS)
+    gen = _generation[key] = _generation.get(key, 0) + 1
     L = _native.lib()
     bufs = None
     with torch.cuda.device(dev):
@@ -70,13 +74,13 @@ def marching_cubes_begin(volume, level=0.0, slot=0, capacity=None):
                           "asdf_mc_emit_bounded")
         done = torch.cuda.Event()
         done.record()
-    return vol, float(level), ws, result, done, bufs
+    return vol, float(level), ws, result, done, bufs, key, gen
 
 
 def marching_cubes_finish(ticket):
     """Wait for the sizes of marching_cubes_begin (an event, not the stream), allocate, emit.  Returns (verts [V,3] fp32,
     faces [F,3] int32) device tensors; raises ValueError / RuntimeError with skimage's messages."""
-    vol, level, ws, result, done, bufs = ticket
+    vol, level, ws, result, done, bufs, key, gen = ticket
     done.synchronize()
     L = _native.lib()
     r = result.numpy().view(np.uint32)
@@ -91,7 +95,11 @@ def marching_cubes_finish(ticket):
         if V <= bufs[0].shape[0] and F <= bufs[1].shape[0]:
             return bufs[0][:V], bufs[1][:F]          # (emitted behind the count phase: nothing left to do)
         # a capacity was too small; the workspace may have served another volume since: both phases again, sizes known
-        return marching_cubes_finish(marching_cubes_begin(vol, level))
+        return marching_cubes_finish(marching_cubes_begin(vol, level, key[2]))
+    if _generation.get(key) != gen:
+        # another volume's count phase has used this workspace since (a caller that interleaves tickets on one slot): the emit below
+        # would read ITS scan results with THIS ticket's sizes - count again, emit right away
+        return marching_cubes_finish(marching_cubes_begin(vol, level, key[2]))
     dev = vol.device
     verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
     faces = torch.empty((F, 3), dtype=torch.int32, device=dev)

@@ -508,8 +508,9 @@ def main():
             if world > 1:
                 dist.barrier()
             dec.event_log, dec.box_event_log = [], []
-            # (N < 256: the one-plane kernel is timed on every 8th sweep - the two event pairs per sweep cost 0.1 ms of a 1 ms sample)
-            dec.box_event_stride = 1 if n >= 256 else 8
+            # (N < 256 and enough steps to leave a sample of launches: the one-plane kernel is timed on every 8th sweep - the two event
+            # pairs per sweep cost 0.1 ms of a 1 ms sample)
+            dec.box_event_stride = 1 if n >= 256 or count < 32 else 8
             t0 = time.perf_counter()
             done = self.run(first, count, n, keep_meshes)
             torch.cuda.synchronize(dev)

@@ -320,6 +320,22 @@ int asdf_mesh_largest_component(const float* verts_dev, int32_t num_verts, const
                                 float voxel_size, const float origin[3], void* workspace_dev, size_t workspace_bytes,
                                 float* out_verts_dev, int32_t* out_faces_dev, int32_t* counts_dev, void* stream);
 
+/* ---- K9: eval mode's surface sampling and sample normalisation on the device (csrc/surface_sample.hip).
+ * asdf_sample_surface replaces `trimesh.sample.sample_surface(mesh, count)` (utils/mesh.py:386-389 through
+ * deep_sdf/metrics/icp_trans_scale.py:19-23) with the seeded, area-quantised sampler of alignsdf_amd/surface_sampling.py, bit for bit:
+ * verts_dev [V][3] fp32 - lattice units when place != 0 (placed on the fly: v * voxel_size + origin, an fp32 multiply and an fp32 add, the
+ * exporter's arithmetic of utils/mesh.py:360-369), positions otherwise - faces_dev [faces_cap][3], of which the first *num_faces_dev (a
+ * device word; NULL = all) are faces (K8's output), u_dev [count] / r_dev [count][2] the draws (surface_sampling._uniforms) and
+ * points_dev [count][3] fp64 the samples.  Four launches, no host synchronisation.
+ * asdf_icp_normalise is ICP_T_S.sample_mesh's normalisation (icp_trans_scale.py:25-31): src_out_dev = (src - mean_s) / rms_s * rms_t +
+ * mean_t; stats_mapped (optional, device-accessible host memory, 8 doubles) receives mean_s[3], rms_s, mean_t[3], rms_t. */
+int asdf_sample_surface_workspace_bytes(int32_t faces_cap, size_t* bytes);
+int asdf_sample_surface(const float* verts_dev, const int32_t* faces_dev, int32_t faces_cap, const int32_t* num_faces_dev,
+                        int32_t place, float voxel_size, const float origin[3], const double* u_dev, const double* r_dev, int32_t count,
+                        double* points_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int asdf_icp_normalise(const double* src_dev, int32_t ns, const double* tgt_dev, int32_t nt, double* src_out_dev, double* stats_mapped,
+                       void* stream);
+
 /* ---- Translate + scale ICP of the reference's eval mode: ICP_T_S.run_icp_f (deep_sdf/metrics/icp_trans_scale.py:33-113),
  * called from utils/mesh.py:385-395.  src_dev [ns][3] are the ALREADY NORMALISED source samples (sample_mesh :25-31),
  * tgt_dev [nt][3] the target samples, both fp64 on the device.  Runs until the reference's stopping rules fire

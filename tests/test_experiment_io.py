@@ -187,3 +187,36 @@ def test_rccl_backend_executes_the_collectives_of_the_path():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["rccl_ok"] and line["backend"] == "nccl" and line["n_ranks"] == 1 and line["max_elapsed"] == 1.25
     assert [m["index"] for m in line["merged"]] == [1, 3] and line["merged"][1]["icp_skipped"] == 1 and line["empty"] == []
+
+
+@pytest.mark.gpu
+def test_code_upload_does_not_wait_for_the_queued_passes(tmp_path):
+    """The per-sample codes reach the device through CodeUploader (pinned ring, side stream, device-side wait): the values arrive,
+    the ring survives more uploads than it has slots, the compute stream sees the data (a consumer kernel queued right behind), and
+    the CALL returns while a long kernel queue is still running - a plain `.to(device)` waited for all of it (50 ms per sample
+    with a sample's two passes queued: the eval-mode flow then ran with 4.4 ms of idle GPU per sample)."""
+    import time
+    from alignsdf_amd.reconstruct import CodeUploader, npz_code_source
+    up = CodeUploader("cuda")
+    rng = np.random.default_rng(0)
+    arrays = [rng.standard_normal((1, 256)).astype(np.float32) for _ in range(3 * CodeUploader.SLOTS)]
+    a = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        a = (a @ a) * 1e-3
+    queued = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = [up(x) * 2.0 for x in arrays]                       # (the multiply is the consumer on the compute stream)
+    call = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    for x, y in zip(arrays, out):
+        assert np.array_equal(y.cpu().numpy(), x * 2.0)
+    assert total > 4 * call, "the uploads waited for the queue: %.1f ms of calls, queue drained after %.1f ms (enqueue %.1f ms)" % (1e3 * call, 1e3 * total, 1e3 * queued)
+    # the product's code source goes through it
+    np.savez(tmp_path / "s.npz", latent=arrays[0], global_trans=np.tile(np.eye(4, dtype=np.float32), (1, 16, 1, 1)),
+             rot_center=np.zeros((1, 1, 3), np.float32), obj_trans=np.eye(4, dtype=np.float32)[None])
+    lat, mano, obj = npz_code_source(str(tmp_path))("s", 0)
+    torch.cuda.synchronize()
+    assert lat.is_cuda and np.array_equal(lat.cpu().numpy(), arrays[0]) and mano["global_trans"].shape == (1, 16, 4, 4) and obj["obj_trans"].shape == (1, 4, 4)

@@ -65,7 +65,7 @@ def test_device_surface_sampler_is_the_host_sampler_bit_for_bit():
     """The eval-mode hook samples the predicted surface on the device (alignsdf_amd.icp.sample_surface_device): same faces picked,
     same points, bit for bit, as the host sampler on the same mesh - for a marching-cubes surface, for a mesh padded to a larger
     capacity with its face count on the device (the largest-component filter's output), and for other seeds / counts."""
-    from alignsdf_amd.icp import sample_surface, sample_surface_device
+    from alignsdf_amd.icp import sample_surface, sample_surface_device, sample_surface_native, sample_surface_torch
     from alignsdf_amd.marching_cubes import marching_cubes_device
     from alignsdf_amd.mesh_post import keep_largest_component_device
     v, f = marching_cubes_device(_sphere_volume(), 0.0)
@@ -76,6 +76,12 @@ def test_device_surface_sampler_is_the_host_sampler_bit_for_bit():
         want = sample_surface(host_v, host_f, count, seed)
         got = sample_surface_device(placed, f, count, seed)
         assert got.dtype == torch.float64 and np.array_equal(got.cpu().numpy(), want), (count, seed)
+        # the three device forms: K9 on positions (what the line above ran: fp32 vertices, int32 faces), K9 placing lattice-unit
+        # vertices itself (the exporter's fp32 multiply + add), and the elementwise torch form other input types take
+        assert f.dtype == torch.int32 and placed.dtype == torch.float32
+        assert np.array_equal(sample_surface_native(v, f, count, seed, placement=(vs, org)).cpu().numpy(), want), (count, seed)
+        assert np.array_equal(sample_surface_torch(placed, f, count, seed).cpu().numpy(), want), (count, seed)
+        assert np.array_equal(sample_surface_device(placed.double(), f.long(), count, seed).cpu().numpy(), want), (count, seed)
     # K8's output: capacity of the input, the kept counts on the device
     kv, kf, counts = keep_largest_component_device(v, f, vs, org)
     c = counts.cpu().numpy()
@@ -87,6 +93,37 @@ def test_device_surface_sampler_is_the_host_sampler_bit_for_bit():
     pad = torch.cat([kf[:c[1]], torch.randint(0, int(c[0]), (5000, 3), dtype=kf.dtype, device="cuda")], 0)
     got = sample_surface_device(kept_placed, pad, 30000, 0, counts[1:2])
     assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(sample_surface_torch(kept_placed, pad, 30000, 0, counts[1:2]).cpu().numpy(), want)
+    assert np.array_equal(sample_surface_native(kv, pad, 30000, 0, counts[1:2], placement=(vs, org)).cpu().numpy(), want)
+    # meshes around the scan's chunk size (4096 faces per round of the one-workgroup scan) and a single face
+    rng = np.random.default_rng(5)
+    for nf in (1, 2, 4095, 4096, 4097, 12289):
+        hv = rng.standard_normal((max(3, nf // 2 + 3), 3)).astype(np.float32)
+        hf = rng.integers(0, hv.shape[0], (nf, 3)).astype(np.int32)
+        hf[0] = [0, 1, 2]
+        want = sample_surface(hv, hf, 5000, 3)
+        got = sample_surface_device(torch.from_numpy(hv).cuda(), torch.from_numpy(hf).cuda(), 5000, 3)
+        assert np.array_equal(got.cpu().numpy(), want), nf
+
+
+def test_device_normalisation_equals_the_host_normalisation():
+    """asdf_icp_normalise (K9: mean / RMS radius of both sample sets and the moved source set, one launch) against normalise_source
+    (icp_trans_scale.py:25-31 in numpy): statistics and points to 1e-12 relative (the sums are associated differently), and the same
+    bits run to run."""
+    from alignsdf_amd.icp import normalise_source, start_icp_device, finish_icp
+    rng = np.random.default_rng(11)
+    ps = rng.standard_normal((30000, 3)) * [0.3, 0.2, 0.5] + [0.1, -0.2, 0.05]
+    pt = ps * 1.3 + [0.4, 0.1, -0.3] + rng.standard_normal((30000, 3)) * 1e-3
+    want, (os_, ss, ot, st) = normalise_source(ps, pt)
+    runs = []
+    for _ in range(2):
+        job = start_icp_device(torch.from_numpy(ps).cuda(), torch.from_numpy(pt).cuda(), max_iter=1)
+        finish_icp(job, ps[:4])
+        runs.append((job.src.cpu().numpy(), job.host[0].numpy().copy()))
+    got, stats = runs[0]
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert np.allclose(stats, np.concatenate([os_, [ss], ot, [st]]), rtol=1e-12, atol=1e-15)
+    assert np.abs(got - want).max() <= 1e-12
 
 
 def test_device_alignment_equals_the_host_alignment(tmp_path):

@@ -125,15 +125,21 @@ def test_bounded_emit_and_its_fallback():
     N = 96
     _bind(hip, specs, 3)
     vh, vo, _ = hip.decode_grid(N, [-0.62, -0.36, -0.37], 1.21 / (N - 1))
+    direct = {id(vol): marching_cubes_device(vol, 0.0) for vol in (vh, vo)}
     for vol in (vh, vo):
-        v0, f0 = marching_cubes_device(vol, 0.0)
+        v0, f0 = direct[id(vol)]
         for cap in ((v0.shape[0] + 100, f0.shape[0] + 100), (v0.shape[0], f0.shape[0]), (v0.shape[0] // 2, f0.shape[0] + 5), (v0.shape[0] + 5, 10)):
             # another volume's count phase in between (the next sample's): the ticket's sizes must survive it
             t = marching_cubes_begin(vol, 0.0, 0, capacity=cap)
-            other = marching_cubes_begin(vo if vol is vh else vh, 0.0, 0)
+            other_vol = vo if vol is vh else vh
+            other = marching_cubes_begin(other_vol, 0.0, 0)
             v1, f1 = marching_cubes_finish(t)
-            marching_cubes_finish(other)
             assert torch.equal(v0, v1) and torch.equal(f0, f1), cap
+            # ... and the OTHER ticket - counted only, on the same workspace, which a too-small capacity above has just used again for
+            # its second attempt - notices that (the workspace's generation moved on) and counts again instead of emitting the
+            # first volume's scan results with its own sizes (found as an abort of this test, round 5)
+            v2, f2 = marching_cubes_finish(other)
+            assert torch.equal(v2, direct[id(other_vol)][0]) and torch.equal(f2, direct[id(other_vol)][1]), cap
     hip.close()
 
 

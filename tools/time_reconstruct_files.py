@@ -33,6 +33,19 @@ kw = dict(eval_mode=True, data_root=os.path.join(tmp, "data")) if EVAL else {}
 kw["code_source"] = rc.synthetic_code_source("nerf3")
 rc.reconstruct(dec, specs, split, tmp, 0, 1, cube_dim=N, **kw)          # warm-up
 REPS = int(os.environ.get('ASDF_TIMING_REPS', '5'))      # the boxes are shared hosts: the worker threads (and the main one) get descheduled now and then - median of 5 runs
+if os.environ.get("ASDF_TIMING_PROFILE"):          # host profile of one timed call (cProfile roughly doubles the interpreter's share)
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    rc.reconstruct(dec, specs, split, tmp, 1, n_samples + 1, cube_dim=N, **kw)
+    torch.cuda.synchronize()
+    pr.disable()
+    for key, pat in (("tottime", None), ("cumulative", "alignsdf_amd")):
+        out = io.StringIO()
+        st = pstats.Stats(pr, stream=out).sort_stats(key)
+        st.print_stats(pat, 40) if pat else st.print_stats(40)
+        print(out.getvalue())
+    sys.exit(0)
 runs = []
 for _ in range(REPS):
     torch.cuda.synchronize()
