@@ -460,10 +460,10 @@ __global__ __launch_bounds__(256) void band_compact_kernel(const unsigned char* 
     }
     __syncthreads();
   }
-  if (done && threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(done, 1) == (int)gridDim.x - 1) *count_copy = atomicAdd(count, 0);
-  }
+  // (no fence: thread 0 issued this workgroup's reservations on *count itself and has their return values - they are complete -
+  // before it arrives here, and device-scope atomics are coherent across the XCDs.  A __threadfence() per workgroup is an L2
+  // write-back each: 19 -> 131 us per launch at N = 256, seen in the kernel statistics)
+  if (done && threadIdx.x == 0 && atomicAdd(done, 1) == (int)gridDim.x - 1) *count_copy = atomicAdd(count, 0);
 }
 
 // near-level voxels among the LISTED ones of one volume (the narrow-band sweep refines only where it re-evaluated)
@@ -1017,6 +1017,11 @@ static int launch_subset(asdf_decoder* d, const DecodeParams& q_in, bool two_out
     q.short_max = d->short_max;
     ShortParams sp = d->shortp;
     if (sp.cluster_max > d->short_max) sp.cluster_max = d->short_max;
+    if (d->num_cus < 64) sp.cluster_max = 0;       // (its members wait for each other: they need workgroup slots side by side)
+    // four workgroups per block and MLP, one per compute unit (155 KB of LDS each): beyond 64 blocks x MLPs the cluster form needs a
+    // second round of the chip and loses to the short form's single one (N = 128 trace: 1 400 candidates x 2 MLPs, 0.22 -> 0.36 ms per
+    // sample) - lists of up to 2048 / MLPs voxels take it
+    if (sp.cluster_max > kClusterCap / q.num_mlps) sp.cluster_max = kClusterCap / q.num_mlps;
     k1_short_launch(two_out, q, sp, st);
   }
   if (two_out || q.num_mlps != 2 || !q.sdf0 || !q.sdf1 || !d->side) {
@@ -1387,8 +1392,12 @@ static int decode_grid_band_impl(asdf_decoder_t* d, int32_t N, const float* orig
     int* list = d->band_idx + (size_t)h * kBandCap;
     // the audit picks of this head - unmarked voxels, i.e. voxels marching cubes will read the SIGN of and nothing else - ride
     // behind the marked ones in the same list (positions >= audit_rec[4 + h]: the compaction's last workgroup writes that word)
+    // (... on the small lattices, where a launch is what counts.  On a large one the 4096 arrivals on one word cost more than the
+    // 4-byte copy they replace - 19 -> 51 us per launch at N = 256 in the kernel statistics - so there the copy stays)
+    const bool publish = cgrid <= 256;
     hipLaunchKernelGGL(band_compact_kernel, dim3(cgrid), dim3(256), 0, st, d->band_mark, P, list, d->band_count + h, kBandCap,
-                       d->audit_rec + 10 + h, d->audit_rec + 4 + h);
+                       publish ? d->audit_rec + 10 + h : nullptr, d->audit_rec + 4 + h);
+    if (!publish) ASDF_HIP(hipMemcpyAsync(d->audit_rec + 4 + h, d->band_count + h, sizeof(int), hipMemcpyDeviceToDevice, st));
     { const int rc = enqueue_audit_picks(d, vols[h], two_out ? vols[1] : nullptr, d->band_mark, P, tau, list, d->band_count + h, kBandCap, h, st); if (rc != ASDF_OK) return rc; }
     // the values of the ordinary sweep at the listed voxels of this head: the split-half kernel over the list ...
     DecodeParams q = p;

@@ -234,8 +234,16 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
       }
     };
     auto await = [&](int which) {
-      if (tid == 0)
-        while (__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all < 0) __builtin_amdgcn_s_sleep(1);
+      if (tid == 0) {
+        // (bounded: the other members are resident or next in line - see the header - so this takes microseconds.  A device on which
+        // they can never become resident (fewer than four workgroup slots: a CU mask) would spin forever and hang the queue; the host
+        // does not select this form there (decoder.hip), and should the assumption ever fail the wave traps after ~1 s instead)
+        unsigned spins = 0;
+        while (__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all < 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) __builtin_trap();
+        }
+      }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };

@@ -235,7 +235,7 @@ int asdf_decoder_set_refine(asdf_decoder_t* dec, float tau);
 int asdf_decoder_set_short_list(asdf_decoder_t* dec, int32_t max_points);
 
 /* ... and the SHORTEST lists (up to max_points voxels, default and at most 2048; 0 = never; effective limit min(max_points, the
- * short-list limit above)): the same launch gives each block of 32 points to a cluster of four workgroups on one XCD - one output
+ * short-list limit above, 2048 / MLPs evaluated - beyond 64 blocks x MLPs the form needs a second round of the chip): the same launch gives each block of 32 points to a cluster of four workgroups on one XCD - one output
  * tile per wave and layer, the layers' activations exchanged through device memory behind agent-scope release / acquire - so the
  * longest dependent chain is 642 MFMAs instead of 2064 (0.10 -> about 0.04 ms per launch; two launches per sample, which is a
  * sixth of a 64^3 sample).  Bit-identical to the other two forms (per-tile instruction sequence unchanged). */
