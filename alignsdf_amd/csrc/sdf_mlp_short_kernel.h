@@ -220,17 +220,17 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
     // ---- the cluster form: one output tile per wave and layer, activations through the cluster's exchange buffer
     float* xb = sp.xchg + (size_t)cluster * kXchgFloats;
     float* x1 = xb, *x2 = xb + kTilesL1 * 1024, *x3 = xb + (kTilesL1 + kTilesHidden) * 1024;
-    int* arrivals = sp.arrivals + cluster * 4;
+    unsigned* arrivals = reinterpret_cast<unsigned*>(sp.arrivals) + cluster * 4;
     const int gw = member * kWaves + wave;                     // 0 .. 15
     // publish: this workgroup's tile stores become visible device-wide, then one arrival; await: all four have arrived.  (Between the
     // two a wave issues the first weights of its next tile: they travel while it waits.)
-    int all = 0;
+    unsigned all = 0;                                          // (unsigned: the counters wrap after 2^30 launches - days of 64^3 samples - and the comparison below survives that)
     auto publish = [&](int which) {
       __threadfence();
       __syncthreads();
       if (tid == 0) {
-        const int seen = __hip_atomic_fetch_add(arrivals + which, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        all = (seen & ~(kClusterWgs - 1)) + kClusterWgs;
+        const unsigned seen = __hip_atomic_fetch_add(arrivals + which, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        all = (seen & ~(unsigned)(kClusterWgs - 1)) + kClusterWgs;
       }
     };
     auto await = [&](int which) {
@@ -239,7 +239,7 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
         // they can never become resident (fewer than four workgroup slots: a CU mask) would spin forever and hang the queue; the host
         // does not select this form there (decoder.hip), and should the assumption ever fail the wave traps after ~1 s instead)
         unsigned spins = 0;
-        while (__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all < 0) {
+        while ((int)(__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all) < 0) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1u << 24)) __builtin_trap();
         }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void quantise_scan_kernel(const double* __res
     for (int k = 0; k < kPer; ++k) {
       const int f = base + threadIdx.x * kPer + k;
       long long v = 0;
-      if (f < faces_cap) v = (long long)rint(__dmul_rn(__ddiv_rn(area[f], amax), kAreaQuantum));     // (rint: half to even, torch.round)
+      if (f < faces_cap && amax > 0.0) v = (long long)rint(__dmul_rn(__ddiv_rn(area[f], amax), kAreaQuantum));     // (rint: half to even, torch.round; a mesh of zero area has no weights)
       run += v;
       q[k] = run;
     }
