@@ -1291,11 +1291,16 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
   // candidates -> exact values (fp32 MFMA chain) -> the box is extended by every candidate that is negative
   const long long items = (N & 3) == 0 ? p.P / 4 : p.P;
   const int cgrid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+  // A lattice of up to 8 x kCandDirect voxels (N <= 64) gets no two-step form: more than kCandDirect candidates there would mean an
+  // eighth of the lattice within tau of the level - such a sweep is refused as a list overflow (status[1], the caller repeats it as an
+  // ordinary sweep) and its five launches, which did nothing in every other sweep, are not enqueued (a 64^3 sample is ~40 launches)
+  const bool direct_only = p.P <= 8LL * kCandDirect;
+  const int cand_cap = direct_only ? kCandDirect : kCandCap;
   hipLaunchKernelGGL(collect_box_candidates_kernel, dim3(cgrid), dim3(256), 0, st, p.sdf0, p.sdf1, N, tau, p.bbox, d->near_idx,
-                     d->near_count, kCandCap, d->status);
+                     d->near_count, cand_cap, d->status);
   if (!d->box_aux) ASDF_HIP(hipMalloc((void**)&d->box_aux, (4 + (size_t)kNearCap) * sizeof(int)));
   int* direct_count = d->box_aux, *twostep_count = d->box_aux + 1, *twostep_near = d->box_aux + 2, *twostep_idx = d->box_aux + 4;
-  hipLaunchKernelGGL(split_candidate_count_kernel, dim3(1), dim3(64), 0, st, d->near_count, kCandCap, kCandDirect, d->box_aux);
+  hipLaunchKernelGGL(split_candidate_count_kernel, dim3(1), dim3(64), 0, st, d->near_count, cand_cap, kCandDirect, d->box_aux);
   const int rgrid = kCandCap / kWgPts < d->num_cus ? kCandCap / kWgPts : d->num_cus;
   {
     // up to kCandDirect candidates: the fp32 chain patches values and boxes in one step
@@ -1304,7 +1309,7 @@ int asdf_decode_grid_box(asdf_decoder_t* d, int32_t N, const float origin[3], fl
     q.mode = kGridSubset; q.grid_mode = p.mode; q.idx = d->near_idx; q.count_dev = direct_count; q.P = kCandCap;
     { const int rc = launch_subset(d, q, two_out, rgrid, st); if (rc != ASDF_OK) return rc; }
   }
-  {
+  if (!direct_only) {
     // more: the values of the ordinary sweep (split-half kernel; it reports the largest |exact - one-plane| to status[3]) ...
     DecodeParams e = p;
     e.stream = d->stream16; e.cst = d->cst16; e.bbox = nullptr; e.neg_thr = 0.0f;

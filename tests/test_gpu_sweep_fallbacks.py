@@ -122,6 +122,31 @@ def test_near_level_overflow_in_a_box_sweep():
     hip.close()
 
 
+def test_candidate_overflow_on_a_small_lattice_is_refused_and_repeated():
+    """N = 64 (round 5): a lattice of up to 8 x 32 768 voxels has no two-step candidate form - its five launches did nothing in any
+    real sweep of such a lattice - so more than 32 768 candidates (an absurd allowance of 0.2: every voxel) are a list overflow: the box
+    sweep is refused and repeated as an ordinary sweep, and the boxes are the ordinary sweep's."""
+    N = 64
+    dec, specs = _module()
+    hip = _hip(dec, specs)
+    lat = lambda s: torch.from_numpy(syn.latent_code(s)).cuda()
+    vs = 2.0 / (N - 1)
+    hip.set_sample(lat(0))
+    hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))       # calibration
+    hip.set_sample(lat(5))
+    want = hip.decode_grid(N, [-1.0, -1.0, -1.0], vs)[2].cpu().numpy()
+    ok = hip.coarse_finish(hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs))  # an ordinary allowance: accepted, the same boxes
+    assert hip.box_stats["fallback"] == 0 and ok[:6].tolist() == want[:6].tolist() and ok[8:14].tolist() == want[8:14].tolist()
+    assert (ok[6] != 0, ok[14] != 0) == (want[6] != 0, want[14] != 0)        # (a box sweep's count words only say whether there is a negative voxel)
+    hip._box_tau = 0.2
+    t = hip.coarse_begin(N, [-1.0, -1.0, -1.0], vs)
+    assert t["kind"] == "box"
+    got = hip.coarse_finish(t)
+    assert hip.box_stats["fallback"] == 1 and hip.box_stats["max_candidates"] > 32768
+    assert got[:7].tolist() == want[:7].tolist() and got[8:15].tolist() == want[8:15].tolist()
+    hip.close()
+
+
 def test_three_refused_band_sweeps_in_a_row_switch_the_mode_off_and_lists_beyond_capacity_cost_only_time(monkeypatch):
     """N = 256 through the SAMPLE PIPELINE with an absurd allowance (0.2: every voxel is 'undecided'): the box sweep lists
     more than CAND_CAP candidates, the band sweep marks more than BAND_CAP voxels - every such sweep is refused and repeated as an
