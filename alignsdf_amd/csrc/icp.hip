@@ -32,6 +32,7 @@ constexpr int kIcpTile = 1024;          // reference points per LDS tile (24 KiB
 constexpr int kIcpSplits = 8;           // reference-set splits per query tile
 constexpr int kIcpSums = 9;             // err, sum X (3), sum Y (3), sum X.Y, sum X.X
 constexpr int kIcpBatch = 8;            // iterations enqueued between two reads of the state
+constexpr int kIcpUpdateGrid = 64;      // workgroups of the reduction kernel (K7b)
 
 struct IcpState {
   double scale, t[3];
@@ -223,8 +224,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_grid_kernel(const double* 
   const bool valid = gidx < ns + nt;              // (all lanes of a query agree; invalid lanes walk query 0 and write nothing)
   const int qid = valid ? gidx : 0;
   const int dir = qid >= ns;
-  const int i = dir ? qid - ns : qid;
-  const double* pp = (dir ? tgt : src) + 3 * (size_t)i;
+  // queries are taken in the CELL-SORTED order of their own set's grid (the source set has one for the target's queries, and vice
+  // versa): the lanes of a wave then walk neighbouring cells of the other grid - similar trip counts, shared cache lines - instead
+  // of eight unrelated places each (the samples are in random order).  Results go to the query's own slot: nothing downstream changes
+  const int k = dir ? qid - ns : qid;
+  const int i = (dir ? gt : gs).sorted_idx[k];
+  const double* pp = (dir ? gt : gs).sorted + 3 * (size_t)k;
   const double s = state->scale, t0 = state->t[0], t1 = state->t[1], t2 = state->t[2];
   double q[3];
   if (dir == 0) { q[0] = pp[0] * s + t0; q[1] = pp[1] * s + t1; q[2] = pp[2] * s + t2; }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_grid_kernel(const double* 
     }
     if (!inside) scan_box(blo[0], bhi[0], blo[1], bhi[1], blo[2], bhi[2]);
   }
-  if (valid && sub == 0) { cand_d[gidx] = best; cand_i[gidx] = bidx; }
+  if (valid && sub == 0) { const int slot = dir ? ns + i : i; cand_d[slot] = best; cand_i[slot] = bidx; }
 }
 
 __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* __restrict__ src, int ns,
@@ -292,11 +297,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* _
   if (state->done) return;
   __shared__ double red[kIcpThreads / 64][kIcpSums];
   __shared__ bool last;
-  const int g = blockIdx.x * kIcpThreads + threadIdx.x;
   const int total = ns + nt;
   const double s = state->scale, t0 = state->t[0], t1 = state->t[1], t2 = state->t[2];
   double v[kIcpSums] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (g < total) {
+  // at most kIcpUpdateGrid workgroups, every thread adds its queries in index order (a fixed order: the sums are reproducible).  It was
+  // one workgroup per 256 queries - 235 of them at 30k + 30k, each paying an L2 write-back for its fence before the ticket: 61 us per
+  // launch, more than the nearest-neighbour search it follows (round 5)
+  for (int g = blockIdx.x * kIcpThreads + threadIdx.x; g < total; g += gridDim.x * kIcpThreads) {
     const int dir = g >= ns;
     const int i = dir ? g - ns : g;
     double best = cand_d[g];
@@ -309,14 +316,14 @@ __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* _
     const double* bb = (dir ? src : tgt) + 3 * (size_t)idx;
     const double p0 = pp[0], p1 = pp[1], p2 = pp[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
     if (dir == 0) {
-      v[0] = best;                                   // |q - ct|^2
-      v[1] = p0; v[2] = p1; v[3] = p2; v[4] = b0; v[5] = b1; v[6] = b2;
-      v[7] = p0 * b0 + p1 * b1 + p2 * b2; v[8] = p0 * p0 + p1 * p1 + p2 * p2;
+      v[0] += best;                                  // |q - ct|^2
+      v[1] += p0; v[2] += p1; v[3] += p2; v[4] += b0; v[5] += b1; v[6] += b2;
+      v[7] += p0 * b0 + p1 * b1 + p2 * b2; v[8] += p0 * p0 + p1 * p1 + p2 * p2;
     } else {
       const double c0 = b0 * s + t0, c1 = b1 * s + t1, c2 = b2 * s + t2;     // nearest source sample, transformed
-      v[0] = (p0 - c0) * (p0 - c0) + (p1 - c1) * (p1 - c1) + (p2 - c2) * (p2 - c2);
-      v[1] = b0; v[2] = b1; v[3] = b2; v[4] = p0; v[5] = p1; v[6] = p2;
-      v[7] = b0 * p0 + b1 * p1 + b2 * p2; v[8] = b0 * b0 + b1 * b1 + b2 * b2;
+      v[0] += (p0 - c0) * (p0 - c0) + (p1 - c1) * (p1 - c1) + (p2 - c2) * (p2 - c2);
+      v[1] += b0; v[2] += b1; v[3] += b2; v[4] += p0; v[5] += p1; v[6] += p2;
+      v[7] += b0 * p0 + b1 * p1 + b2 * p2; v[8] += b0 * b0 + b1 * b1 + b2 * b2;
     }
   }
 #pragma unroll
@@ -333,13 +340,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* _
     for (int k = 0; k < kIcpThreads / 64; ++k) a += red[k][threadIdx.x];
     partials[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = a;
   }
-  // the last block to arrive closes the iteration
-  __threadfence();
+  // the last block to arrive closes the iteration (the partial sums were written by wave 0: its fence, then the ticket)
+  if (threadIdx.x < 64) __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  if (threadIdx.x < 64) __threadfence();
   if (threadIdx.x < kIcpSums) {
     double a = 0;
     for (unsigned b = 0; b < gridDim.x; ++b) a += ((volatile double*)partials)[(size_t)b * kIcpSums + threadIdx.x];
@@ -582,7 +589,7 @@ void icp_iterations(const IcpRun& r, const double* src_dev, int ns, const double
                     double stop_error, double stop_improvement, hipStream_t st) {
   for (int it = first; it < last; ++it) {
     icp_nn(r, src_dev, ns, tgt_dev, nt, st);
-    hipLaunchKernelGGL(icp_update_kernel, dim3(r.l.update_blocks), dim3(kIcpThreads), 0, st, src_dev, ns, tgt_dev, nt, r.state,
+    hipLaunchKernelGGL(icp_update_kernel, dim3(r.l.update_blocks < kIcpUpdateGrid ? r.l.update_blocks : kIcpUpdateGrid), dim3(kIcpThreads), 0, st, src_dev, ns, tgt_dev, nt, r.state,
                        r.cand_d, r.cand_i, r.partials, it, stop_error, stop_improvement, r.grid ? 1 : kIcpSplits);
   }
 }
