@@ -402,12 +402,12 @@ __global__ __launch_bounds__(kIcpThreads) void chamfer_reduce_kernel(int na, int
     for (int k = 0; k < kIcpThreads / 64; ++k) a += red[k];
     partials[blockIdx.x] = a;
   }
-  __threadfence();
+  if (threadIdx.x < 64) __threadfence();           // (the writing wave's fence only: each one is an L2 write-back)
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  if (threadIdx.x < 64) __threadfence();
   if (threadIdx.x < 2) {
     const int lo = threadIdx.x ? blocks_a : 0, hi = threadIdx.x ? (int)gridDim.x : blocks_a;
     double a = 0;

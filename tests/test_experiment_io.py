@@ -220,3 +220,15 @@ def test_code_upload_does_not_wait_for_the_queued_passes(tmp_path):
     lat, mano, obj = npz_code_source(str(tmp_path))("s", 0)
     torch.cuda.synchronize()
     assert lat.is_cuda and np.array_equal(lat.cpu().numpy(), arrays[0]) and mano["global_trans"].shape == (1, 16, 4, 4) and obj["obj_trans"].shape == (1, 4, 4)
+
+
+def test_code_sources_on_a_cpu_device_need_no_stream(tmp_path):
+    """CodeUploader on a non-CUDA device is a plain conversion (the CPU tests and tools construct code sources with device="cpu")."""
+    from alignsdf_amd.reconstruct import CodeUploader, npz_code_source
+    up = CodeUploader("cpu")
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)[:, ::2]          # (not contiguous)
+    y = up(x)
+    assert y.device.type == "cpu" and y.dtype == torch.float32 and np.array_equal(y.numpy(), x) and up.stream is None
+    np.savez(tmp_path / "a.npz", latent=np.ones((1, 256), np.float64), obj_trans=np.eye(4)[None])
+    lat, mano, obj = npz_code_source(str(tmp_path), device="cpu")("a", 0)
+    assert lat.dtype == torch.float32 and mano is None and obj["obj_trans"].dtype == torch.float32 and obj["obj_trans"].shape == (1, 4, 4)
