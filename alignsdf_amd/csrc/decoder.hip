@@ -1186,12 +1186,15 @@ int asdf_zoom_cube(const int32_t* bbox_dev, int32_t N, float voxel_size, int32_t
   return ASDF_OK;
 }
 
-// the audit of a one-plane sweep: min(d->audit_n, P / 16) voxels the sweep decided by sign alone are appended to list[*count ..] -
+// the audit of a one-plane sweep: min(d->audit_n, P / 64) voxels the sweep decided by sign alone are appended to list[*count ..] -
 // half of them drawn uniformly (audit_pick_kernel), half from the at-risk shell (shell_count_kernel / shell_pick_kernel) - and the
-// seed advances.  The small lattices pay a sixteenth of their own size, not a sample sized for 256^3.
+// seed advances.  The small lattices pay a share of their own size, not a sample sized for 256^3 (round 5: a
+// 64th - still four times the share of the lattice that 65 536 picks are at N = 256.  At a sixteenth a 128^3 lattice paid the full
+// 256^3 sample, 5 % of its sample time.  The shell half stays exhaustive wherever the shell is smaller than its budget - hundreds to
+// thousands of voxels on these lattices - and the uniform half's size enters the tail ratio the estimate is corrected with).
 static int audit_size(const asdf_decoder* d, long long P) {
   if (d->audit_n <= 0) return 0;
-  const long long cap = P / 16 > 64 ? P / 16 : 64;
+  const long long cap = P / 64 > 64 ? P / 64 : 64;
   return (long long)d->audit_n < cap ? d->audit_n : (int)cap;
 }
 static int enqueue_audit_picks(asdf_decoder* d, const float* a, const float* b, const unsigned char* mark, long long P, float tau,

@@ -591,7 +591,7 @@ class HipSdfDecoder:
         """(uniform picks, shell budget) per sweep and head on a lattice of `points` voxels - csrc/decoder.hip: audit_size."""
         if audit_voxels <= 0:
             return 0, 0
-        n = int(min(audit_voxels, max(points // 16, 64)))
+        n = int(min(audit_voxels, max(points // 64, 64)))
         return n - n // 2, n // 2
 
     def _tail_for(self, points, which="coarse"):

@@ -182,7 +182,7 @@ int asdf_decode_grid_dev(asdf_decoder_t* dec, int32_t N, const float* lattice_de
  * carried that way (0: the caller runs ordinary sweeps).  Changes with asdf_decoder_set_act_scales. */
 int asdf_decoder_one_plane_usable(const asdf_decoder_t* dec);
 
-/* The audit sample of the one-plane sweeps above: min(`voxels`, lattice / 16) per sweep and head (0 switches it off, at most
+/* The audit sample of the one-plane sweeps above: min(`voxels`, lattice / 64) per sweep and head (0 switches it off, at most
  * 262144; default 65536) - half drawn uniformly from the voxels decided by sign alone, half from the at-risk shell among them -
  * with a splitmix64 stream that starts at `seed` and advances with every sweep - so a run is reproducible and
  * no two sweeps look at the same voxels. */
