@@ -174,19 +174,33 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const IcpGrid* grid, co
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   const int ncell = grid->ncell, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int base = 0; base < ncell; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < ncell ? counts[i] : 0;
-    int x = v;
+  // four consecutive cells per thread as ONE 16-byte load (coalesced): 110 k cells are 27 rounds of this one workgroup, not 108.
+  // (counts is zeroed up to the workspace's capacity, a multiple of 64 ints: reading the vector that straddles ncell is in bounds)
+  for (int base = 0; base < ncell; base += 4096) {
+    const int i0 = base + 4 * threadIdx.x;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i0 < ncell) v = *reinterpret_cast<const int4*>(counts + i0);
+    if (i0 + 1 >= ncell) v.y = 0;
+    if (i0 + 2 >= ncell) v.z = 0;
+    if (i0 + 3 >= ncell) v.w = 0;
+    const int run = v.x + v.y + v.z + v.w;
+    int x = run;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int y = __shfl_up(x, m); if (lane >= m) x += y; }
     if (lane == 63) wsum[w] = x;
     __syncthreads();
-    int off = carry;
+    int off = carry + x - run;
     for (int k = 0; k < w; ++k) off += wsum[k];
-    if (i < ncell) { starts[i] = off + x - v; cursor[i] = off + x - v; }
+    const int4 o = make_int4(off, off + v.x, off + v.x + v.y, off + v.x + v.y + v.z);
+    if (i0 + 3 < ncell) {
+      *reinterpret_cast<int4*>(starts + i0) = o;
+      *reinterpret_cast<int4*>(cursor + i0) = o;
+    } else if (i0 < ncell) {
+      const int e[4] = {o.x, o.y, o.z, o.w};
+      for (int k = 0; k < 4 && i0 + k < ncell; ++k) { starts[i0 + k] = e[k]; cursor[i0 + k] = e[k]; }
+    }
     __syncthreads();
-    if (threadIdx.x == 1023) carry = off + x;
+    if (threadIdx.x == 1023) carry = off + run;
     __syncthreads();
   }
   if (threadIdx.x == 0) starts[ncell] = carry;
@@ -346,11 +360,18 @@ __global__ __launch_bounds__(kIcpThreads) void icp_update_kernel(const double* _
   if (threadIdx.x == 0) last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  if (threadIdx.x < 64) __threadfence();
-  if (threadIdx.x < kIcpSums) {
-    double a = 0;
-    for (unsigned b = 0; b < gridDim.x; ++b) a += ((volatile double*)partials)[(size_t)b * kIcpSums + threadIdx.x];
-    red[0][threadIdx.x] = a;
+  if (threadIdx.x < 64) {
+    // the block sums (at most kIcpUpdateGrid = 64 of them: one per lane), added by a fixed butterfly - the same tree every run.
+    // (nine serial loops over the partial sums by nine threads were 19 of the kernel's 20 us)
+    __threadfence();
+    static_assert(kIcpUpdateGrid <= 64, "one partial sum per lane");
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) {
+      double a = threadIdx.x < gridDim.x ? ((volatile double*)partials)[(size_t)threadIdx.x * kIcpSums + k] : 0.0;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+      if (threadIdx.x == 0) red[0][k] = a;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
