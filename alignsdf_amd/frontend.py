@@ -23,16 +23,26 @@ import torch.nn as nn
 def model_output_code_source(decode_fn, device="cuda"):
     """decode_fn(name, index) -> (latent [1, L] (or a [1, C, H, W] feature map under PixelAlign), mano_results or None,
     obj_results or None) exactly as utils.decode_model_output returns them (utils/utils.py:620-625)."""
+    from .reconstruct import CodeUploader
+    up = CodeUploader(device)
+
+    def on_device(t):
+        # codes that are still on the host travel through the pinned ring + side stream: a plain .to(device) of pageable memory is
+        # a synchronous copy behind every pass already queued (reconstruct.CodeUploader)
+        t = t.detach()
+        if t.device.type == "cpu" and torch.device(device).type == "cuda":
+            return up(t.to(torch.float32).numpy())
+        return t.to(device=device, dtype=torch.float32)
+
     def source(name, index):
         latent, mano_results, obj_results = decode_fn(name, index)
-        lat = latent.detach().to(device=device, dtype=torch.float32)
+        lat = on_device(latent)
         mano = obj = None
         if mano_results is not None:
             # the decoder path reads global_trans / rot_center (kinematic_embedding) and, under PixelAlign, joints
-            mano = {k: mano_results[k].detach().to(device=device, dtype=torch.float32)
-                    for k in ("global_trans", "rot_center", "joints") if k in mano_results}
+            mano = {k: on_device(mano_results[k]) for k in ("global_trans", "rot_center", "joints") if k in mano_results}
         if obj_results is not None:
-            obj = {"obj_trans": obj_results["obj_trans"].detach().to(device=device, dtype=torch.float32)}
+            obj = {"obj_trans": on_device(obj_results["obj_trans"])}
         return lat, mano, obj
     return source
 
