@@ -368,45 +368,55 @@ __global__ __launch_bounds__(256) void extend_box_from_list_kernel(const float* 
 // active only if its corners' one-plane signs are mixed or one of them is undecided (|v| < tau): for those cells all eight
 // corners are marked for exact re-evaluation; every other cell is inactive whatever the error, and its corners are never read.
 // One thread per 4 x-consecutive cells, like mc_classify: 4 corner rows of 5 values.
+// (round 5: z from blockIdx.y, (y, group) from a 32-bit index - no 64-bit divisions - and the four corner rows as one 16-byte load
+// plus one word each where the row length allows: 80 -> about 30 us per 256^3 volume; same marks)
 __global__ __launch_bounds__(256) void band_mark_kernel(const float* __restrict__ vol, int N, float tau, unsigned char* __restrict__ mark) {
-  const int cx = N - 1, cxp = (cx + 3) & ~3, groups = cxp >> 2;
-  const long long total = (long long)groups * cx * cx;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const int x0 = (int)(g % groups) * 4;
-    const long long r = g / groups;
-    const int y = (int)(r % cx), z = (int)(r / cx);
-    const float* r00 = vol + ((size_t)z * N + y) * N;
-    const float* rows[4] = {r00, r00 + N, r00 + (size_t)N * N, r00 + (size_t)N * N + N};
-    unsigned pos[4], neg[4];           // bit i: value i of the row is certainly positive / certainly negative
+  const int cx = N - 1, groups = (cx + 3) >> 2;
+  const int per_slab = groups * cx;                   // (y, group) pairs of one z
+  const bool vec = (N & 3) == 0;                      // rows start 16-byte aligned and x0 is a multiple of 4
+  for (int z = blockIdx.y; z < cx; z += gridDim.y) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < per_slab; g += gridDim.x * blockDim.x) {
+      const int y = g / groups, x0 = (g - y * groups) * 4;
+      const float* r00 = vol + ((size_t)z * N + y) * N;
+      const float* rows[4] = {r00, r00 + N, r00 + (size_t)N * N, r00 + (size_t)N * N + N};
+      unsigned pos[4], neg[4];           // bit i: value i of the row is certainly positive / certainly negative
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      pos[q] = neg[q] = 0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        if (x0 + i < N) {
-          const float v = rows[q][x0 + i];
-          pos[q] |= (v >= tau ? 1u : 0u) << i;
-          neg[q] |= (v < -tau ? 1u : 0u) << i;
+      for (int q = 0; q < 4; ++q) {
+        float v[5];
+        if (vec) {
+          const float4 t = *reinterpret_cast<const float4*>(rows[q] + x0);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          v[4] = x0 + 4 < N ? rows[q][x0 + 4] : 0.0f;
         } else {
-          pos[q] |= 1u << i; neg[q] |= 1u << i;      // beyond the row: neutral for the AND reductions below, cells there are masked off
+#pragma unroll
+          for (int i = 0; i < 5; ++i) v[i] = x0 + i < N ? rows[q][x0 + i] : 0.0f;
+        }
+        pos[q] = neg[q] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          if (x0 + i < N) {
+            pos[q] |= (v[i] >= tau ? 1u : 0u) << i;
+            neg[q] |= (v[i] < -tau ? 1u : 0u) << i;
+          } else {
+            pos[q] |= 1u << i; neg[q] |= 1u << i;      // beyond the row: neutral for the AND reductions below, cells there are masked off
+          }
         }
       }
-    }
-    // a cell is certainly inactive iff all 8 corners are certainly positive, or all certainly negative
-    const unsigned ap = pos[0] & pos[1] & pos[2] & pos[3], an = neg[0] & neg[1] & neg[2] & neg[3];
-    const int ncell = min(4, cx - x0);
-    const unsigned inactive = (ap & (ap >> 1)) | (an & (an >> 1));
-    const unsigned cand = ~inactive & ((1u << ncell) - 1);
-    if (!cand) continue;
-    // corners of the candidate cells: columns x0 + i and x0 + i + 1 of the four rows
-    const unsigned cols = (cand | (cand << 1)) & 0x1fu;
+      // a cell is certainly inactive iff all 8 corners are certainly positive, or all certainly negative
+      const unsigned ap = pos[0] & pos[1] & pos[2] & pos[3], an = neg[0] & neg[1] & neg[2] & neg[3];
+      const int ncell = min(4, cx - x0);
+      const unsigned inactive = (ap & (ap >> 1)) | (an & (an >> 1));
+      const unsigned cand = ~inactive & ((1u << ncell) - 1);
+      if (!cand) continue;
+      // corners of the candidate cells: columns x0 + i and x0 + i + 1 of the four rows
+      const unsigned cols = (cand | (cand << 1)) & 0x1fu;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned char* m = mark + (rows[q] - vol);
+      for (int q = 0; q < 4; ++q) {
+        unsigned char* m = mark + (rows[q] - vol);
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
-        if ((cols >> i) & 1) m[x0 + i] = 1;
+        for (int i = 0; i < 5; ++i)
+          if ((cols >> i) & 1) m[x0 + i] = 1;
+      }
     }
   }
 }
@@ -1391,10 +1401,10 @@ static int decode_grid_band_impl(asdf_decoder_t* d, int32_t N, const float* orig
   for (int h = 0; h < (two_out ? 1 : 2); ++h) {
     if (!vols[h]) continue;
     ASDF_HIP(hipMemsetAsync(d->band_mark, 0, (size_t)P, st));
-    const long long groups = (long long)(((N - 1) + 3) >> 2) * (N - 1) * (N - 1);
-    const int mgrid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
-    hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[h], N, tau, d->band_mark);
-    if (two_out) hipLaunchKernelGGL(band_mark_kernel, dim3(mgrid), dim3(256), 0, st, vols[1], N, tau, d->band_mark);
+    const int per_slab = (((N - 1) + 3) >> 2) * (N - 1);          // (y, group of four x-consecutive cells) pairs per z
+    const dim3 mgrid((per_slab + 255) / 256, N - 1 < 1024 ? N - 1 : 1024);
+    hipLaunchKernelGGL(band_mark_kernel, mgrid, dim3(256), 0, st, vols[h], N, tau, d->band_mark);
+    if (two_out) hipLaunchKernelGGL(band_mark_kernel, mgrid, dim3(256), 0, st, vols[1], N, tau, d->band_mark);
     const long long items = (P + 15) / 16;
     const int cgrid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     int* list = d->band_idx + (size_t)h * kBandCap;
