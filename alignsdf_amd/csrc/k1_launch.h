@@ -16,7 +16,12 @@ struct ShortParams {
   float* xchg;          // [clusters][kXchgFloats]
   int* arrivals;        // [clusters][4] (three in use): multiples of 4 between launches
   int cluster_max;      // lists of up to this many points take the cluster form (0 = never)
+  int* fault;           // device word (the decoder's status[11]), sticky: a member waited longer than `timeout_ticks` for another one.
+                        // A cluster that sees it writes NO output; the tile form enqueued behind the launch evaluates the list instead
+                        // (DecodeParams::short_fault) and the host switches the cluster form off when it reads the word
+  unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a member waits for the others before it gives up
 };
+constexpr unsigned long long kClusterTimeoutTicks = 100000000ull;              // 1 s: a healthy wait is microseconds
 
 // raise the dynamic-LDS limit of the family's kernels (once per process; cheap)
 hipError_t k1_prepare();

@@ -28,6 +28,9 @@ struct CcHeader {
   int valid;        // qualifying components
   int best;         // root (= first face) of the component that is kept when valid > 1
   int out_v, out_f;
+  int open_dropped;   // components of >= 4 faces that do not qualify because an edge is shared by a number of faces other than two -
+                      // the only place where trimesh's fill_holes (not reproduced: PARITY UNPINNED) could have changed the outcome
+  int small_dropped;  // components of fewer than 4 faces (graph.split's min_len)
 };
 
 __global__ void cc_edges_kernel(const int* __restrict__ faces, int F, unsigned long long V, unsigned long long* keys, int* owner,
@@ -143,16 +146,22 @@ __global__ __launch_bounds__(1024) void cc_select_kernel(const int* __restrict__
                                                          CcHeader* hdr) {
   __shared__ double s_area[1024];
   __shared__ int s_root[1024], s_valid[1024];
+  __shared__ int s_open, s_small;
+  if (threadIdx.x == 0) { s_open = 0; s_small = 0; }
+  __syncthreads();
   double best_a = -1.0;
-  int best_r = 0x7fffffff, valid = 0;
+  int best_r = 0x7fffffff, valid = 0, n_open = 0, n_small = 0;
   for (int f = threadIdx.x; f < F; f += 1024) {
     if (label[f] != f) continue;                        // roots only
-    if (size[f] < 4 || open_comp[f]) continue;          // graph.split: min_len 4, only_watertight
+    if (size[f] < 4) { ++n_small; continue; }           // graph.split: min_len 4 ...
+    if (open_comp[f]) { ++n_open; continue; }           // ... only_watertight
     ++valid;
     const double a = area[f];
     if (a > best_a || (a == best_a && f < best_r)) { best_a = a; best_r = f; }   // first maximum in order of first faces
   }
   s_area[threadIdx.x] = best_a; s_root[threadIdx.x] = best_r; s_valid[threadIdx.x] = valid;
+  if (n_open) atomicAdd(&s_open, n_open);
+  if (n_small) atomicAdd(&s_small, n_small);
   __syncthreads();
   for (int m = 512; m >= 1; m >>= 1) {
     if ((int)threadIdx.x < m) {
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(1024) void cc_select_kernel(const int* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { hdr->valid = s_valid[0]; hdr->best = s_root[0]; }
+  if (threadIdx.x == 0) { hdr->valid = s_valid[0]; hdr->best = s_root[0]; hdr->open_dropped = s_open; hdr->small_dropped = s_small; }
 }
 
 __global__ void cc_fill_kernel(int* a, int n, int value) {
@@ -188,6 +197,7 @@ __global__ void cc_fill_all_if_unchanged_kernel(int* used, int V, const CcHeader
 
 __global__ void cc_counts_kernel(const CcHeader* hdr, int* counts) {
   counts[0] = hdr->out_v; counts[1] = hdr->out_f; counts[2] = hdr->valid; counts[3] = hdr->best;
+  counts[4] = hdr->open_dropped; counts[5] = hdr->small_dropped; counts[6] = 0; counts[7] = 0;
 }
 
 __global__ void cc_compact_kernel(const float* __restrict__ verts, const int* __restrict__ faces, int V, int F,
@@ -289,7 +299,8 @@ int asdf_mesh_largest_component(const float* verts_dev, int32_t V, const int32_t
   hipLaunchKernelGGL(cc_compact_kernel, dim3(gm), dim3(T), 0, st, verts_dev, faces_dev, V, F, keep, fpos, used, vpos, out_verts_dev,
                      out_faces_dev, hdr);
   ASDF_HIP(hipGetLastError());
-  // counts: [0] kept vertices, [1] kept faces, [2] qualifying components, [3] root (first face) of the kept component
+  // counts[8]: [0] kept vertices, [1] kept faces, [2] qualifying components, [3] root (first face) of the kept component, [4] open
+  // components of >= 4 faces that did not qualify, [5] components of < 4 faces, [6..7] zero
   hipLaunchKernelGGL(cc_counts_kernel, dim3(1), dim3(1), 0, st, hdr, counts_dev);
   ASDF_HIP(hipGetLastError());
   return ASDF_OK;

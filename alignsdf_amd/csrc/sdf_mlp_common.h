@@ -60,6 +60,9 @@ struct DecodeParams {
   const int* count_dev;     // kGridSubset: number of listed points (device word; P is the capacity)
   int short_max;            // kGridSubset, fp32 chain: lists of up to this many points belong to the short-list form
                             // (sdf_mlp_short_kernel.h) - it returns for longer ones, the tile form for these; 0 = no such split
+  const int* short_fault;   // kGridSubset, fp32 chain: when non-null and *short_fault != 0 the TILE form takes the short lists as well - a
+                            // cluster-form launch in front of it timed out waiting for a member and wrote nothing for that block
+                            // (sdf_mlp_short_kernel.h: the recoverable failure of round 6); the results are the same bits
   int grid_mode;            // kGridSubset: kGridReference / kGridInteger of the lattice
   int* fixup_flag;          // kGridSubset with bbox: the outputs REPLACE earlier values - the box is patched in place (a voxel
                             // that turns negative extends it) and *fixup_flag is raised when one turns non-negative

@@ -104,7 +104,9 @@ __device__ __forceinline__ void sdf_mlp_body(const DecodeParams& p) {
   if (p.mode == kGridSubset) {
     const long long c = *p.count_dev;
     npts = c < npts ? c : npts;
-    if (KP == 2 && !CLS && p.short_max > 0 && npts <= (long long)p.short_max) return;      // the short-list form's (sdf_mlp_short_kernel.h)
+    // the short-list form's (sdf_mlp_short_kernel.h) - unless its cluster form has reported a member that never arrived: then this
+    // launch, which is enqueued behind it anyway, evaluates the list (bit-identical results, no extra launch)
+    if (KP == 2 && !CLS && p.short_max > 0 && npts <= (long long)p.short_max && !(p.short_fault && *p.short_fault != 0)) return;
   }
   const long long ntiles = (npts + kWgPts - 1) / kWgPts;
   if ((long long)blockIdx.x >= ntiles) return;

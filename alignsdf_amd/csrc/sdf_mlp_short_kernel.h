@@ -28,6 +28,10 @@
 // workgroups are dispatched in id order, so the members a waiting workgroup spins on are resident or next in line whatever else
 // holds compute units (the audit of a box sweep runs beside this kernel on another stream).  Results are bit-identical to both
 // other forms: same per-tile instruction sequence, same last layer (tests/test_gpu_short_list.py).
+// Round 6: a member that waits longer than ShortParams::timeout_ticks (1 s) no longer traps - it raises a sticky fault word, the
+// cluster writes nothing, and the tile form enqueued behind the launch evaluates the list (see await below); the host switches the
+// cluster form off for the decoder when it reads the word (HipSdfDecoder._note_cluster_fault).  The arrival counters and the exchange
+// buffer belong to the decoder: a decoder is driven from ONE stream at a time (handles are not re-entrant).
 #pragma once
 #include "k1_launch.h"
 #include "sdf_mlp_kernel.h"
@@ -225,6 +229,8 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
     // publish: this workgroup's tile stores become visible device-wide, then one arrival; await: all four have arrived.  (Between the
     // two a wave issues the first weights of its next tile: they travel while it waits.)
     unsigned all = 0;                                          // (unsigned: the counters wrap after 2^30 launches - days of 64^3 samples - and the comparison below survives that)
+    __shared__ int s_gave_up;                                  // this workgroup has stopped waiting (see await)
+    if (tid == 0) s_gave_up = 0;
     auto publish = [&](int which) {
       __threadfence();
       __syncthreads();
@@ -234,14 +240,22 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
       }
     };
     auto await = [&](int which) {
-      if (tid == 0) {
-        // (bounded: the other members are resident or next in line - see the header - so this takes microseconds.  A device on which
-        // they can never become resident (fewer than four workgroup slots: a CU mask) would spin forever and hang the queue; the host
-        // does not select this form there (decoder.hip), and should the assumption ever fail the wave traps after ~1 s instead)
-        unsigned spins = 0;
+      if (tid == 0 && !s_gave_up) {
+        // The other members are resident or next in line (see the header), so this takes microseconds.  Forward progress of an
+        // ordinary launch whose workgroups wait for each other is an ASSUMPTION (in-order dispatch, enough free workgroup slots: a CU
+        // mask, a partitioned device or another process's persistent kernels can break it), so the wait is bounded and its failure is
+        // RECOVERABLE (round 6; it used to trap, which takes the whole HIP context along): the member raises the decoder's sticky
+        // fault word - BEFORE its remaining arrivals, which it still makes, so that the counters stay multiples of four and nobody
+        // else waits for it - and stops waiting; whoever runs the last layer of a cluster sees the word behind its acquire and writes
+        // nothing; the tile form enqueued behind this launch then evaluates the list (DecodeParams::short_fault), same bits.
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((int)(__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all) < 0) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) __builtin_trap();
+          if (__builtin_amdgcn_s_memrealtime() - t0 > sp.timeout_ticks) {
+            __hip_atomic_store(sp.fault, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_gave_up = 1;
+            break;
+          }
         }
       }
       __syncthreads();
@@ -286,6 +300,10 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
     publish(2);
     if (member != 0) return;                                   // the last layer is member 0's
     await(2);
+    // a member of this cluster that gave up raised the fault word before its last arrival, and the await above acquired all four:
+    // this block's activations may be stale - nothing is written (the word is sticky: until the host has switched the cluster form
+    // off every cluster launch leaves its list to the tile form behind it)
+    if (__hip_atomic_load(sp.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     fetch(bufY, x3, kTilesHidden);
     if (wave != 0) return;
     short_last_layer<TWO_OUT>(p, hc, bufY, lane, half, head, valid, po);

@@ -279,9 +279,81 @@ def gather_records(local_records, group=None):
     return merged
 
 
-def run_sharded(num_items, process_range, backend=None):
+class ShardFailure(RuntimeError):
+    """One or more shards of a sharded run failed.  `failed` = [{"rank", "range", "error"}] as far as this rank knows, `merged` = the
+    records that did arrive (rank 0; None elsewhere or when the collective itself broke - the shard files on disk are then the
+    record: merge_shard_files)."""
+
+    def __init__(self, message, failed, merged=None):
+        super().__init__(message)
+        self.failed, self.merged = failed, merged
+
+
+def shard_records_path(shard_dir, start, end):
+    return os.path.join(shard_dir, "records_%d_%d.json" % (int(start), int(end)))
+
+
+def write_shard_records(shard_dir, start, end, rank, records, error=None):
+    """`<shard_dir>/records_<start>_<end>.json`, written by every rank BEFORE it enters any collective: whatever
+    happens to the gather - a peer that raised, a peer that died, a watchdog timeout - what this shard produced is on disk.  Only
+    the RECORD_FIELDS (+ name) of each record; written to a temporary name and renamed, so a reader never sees half a file."""
+    os.makedirs(shard_dir, exist_ok=True)
+    keep = RECORD_FIELDS + ("name",)
+    body = {"rank": int(rank), "range": [int(start), int(end)], "status": "ok" if error is None else "failed",
+            "error": None if error is None else "%s: %s" % (type(error).__name__, error),
+            "records": [{k: r[k] for k in keep if k in r} for r in records]}
+    path = shard_records_path(shard_dir, start, end)
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        json.dump(body, f)
+    os.replace(tmp, path)
+    return path
+
+
+def merge_shard_files(shard_dir, num_items, world_size):
+    """(records sorted by index, shards) from the records_<start>_<end>.json files of THIS run's ranges (shard_range per rank - files
+    of an earlier run with another world size are not looked at).  `shards` = one entry per rank: {"rank", "range", "status":
+    "ok" | "failed" | "missing", "samples", "error"}.  What rank 0 falls back to when the gather could not complete, and what
+    `--merge-only` runs after a job that was torn down."""
+    records, shards = [], []
+    for r in range(int(world_size)):
+        a, b = shard_range(num_items, world_size, r)
+        entry = {"rank": r, "range": [a, b], "status": "missing", "samples": 0, "error": None}
+        try:
+            with open(shard_records_path(shard_dir, a, b)) as f:
+                body = json.load(f)
+            entry.update(status=body.get("status", "ok"), samples=len(body.get("records", [])), error=body.get("error"))
+            for rec in body.get("records", []):
+                records.append(dict(rec, rank=r))
+        except (OSError, ValueError):
+            pass
+        shards.append(entry)
+    records.sort(key=lambda x: x["index"])
+    return records, shards
+
+
+def _group_timeout():
+    """Process-group timeout (seconds): ASDF_DIST_TIMEOUT, default 1800 - a rank that dies leaves the others in a collective until
+    the backend notices (gloo: at once; RCCL: this long), never forever."""
+    import datetime
+    try:
+        sec = float(os.environ.get("ASDF_DIST_TIMEOUT", "1800"))
+    except ValueError:
+        sec = 1800.0
+    return datetime.timedelta(seconds=max(sec, 1.0))
+
+
+def run_sharded(num_items, process_range, backend=None, shard_dir=None):
     """Initialise the process group from the torchrun environment, run `process_range(start, end, rank)` on this
-    rank's shard and gather the records on rank 0."""
+    rank's shard and gather the records on rank 0 (returned there, None elsewhere).
+
+    Failure handling (round 6; the reference's fire-and-forget Popens, dist_reconstruct.py:80-84, let the
+    surviving shards finish - so does this): a rank whose process_range RAISES still writes what it has (`shard_dir`), still enters
+    every collective - first an all_gather of one error flag per rank, then the record gather with whatever records it completed
+    (an exception may carry them as `partial_records`) - and only then raises ShardFailure, on every rank, naming the failed
+    shards; rank 0's exception carries the merged records of all the others.  A rank that DIES breaks the collective for the others
+    within the process-group timeout; they raise ShardFailure with `merged=None` and the shard files on disk are the record."""
+    import logging
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -298,21 +370,61 @@ def run_sharded(num_items, process_range, backend=None):
     created = False
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_group_timeout())
         created = True
     start, end = shard_range(num_items, world, rank)
+    error, failed, merged = None, [], None
     try:
-        records = process_range(start, end, rank)
-        merged = gather_records(records) if world > 1 else sorted(records, key=lambda x: x["index"])
-        if created:
-            dist.barrier()
-            dist.destroy_process_group()
+        try:
+            records = process_range(start, end, rank)
+        except Exception as e:                     # (KeyboardInterrupt / SystemExit end the rank: the others time out on it)
+            error = e
+            records = list(getattr(e, "partial_records", []) or [])
+            logging.exception("rank %d: shard %d..%d failed after %d samples", rank, start, end, len(records))
+        if shard_dir is not None:
+            try:
+                write_shard_records(shard_dir, start, end, rank, records, error)
+            except OSError as e:
+                logging.error("rank %d: cannot write its shard records to %s: %s", rank, shard_dir, e)
+        if world > 1:
+            try:
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                flags = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+                dist.all_gather(flags, torch.tensor([0 if error is None else 1], dtype=torch.int64, device=dev))
+                failed = [{"rank": r, "range": list(shard_range(num_items, world, r)), "error": None} for r, f in enumerate(flags) if int(f.item())]
+                merged = gather_records(records)
+                if created:
+                    dist.barrier()
+                    dist.destroy_process_group()
+            except Exception as e:                 # a peer is gone (or the watchdog fired): the shard files are the record now
+                logging.error("rank %d: the record gather did not complete (%s: %s)", rank, type(e).__name__, e)
+                raise ShardFailure("rank %d: a peer left the sharded run before the gather (%s)" % (rank, e),
+                                   [{"rank": None, "range": None, "error": "%s: %s" % (type(e).__name__, e)}], None) from e
+        else:
+            merged = sorted(records, key=lambda x: x["index"])
+            failed = [{"rank": 0, "range": [start, end], "error": None}] if error is not None else []
     finally:
         restore_host_cores()                       # the rank's core mask does not outlive the sharded run
+    if failed:
+        for f in failed:
+            if f["rank"] == rank and error is not None:
+                f["error"] = "%s: %s" % (type(error).__name__, error)
+        raise ShardFailure("shard(s) of rank(s) %s failed" % ", ".join(str(f["rank"]) for f in failed), failed, merged) from error
     return merged
 
 
+def write_summary(output_dir, records, shards):
+    """`reconstruct_summary.json`: {"complete", "records" (sorted by sample index), "shards" (one entry per rank: range, status,
+    samples, error)}."""
+    body = {"complete": all(s["status"] == "ok" for s in shards), "samples": len(records), "shards": shards, "records": records}
+    path = os.path.join(output_dir, "reconstruct_summary.json")
+    with open(path, "w") as f:
+        json.dump(body, f)
+    return path
+
+
 def main(argv=None):
+    import sys
     from . import reconstruct as rc
     p = argparse.ArgumentParser(description="Generate meshes in parallel (one process per GPU under torchrun)")
     p.add_argument("--experiment", "-e", dest="experiment_directory", required=True)
@@ -324,48 +436,83 @@ def main(argv=None):
     p.add_argument("--data_root", default="data")
     p.add_argument("--cube_dim", type=int, default=128)
     p.add_argument("--split", dest="split_filename", default=None, help="default: input/<task>.json like the reference")
-    p.add_argument("--coarse", choices=["exact", "box"], default=None,
-                   help="coarse pass: the audited box-only one-plane sweep with exact re-evaluation of the voxels that can move the "
-                        "zoom cube (default; same cubes while its calibrated bound holds, checked on every sweep) or an ordinary sweep")
-    p.add_argument("--fine", choices=["exact", "band"], default=None,
-                   help="fine pass: the audited narrow-band sweep (default: one fp16 plane, the corners of every cell that can be "
-                        "active re-evaluated as an ordinary sweep would - identical meshes while the bound holds, checked on every "
-                        "sweep) or an ordinary sweep")
+    p.add_argument("--merge-only", dest="merge_only", type=int, default=None, metavar="WORLD_SIZE",
+                   help="no reconstruction: build reconstruct_summary.json / sweeps.json from the records_*.json / sweeps_*.json the "
+                        "ranks of a WORLD_SIZE-rank run left in Eval_<task>/ (after a job that was torn down before its gather)")
+    rc.add_sweep_arguments(p)       # --fast / --coarse / --fine: ordinary sweeps (every voxel at <= 1e-5) unless the caller opts in
     args = p.parse_args(argv)
-    if args.coarse:
-        os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
-    if args.fine:
-        os.environ["ASDF_FINE"] = args.fine
+    rc.apply_sweep_arguments(args)
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     names = json.load(open(split))["filenames"]
-    specs, decoder = rc.load_experiment(args.experiment_directory)
     output_dir = os.path.join(args.experiment_directory, "Eval_" + args.task)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.merge_only is None else int(args.merge_only)
+    rank = int(os.environ.get("RANK", "0"))
+
+    def finish(records, shards):
+        """Rank 0: the summary files and the lines a user reads."""
+        write_summary(output_dir, records, shards)
+        ranges = [tuple(s["range"]) for s in shards]
+        summary = rc.merge_sweeps_json(output_dir, ranges=ranges)
+        print(rc.sweeps_summary_line(json.load(open(summary))["totals"]) + " (%s)" % summary)
+        print("reconstructed %d samples" % len(records))
+        skipped = sum(1 for r in records if r.get("icp_skipped"))
+        if skipped:
+            print("WARNING: %d of them were written WITHOUT the eval-mode alignment (no ground-truth mesh)" % skipped)
+        bad = [s for s in shards if s["status"] != "ok"]
+        for s in bad:
+            print("FAILED SHARD: rank %d, samples %d..%d: %s (%d samples of it are in the summary)%s" % (
+                s["rank"], s["range"][0], s["range"][1] - 1, s["status"], s["samples"], " - %s" % s["error"] if s["error"] else ""), flush=True)
+        return 1 if bad else 0
+
+    if args.merge_only is not None:
+        sys.exit(finish(*merge_shard_files(output_dir, len(names), world)))
+
+    specs, decoder = rc.load_experiment(args.experiment_directory)
     source = rc.code_source_from_args(args, specs, p)
 
     def process(start, end, rank):
         print("rank %d: samples %d to %d" % (rank, start, end - 1), flush=True)
-        recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
-                              eval_mode=True, label_out=args.optim, code_source=source, data_root=args.data_root,
-                              allow_missing_gt=args.allow_missing_gt)
+        try:
+            recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
+                                  eval_mode=True, label_out=args.optim, code_source=source, data_root=args.data_root,
+                                  allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None)
+        except Exception as e:
+            for r in getattr(e, "partial_records", []) or []:
+                r["milliseconds"] = 1e3 * r.get("seconds", 0.0)
+            raise
         for r in recs:
             r["milliseconds"] = 1e3 * r["seconds"]
         return recs
 
-    merged = run_sharded(len(names), process)
-    if merged is not None:
-        with open(os.path.join(output_dir, "reconstruct_summary.json"), "w") as f:
-            json.dump(merged, f)
-        # every shard left a sweeps_<start>_<end>.json next to meshes/ (which sweeps produced them, refusals, repeats, mode
-        # switches); rank 0 - behind the gather, i.e. behind every shard's last file - merges them into one sweeps.json
-        summary = rc.merge_sweeps_json(output_dir)
-        tot = json.load(open(summary))["totals"]
-        print("sweeps: %d audited, %d refused, %d repeated%s (%s)" % (
-            tot["sweeps_audited"], tot["sweeps_refused"], tot["sweeps_repeated"],
-            "; MODES SWITCHED OFF: %s" % "; ".join(tot["modes_switched_off"]) if tot["modes_switched_off"] else "", summary))
-        print("reconstructed %d samples" % len(merged))
-        skipped = sum(1 for r in merged if r.get("icp_skipped"))
-        if skipped:
-            print("WARNING: %d of them were written WITHOUT the eval-mode alignment (no ground-truth mesh)" % skipped)
+    try:
+        merged = run_sharded(len(names), process, shard_dir=output_dir)
+        code = 0
+        if merged is not None:
+            shards = [{"rank": r, "range": list(shard_range(len(names), world, r)), "status": "ok", "error": None,
+                       "samples": sum(1 for m in merged if m.get("rank", 0) == r)} for r in range(world)]
+            code = finish(merged, shards)
+    except ShardFailure as e:
+        code = 1
+        if rank == 0:
+            if e.merged is not None:
+                bad = {f["rank"]: f for f in e.failed}
+                shards = [{"rank": r, "range": list(shard_range(len(names), world, r)), "status": "failed" if r in bad else "ok",
+                           "error": bad[r]["error"] if r in bad else None, "samples": sum(1 for m in e.merged if m.get("rank", 0) == r)}
+                          for r in range(world)]
+                # (the failing rank's own message is in its records file; rank 0 only knows its own)
+                for s in shards:
+                    if s["status"] == "failed" and s["error"] is None:
+                        try:
+                            s["error"] = json.load(open(shard_records_path(output_dir, *s["range"]))).get("error")
+                        except (OSError, ValueError):
+                            pass
+                finish(e.merged, shards)
+            else:
+                finish(*merge_shard_files(output_dir, len(names), world))      # a peer is gone: what the ranks left on disk
+        else:
+            print("rank %d: %s" % (rank, e), flush=True)
+    if code:
+        sys.exit(code)
 
 
 if __name__ == "__main__":

@@ -23,15 +23,13 @@ import torch.nn as nn
 def model_output_code_source(decode_fn, device="cuda"):
     """decode_fn(name, index) -> (latent [1, L] (or a [1, C, H, W] feature map under PixelAlign), mano_results or None,
     obj_results or None) exactly as utils.decode_model_output returns them (utils/utils.py:620-625)."""
-    from .reconstruct import CodeUploader
-    up = CodeUploader(device)
-
     def on_device(t):
-        # codes that are still on the host travel through the pinned ring + side stream: a plain .to(device) of pageable memory is
-        # a synchronous copy behind every pass already queued (reconstruct.CodeUploader)
+        # codes that are still on the HOST stay there (round 6): the HIP decoder's set_sample reads them from pinned memory in stream
+        # order and the module path uploads what it needs itself - a plain .to(device) of pageable memory would be a synchronous copy
+        # behind every pass already queued, and the runtime's blit of 1 KB cannot get a wave slot under a persistent sweep
         t = t.detach()
-        if t.device.type == "cpu" and torch.device(device).type == "cuda":
-            return up(t.to(torch.float32).numpy())
+        if t.device.type == "cpu":
+            return t.to(torch.float32)
         return t.to(device=device, dtype=torch.float32)
 
     def source(name, index):

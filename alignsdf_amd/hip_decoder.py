@@ -17,16 +17,30 @@ from . import _native
 
 
 DEFAULT_MATH = "f16x3"
-# The one-plane sweeps are the default wherever a pass has ONE consumer that reads signs, or values next to the surface only:
-# the coarse pass of the two-pass flow (consumed through its negative-voxel boxes) and a fine pass whose caller declares
-# `mc_only` (consumed by marching cubes).  Every volume-returning call runs ordinary sweeps whatever these say.
-DEFAULT_COARSE = "box"        # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
-DEFAULT_FINE = "band"         # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
+# Round 6: the DEFAULT of every entry point is the reference's arithmetic class on EVERY voxel of both passes - ordinary sweeps
+# (the split-half kernel: 22-bit operands, fp32 accumulate, <= 1e-5; or the fp32 MFMA chain under ASDF_MATH=f32).  The audited
+# one-plane sweeps (one fp16 plane for the SIGNS of a pass with one consumer, every value that consumer reads
+# re-evaluated exactly, a statistical certificate per sweep) are an OPT-IN: ASDF_FAST=1, `--fast` on the CLIs and bench.py,
+# HipSdfDecoder.set_fast(True), or ASDF_COARSE=box / ASDF_FINE=band one by one.  Every volume-returning call runs ordinary sweeps
+# whatever these say.
+DEFAULT_COARSE = "exact"      # coarse pass of the two-pass flow: "exact" | "box" (HipSdfDecoder.coarse_begin)
+DEFAULT_FINE = "exact"        # fine pass (feeds marching cubes only): "exact" | "band" (HipSdfDecoder.fine_begin)
+FAST_COARSE = "box"           # what --fast / ASDF_FAST=1 select
+FAST_FINE = "band"
+
+
+def fast_requested():
+    """ASDF_FAST set to anything but '' / '0': the audited one-plane sweeps wherever a pass has one consumer."""
+    return os.environ.get("ASDF_FAST", "0") not in ("", "0")
+
+
 BAND_CAP = 1 << 22           # voxels per head the narrow-band sweep can re-evaluate (csrc/decoder.hip: kBandCap)
 NEAR_CAP = 1 << 16           # near-level refinement list of a split-half sweep
 CAND_CAP = 1 << 21           # box candidates of one coarse sweep
 AUDIT_VOXELS = 1 << 16        # per one-plane sweep and head (asdf_decoder_set_audit)
 NEAR_OVERFLOW_BIT = 0x40000000
+CLUSTER_FAULT_BIT = 0x20000000   # bit 29 of word 7 of a sweep's bbox record: the short-list kernel's cluster form reported a member that never arrived
+CODE_SLOTS = 16               # pinned staging slots for the per-sample codes of set_sample's host path
 REC_WORDS = 48                # record of a one-plane sweep (include/alignsdf_hip.h: asdf_decode_grid_box)
 # allowance tau = TAU_FACTOR x the estimated lattice maximum of |one-plane - exact| of recent sweeps; a sweep is accepted while ITS
 # estimate (and the error on its re-evaluated voxels) stays within TAU_ACCEPT x the tau it was launched with - a factor
@@ -251,15 +265,18 @@ class HipSdfDecoder:
         self.refine_tau = 4e-6
         # coarse pass of the two-pass flow: "box" = the one-plane box-only sweep (asdf_decode_grid_box) with exact re-evaluation of
         # the voxels that can move the box and a random audit of the others, "exact" = an ordinary sweep; ASDF_COARSE overrides
-        self.coarse_mode = os.environ.get("ASDF_COARSE", DEFAULT_COARSE)
+        fast = fast_requested()
+        self.coarse_mode = os.environ.get("ASDF_COARSE", FAST_COARSE if fast else DEFAULT_COARSE)
         if self.coarse_mode not in ("exact", "box"):
             raise ValueError("ASDF_COARSE must be 'exact' or 'box', not %r" % self.coarse_mode)
         # fine pass: "band" = one-plane sweep + re-evaluation (as the ordinary sweep would) of the corners of every cell that can be
         # active (asdf_decode_grid_band) + the audit - for volumes that go to marching cubes and nowhere else; "exact" = ordinary
-        self.fine_mode = os.environ.get("ASDF_FINE", DEFAULT_FINE)
+        self.fine_mode = os.environ.get("ASDF_FINE", FAST_FINE if fast else DEFAULT_FINE)
         if self.fine_mode not in ("exact", "band"):
             raise ValueError("ASDF_FINE must be 'exact' or 'band', not %r" % self.fine_mode)
+        self._cluster_off = False    # the cluster form of the short-list kernel has been switched off after a fault report
         self._band_failures = 0
+        self._fine_compare_in_flight = False     # a whole-zoom-lattice comparison has been enqueued and not judged yet
         self._band_skip = False      # the next fine_begin runs an ordinary sweep (a band sweep was just refused)
         self._force_f32_once = False # ... and on the fp32 chain (its near-level list overflowed)
         self.band_stats = self._new_stats("band")
@@ -310,6 +327,11 @@ class HipSdfDecoder:
         _native.check(self._L.asdf_decoder_set_audit(self._h, int(voxels), ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)), "asdf_decoder_set_audit")
         self.audit_voxels = int(voxels)
 
+    def set_fast(self, on=True):
+        """Opt in to (or out of) the audited one-plane sweeps for mesh-producing calls: coarse "box" + fine "band" (what ASDF_FAST=1 /
+        `--fast` select when the decoder is packed), or ordinary sweeps in both passes - the default."""
+        self.coarse_mode, self.fine_mode = (FAST_COARSE, FAST_FINE) if on else ("exact", "exact")
+
     def set_math(self, math):
         """Select the arithmetic of the hidden GEMMs ("f32" / "f16x3"); raises for NeRF-encoded decoders and f16x3."""
         code = {"f32": _native.MATH_F32, "f16x3": _native.MATH_F16X3}[math]
@@ -326,7 +348,23 @@ class HipSdfDecoder:
     def _range_words(rec):
         """(fp16 range violations, near-level list overflowed) of a bbox / sweep record: words 7 / 15, bit 30 = the flag."""
         w = (int(rec[7]), int(rec[15]))
-        return sum(v & (NEAR_OVERFLOW_BIT - 1) for v in w), bool((w[0] | w[1]) & NEAR_OVERFLOW_BIT)
+        return sum(v & (CLUSTER_FAULT_BIT - 1) for v in w), bool((w[0] | w[1]) & NEAR_OVERFLOW_BIT)
+
+    def _note_cluster_fault(self, rec):
+        """Bit 29 of word 7 of a bbox record / word 16 + 11 of a one-plane sweep's record: a member of the short-list kernel's cluster
+        form waited longer than its bound for another one (csrc/sdf_mlp_short_kernel.h).  The sweep the record belongs to is COMPLETE -
+        the tile form behind the launch evaluated the list, same bits - and the form is switched off for this decoder, once, here
+        (a recoverable failure instead of a trap that takes the HIP context along)."""
+        hit = bool(int(rec[7]) & CLUSTER_FAULT_BIT) or (len(rec) > 27 and int(rec[27]) != 0)
+        if hit and not self._cluster_off:
+            import logging
+            logging.warning("short-list kernel: a member of a cluster did not arrive in time; the tile form evaluated the list, the cluster "
+                            "form is switched off for this decoder")
+            self._cluster_off = True
+            self.events["modes_switched_off"].append("cluster form of the short-list kernel: a member did not arrive within the bound")
+            if self._h is not None:
+                _native.check(self._L.asdf_decoder_set_cluster_list(self._h, 0), "asdf_decoder_set_cluster_list")
+        return hit
 
     def fall_back_if_overflowed(self, bbox_host, epoch=None):
         """bbox words 7 / 15 count points whose activations left the fp16 range of the split-half planes; they are non-zero
@@ -339,6 +377,7 @@ class HipSdfDecoder:
         overflow says nothing about them.  Bit 30 (the near-level refinement list overflowed: the signs next to the level are not
         certified to be the fp32 chain's) makes the NEXT sweep of this decoder run on the fp32 chain, once."""
         bad, near_over = self._range_words(bbox_host)
+        self._note_cluster_fault(bbox_host)
         if near_over:
             import logging
             logging.warning("split-half sweep: more than %d voxels within %.1e of the level; repeated on the fp32 chain", NEAR_CAP, self.refine_tau)
@@ -448,37 +487,67 @@ class HipSdfDecoder:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _code_slot(self):
+        """The next pinned staging slot for one sample's codes: (latent [L] fp32, embed [2, MAX_POINT_FEATS, 4] fp32, event).  A slot is
+        reused CODE_SLOTS set_sample calls later, after the event recorded behind ITS staging launch (long done: two or three samples
+        are in flight, each bound at most three times)."""
+        if not hasattr(self, "_code_ring"):
+            self._code_ring = [[torch.zeros(self.latent_size, dtype=torch.float32).pin_memory(),
+                                torch.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=torch.float32).pin_memory(), None] for _ in range(CODE_SLOTS)]
+            self._code_next = 0
+        slot = self._code_ring[self._code_next % CODE_SLOTS]
+        self._code_next += 1
+        if slot[2] is not None:
+            slot[2].synchronize()
+        return slot
+
     def set_sample(self, latent_vec, embed=None):
-        """Bind a latent code [1, L] (any device) and optional per-head affine embeddings (hand_E, obj_E)."""
-        lat = latent_vec.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
-        if lat.numel() != self.latent_size:
-            raise ValueError("latent has %d elements, expected %d" % (lat.numel(), self.latent_size))
+        """Bind a latent code [1, L] and optional per-head affine embeddings (hand_E, obj_E).
+
+        A latent on the DEVICE (the reference's case: it comes out of the encoder, reconstruct.py:83-84) is read where it lies.  A latent
+        on the HOST (codes saved by an encoder run, synthetic codes) is NOT uploaded with a copy: it is placed in a pinned staging slot
+        and the fold's staging launch reads it over the link in stream order (asdf_decoder_set_sample_host) - the runtime's copy of
+        1 KB is a shader blit that cannot get a wave slot while a persistent sweep owns every compute unit (round 5's eval-mode
+        trace: 21.5 ms per sample resident), and a plain `.to(device)` of pageable memory makes the caller wait
+        for everything queued."""
+        if latent_vec.numel() != self.latent_size:
+            raise ValueError("latent has %d elements, expected %d" % (latent_vec.numel(), self.latent_size))
+        host = latent_vec.device.type == "cpu"
+        slot = None
         emb_ptr = None
         if self.nerf_features:
             if embed is not None:
                 raise ValueError("a NeRF-encoded decoder takes raw xyz; no affine embedding applies")
         elif embed is not None:
-            # pinned staging ring: the H2D copy is asynchronous, so a slot must outlive the samples in flight (<= 2)
-            if not hasattr(self, "_emb_ring"):
-                self._emb_ring = [torch.zeros((2, _native.MAX_POINT_FEATS, 4), dtype=torch.float32).pin_memory() for _ in range(6)]
-                self._emb_next = 0
-            slot = self._emb_ring[self._emb_next % len(self._emb_ring)]
-            self._emb_next += 1
-            buf = slot.numpy()
+            slot = self._code_slot()
+            buf = slot[1].numpy()
             buf[:] = 0
             for h in range(len(self._pf)):
                 e = np.asarray(embed[h], dtype=np.float64)
                 if e.shape != (self._pf[h], 4):
                     raise ValueError("embedding of head %d has shape %s, expected %s" % (h, e.shape, (self._pf[h], 4)))
                 buf[h, :self._pf[h]] = e.astype(np.float32)
-            emb_ptr = ctypes.c_void_p(slot.data_ptr())
+            emb_ptr = ctypes.c_void_p(slot[1].data_ptr())
         elif not self.nerf_features and any(f != 3 for f in self._pf):
             raise ValueError("this decoder needs a point embedding (point features per head: %s)" % (self._pf,))
-        self._latent = lat   # keep the device buffer alive until the next set_sample
         self._bound = (latent_vec, embed)
         with torch.cuda.device(self.device):
-            _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
-                          "asdf_decoder_set_sample")
+            if host:
+                slot = slot or self._code_slot()
+                slot[0].copy_(latent_vec.detach().reshape(-1).to(torch.float32))
+                self._latent = None
+                _native.check(self._L.asdf_decoder_set_sample_host(self._h, slot[0].data_ptr(), emb_ptr, self._stream()),
+                              "asdf_decoder_set_sample_host")
+            else:
+                lat = latent_vec.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+                self._latent = lat   # keep the device buffer alive until the next set_sample
+                # (the embedding of a device-side latent still travels by hipMemcpyAsync from the pinned slot, in stream order)
+                _native.check(self._L.asdf_decoder_set_sample(self._h, lat.data_ptr(), emb_ptr, self._stream()),
+                              "asdf_decoder_set_sample")
+            if slot is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                slot[2] = ev
 
     def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True,
                     check_range=None):
@@ -617,6 +686,7 @@ class HipSdfDecoder:
         its error invalidates the allowance instead: the next coarse pass measures the whole lattice again (a refusal
         must not inflate the allowance by itself)."""
         bad, near_over = self._range_words(r)
+        self._note_cluster_fault(r)
         f = lambda w: float(np.int32(r[w]).view(np.float32))
         err, audit = f(19), f(35)
         flips, evals = int(r[36]), int(r[37])
@@ -800,8 +870,8 @@ class HipSdfDecoder:
             if ticket.get("recalibrate") and self._band_usable():
                 self._next_recal = "fine"           # the next periodic comparison measures a zoom lattice
         b = b.copy()
-        b[7] &= NEAR_OVERFLOW_BIT - 1
-        b[15] &= NEAR_OVERFLOW_BIT - 1
+        b[7] &= CLUSTER_FAULT_BIT - 1
+        b[15] &= CLUSTER_FAULT_BIT - 1
         return b
 
     # ---- both passes of a sample ENQUEUED in one go (round 5): the box-only coarse sweep, the zoom cube computed on
@@ -820,8 +890,9 @@ class HipSdfDecoder:
         float32[4]: origin, voxel size), `lattice_host` (pinned copy + event), `vol_hand` / `vol_obj` (the fine volumes)."""
         if not self.can_speculate(N):
             return None
-        if self.combined:
-            hand = obj = True
+        # (a CombinedDecoder evaluates both columns whatever the flags say - the launches force that themselves - but the ZOOM CUBE and
+        # the marching-cubes parts follow the caller's HandBranch / ObjectBranch like get_higher_res_cube, utils/mesh.py:239-247, and the
+        # step-by-step path: ADVICE r05)
         self._coarse_since_cal += 1
         self.events["samples_in_one_go"] += 1
         tau = self._box_tau
@@ -860,7 +931,7 @@ class HipSdfDecoder:
         set to fine_mode "band" deliver them exact next to the surface and sign-correct elsewhere."""
         args = (N, origin3, voxel_size, grid_mode, hand, obj)
         band = mc_only and self._band_usable() and not self._force_f32_once
-        fine_due = self._coarse_since_cal > RECAL_EVERY and self._next_recal == "fine"
+        fine_due = self._coarse_since_cal > RECAL_EVERY and self._next_recal == "fine" and not self._fine_compare_in_flight
         if band and not self._band_skip and self._allowance_valid(N) and self._fine_valid(N) and not fine_due:
             rec, vh, vo = self._one_plane_launch(self._L.asdf_decode_grid_band, "asdf_decode_grid_band", N, origin3, voxel_size,
                                                  grid_mode, hand, obj, self._box_tau)
@@ -869,11 +940,14 @@ class HipSdfDecoder:
         self._band_skip = False
         vh, vo, bbox2 = self.decode_grid(N, origin3, voxel_size, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj)
         ticket = {"kind": "exact", "args": args, "rec": bbox2, "epoch": self._recalibrations, "host": self._record_to_host(bbox2)}
-        if band and self.math == "f16x3" and (fine_due or not self._fine_valid(N)):
+        if band and self.math == "f16x3" and (fine_due or not self._fine_valid(N)) and not self._fine_compare_in_flight:
             # the zoom lattice is compared as a whole: this ordinary sweep (whose volumes the caller gets) against a plain one-plane
             # sweep of the same lattice, enqueued here while the decoder is bound to the sample and evaluated in fine_needs_repeat
+            # (ONE comparison in flight: with the software pipeline the next samples' fine_begin run before this one is judged -
+            # they used to enqueue a comparison each, 4 x N^3 fp32 volumes apiece: ADVICE r05)
             ticket["compare"] = self._plain_one_plane(args) + (vh, vo)
             ticket["periodic"] = fine_due
+            self._fine_compare_in_flight = True
         return vh, vo, ticket
 
     def fine_needs_repeat(self, ticket):
@@ -911,6 +985,8 @@ class HipSdfDecoder:
                     self.events["modes_switched_off"].append("fine: three refusals in a row (%s)" % reason)
             self._band_skip = True
             return True
+        if ticket.get("compare") is not None:
+            self._fine_compare_in_flight = False        # judged now, whatever comes of it
         if ticket["rec"] is not None and self.fall_back_if_overflowed(self._record_of(ticket), ticket.get("epoch")):
             self.events["repeated_sweeps"] += 1
             return True

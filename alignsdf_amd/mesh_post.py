@@ -31,9 +31,10 @@ import numpy as np
 def keep_largest_component_device(verts_d, faces_d, voxel_size, origin):
     """The same filter on the device (K8, csrc/mesh_cc.hip), enqueued on the current stream without synchronising.
     verts_d [V,3] fp32 lattice-unit marching-cubes vertices, faces_d [F,3] int32; the component areas are measured on
-    origin + voxel_size * v like the reference's.  Returns device tensors (out_verts [V,3], out_faces [F,3], counts int32[4]):
+    origin + voxel_size * v like the reference's.  Returns device tensors (out_verts [V,3], out_faces [F,3], counts int32[8]):
     the first counts[0] rows of out_verts / counts[1] rows of out_faces are the kept mesh; counts[2] = number of
-    qualifying components, counts[3] = first face of the kept one."""
+    qualifying components, counts[3] = first face of the kept one, counts[4] = components of >= 4 faces dropped as open /
+    non-manifold (where trimesh's fill_holes - not reproduced - could have differed), counts[5] = components of < 4 faces."""
     import torch
     from . import _native
     L = _native.lib()
@@ -44,7 +45,7 @@ def keep_largest_component_device(verts_d, faces_d, voxel_size, origin):
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     out_v = torch.empty((V, 3), dtype=torch.float32, device=dev)
     out_f = torch.empty((F, 3), dtype=torch.int32, device=dev)
-    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    counts = torch.empty(8, dtype=torch.int32, device=dev)
     org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin])
     vs = float(voxel_size.item()) if hasattr(voxel_size, "item") else float(np.float32(voxel_size))
     with torch.cuda.device(dev):

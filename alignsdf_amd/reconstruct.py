@@ -24,7 +24,9 @@ from .utils import mesh as mesh_utils
 
 
 class CodeUploader:
-    """Per-sample codes (a latent vector, a few pose matrices: a few KB) -> device WITHOUT making the host wait for the stream.  A
+    """(Round 6: the code sources below no longer upload - host-side codes stay on the host and the HIP decoder reads them from pinned
+    memory, see _code_converter; this class serves the module path and callers that ask for device tensors.)
+    Per-sample codes (a latent vector, a few pose matrices: a few KB) -> device WITHOUT making the host wait for the stream.  A
     plain `.to(device)` of pageable memory is a synchronous copy in stream order: with two decoder passes of the next sample queued
     (round 5: samples are enqueued in one go) the caller sat 50 ms behind them, the queue ran dry, and everything the host did next -
     K8, the ground-truth hand-over, the sampler and the ICP of eval mode - ran with the GPU idle in between (4.4 ms per sample in
@@ -68,9 +70,20 @@ class CodeUploader:
         return out
 
 
-def synthetic_code_source(tag="nerf3", device="cuda"):
+def _code_converter(device, on_host):
+    """What a code source does with an array that is on the host.  on_host=True (the default, round 6): a float32 CPU tensor - the HIP
+    decoder's set_sample stages it in pinned memory and its fold reads it from there in stream order (asdf_decoder_set_sample_host): no
+    copy engine, no runtime blit kernel behind a persistent sweep, and the pose matrices are consumed on the
+    host anyway (hip_decoder.kinematic_affine).  The module path uploads what it needs itself (torch_decoder.TorchModuleDecoder.
+    set_sample, through a CodeUploader).  on_host=False: a device tensor through CodeUploader."""
+    if on_host:
+        return lambda array: torch.from_numpy(np.ascontiguousarray(array, dtype=np.float32))
+    return CodeUploader(device)
+
+
+def synthetic_code_source(tag="nerf3", device="cuda", on_host=True):
     """Deterministic per-sample codes (64 distinct samples, cycled; the grasp family: its 16 trained scenes)."""
-    up = CodeUploader(device)
+    up = _code_converter(device, on_host)
 
     def source(name, index):
         s = index % (synthetic.GRASP_SAMPLES if tag in synthetic.GRASP_TAGS else 64)
@@ -82,10 +95,10 @@ def synthetic_code_source(tag="nerf3", device="cuda"):
     return source
 
 
-def npz_code_source(code_dir, device="cuda"):
+def npz_code_source(code_dir, device="cuda", on_host=True):
     """Codes saved by an external encoder run: <code_dir>/<sample>.npz with `latent` [1,256] and optionally
     `global_trans` [1,16,4,4], `rot_center` [1,1,3], `obj_trans` [1,4,4]."""
-    up = CodeUploader(device)
+    up = _code_converter(device, on_host)
 
     def source(name, index):
         z = np.load(os.path.join(code_dir, name + ".npz"))
@@ -100,15 +113,17 @@ def npz_code_source(code_dir, device="cuda"):
     return source
 
 
-def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False, midpoint=None, report=None):
+def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_copy=False, label_out=False, midpoint=None, report=None,
+                       fast=None):
     """Software pipeline over independent samples.  `samples` yields (key, latent, mano_results, obj_results); the
     generator yields (key, result) in order, where result holds the pass-2 volumes (device), the zoom cube and the
     marching-cubes output per enabled branch (`verts_*`, `faces_*` device tensors, absent when MC found no surface).
 
     The pipeline exists to produce meshes: it runs the coarse pass through `coarse_begin` / `coarse_finish` and the fine pass
-    through `fine_begin(..., mc_only=True)`, i.e. on the audited one-plane sweeps wherever the decoder supports them (the default;
-    ASDF_COARSE=exact / ASDF_FINE=exact for ordinary sweeps) - the yielded `vol_*` are then exact only where marching cubes reads
-    values and must not be used as SDF volumes.
+    through `fine_begin(..., mc_only=True)`.  By default (round 6) both are ORDINARY sweeps: every voxel of both lattices in the
+    reference's arithmetic class (<= 1e-5).  `fast=True` (or ASDF_FAST=1 / `--fast`; `fast=None` leaves the decoder as it is
+    configured) opts in to the audited one-plane sweeps wherever the decoder supports them - the yielded `vol_*` are then exact only
+    where marching cubes reads values and must not be used as SDF volumes.
 
     Per sample the GPU work is  pass 1 -> [64-byte bbox readback, zoom cube on the host] -> pass 2 -> marching cubes,
     and only the bracketed step and the MC size readbacks synchronise with the host.  Pass 1 of sample k+1 is queued
@@ -138,6 +153,8 @@ def pipelined_two_pass(decoder, specs, samples, N, grid_mode="reference", host_c
     if cur is None:
         return
     hip = decoder_for(decoder, specs, cur[2])      # the HIP kernels, or the module on PyTorch-ROCm for variants they do not cover
+    if fast is not None and hasattr(hip, "set_fast"):
+        hip.set_fast(bool(fast))
     if report is not None:                         # (the caller's `sweeps.json`: which evaluator ran, and its counters at the start)
         report["evaluator"], report["snapshot"] = hip, hip.sweep_snapshot()
     hb, ob = specs.get("HandBranch", True), specs.get("ObjectBranch", True)
@@ -474,7 +491,7 @@ class FileWriter:
             raise first
 
 
-def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim):
+def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim, components=None):
     """`<output_dir>/sweeps_<start>_<end>.json` - next to `meshes/`, whose listing stays the reference's (reconstruct.py:34-35) -: which
     sweeps produced the volumes behind this shard's meshes.
     The default sweeps of a mesh-producing run rest on a measured, statistical certificate; a run whose sweeps
@@ -483,33 +500,80 @@ def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim
     hip = report.get("evaluator")
     body = {"range": [int(start_point), int(end_point)], "samples": int(samples), "cube_dim": int(cube_dim),
             "sweeps": hip.sweep_report(report.get("snapshot")) if hip is not None else None}
+    if components is not None:
+        # f1, the largest-component filter (K8; PARITY UNPINNED against trimesh): how many components of >= 4 faces it dropped as open /
+        # non-manifold - the only place where trimesh's fill_holes (utils/mesh.py:371 -> graph.split -> submesh(repair=True); not
+        # reproduced) could have changed which component is written.  Expected 0 on marching-cubes surfaces
+        body["dropped_open_components"] = int(components.get("open", 0))
+        body["dropped_small_components"] = int(components.get("small", 0))
+        body["surfaces_filtered"] = int(components.get("surfaces", 0))
     path = os.path.join(out_dir, "sweeps_%d_%d.json" % (int(start_point), int(end_point)))
     with open(path, "w") as f:
         json.dump(body, f, indent=1)
     return path
 
 
-def merge_sweeps_json(out_dir, out_name="sweeps.json"):
+def merge_sweeps_json(out_dir, out_name="sweeps.json", ranges=None):
     """One `sweeps.json` for the whole run from the per-shard files (dist_reconstruct: rank 0, behind the gather): the per-shard
-    records side by side plus the totals a reader looks for first."""
-    shards = []
-    for name in sorted(os.listdir(out_dir)):
-        if name.startswith("sweeps_") and name.endswith(".json"):
+    records side by side plus the totals a reader looks for first.  `ranges` = the [start, end) shard ranges of THIS run: only their
+    `sweeps_<start>_<end>.json` are merged (a glob also picked up the shards an earlier run with another world size had
+    left in the directory); None = every shard file present.  On a multi-node run without a shared file system rank 0 sees its own
+    host's shards only - `shards_missing` in the totals says how many of `ranges` had no file."""
+    shards, missing = [], 0
+    if ranges is None:
+        wanted = sorted(n for n in os.listdir(out_dir) if n.startswith("sweeps_") and n.endswith(".json"))
+    else:
+        wanted = ["sweeps_%d_%d.json" % (int(a), int(b)) for a, b in ranges]
+    for name in wanted:
+        try:
             with open(os.path.join(out_dir, name)) as f:
                 shards.append(json.load(f))
+        except (OSError, ValueError):
+            missing += 1                               # (a shard that failed before it wrote one, or another host's)
     shards.sort(key=lambda b: b["range"][0])
     tot = {"samples": sum(b["samples"] for b in shards), "sweeps_audited": 0, "sweeps_refused": 0, "sweeps_repeated": 0,
-           "modes_switched_off": [], "fell_back_to_fp32_chain": False}
+           "ordinary_sweeps": 0, "modes_switched_off": [], "fell_back_to_fp32_chain": False, "shards_missing": missing,
+           "min_tau_over_sigma": None, "min_tau_over_estimate": None, "tail_ratio_max": None, "dropped_open_components": 0}
     for b in shards:
         sw = b.get("sweeps") or {}
         for k in ("sweeps_audited", "sweeps_refused", "sweeps_repeated"):
             tot[k] += int(sw.get(k, 0))
+        tot["ordinary_sweeps"] += int(sw.get("coarse_pass", {}).get("ordinary_sweeps", 0)) + int(sw.get("fine_pass", {}).get("ordinary_sweeps", 0))
+        tot["dropped_open_components"] += int(b.get("dropped_open_components", 0) or 0)
+        for k in ("min_tau_over_sigma", "min_tau_over_estimate"):
+            v = sw.get(k)
+            if v is not None:
+                tot[k] = v if tot[k] is None else min(tot[k], v)
+        for v in (sw.get("tail_ratio_max") or {}).values():
+            if v is not None:
+                tot["tail_ratio_max"] = v if tot["tail_ratio_max"] is None else max(tot["tail_ratio_max"], v)
         tot["modes_switched_off"] += ["samples %d..%d: %s" % (b["range"][0], b["range"][1], m) for m in sw.get("modes_switched_off", [])]
         tot["fell_back_to_fp32_chain"] = tot["fell_back_to_fp32_chain"] or bool(sw.get("arithmetic", {}).get("fell_back_to_fp32_chain"))
     path = os.path.join(out_dir, out_name)
     with open(path, "w") as f:
         json.dump({"totals": tot, "shards": shards}, f, indent=1)
     return path
+
+
+def sweeps_summary_line(tot):
+    """The one line about the sweeps a user of dist_reconstruct actually reads, from merge_sweeps_json's totals."""
+    if not tot.get("sweeps_audited") and not tot.get("sweeps_refused"):
+        line = "sweeps: %d ordinary (every voxel of both passes at <= 1e-5; --fast selects the audited one-plane sweeps)" % tot.get("ordinary_sweeps", 0)
+    else:
+        f = lambda v: "n/a" if v is None else "%.1f" % v
+        line = ("sweeps (--fast): %d audited one-plane, %d REFUSED and repeated, %d ordinary; certificate: min allowance / sigma %s, "
+                "min allowance / estimate %s, largest tail ratio %s" % (
+                    tot["sweeps_audited"], tot["sweeps_refused"], tot.get("ordinary_sweeps", 0), f(tot.get("min_tau_over_sigma")),
+                    f(tot.get("min_tau_over_estimate")), f(tot.get("tail_ratio_max"))))
+    if tot.get("modes_switched_off"):
+        line += "; MODES SWITCHED OFF: %s" % "; ".join(tot["modes_switched_off"])
+    if tot.get("fell_back_to_fp32_chain"):
+        line += "; a decoder FELL BACK to the fp32 chain"
+    if tot.get("dropped_open_components"):
+        line += "; %d open components dropped by the largest-component filter (where trimesh's fill_holes could have differed)" % tot["dropped_open_components"]
+    if tot.get("shards_missing"):
+        line += "; %d shard report(s) missing" % tot["shards_missing"]
+    return line
 
 
 def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mesh_filename=None, grid_mode="reference",
@@ -552,10 +616,10 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
 
 def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, end_point, task="obman", device="cuda", scale=None,
                 cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference",
-                data_root="data", allow_missing_gt=False):
+                data_root="data", allow_missing_gt=False, fast=None):
     """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
     decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
-    Returns the list of per-sample records."""
+    `fast`: see pipelined_two_pass (default: ordinary sweeps, every voxel at <= 1e-5).  Returns the list of per-sample records."""
     mesh_dir = os.path.join(output_dir, "meshes")
     os.makedirs(mesh_dir, exist_ok=True)
     with open(split_filename, "r") as f:
@@ -582,6 +646,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
 
     records = []
     sweeps = {}
+    components = {"open": 0, "small": 0, "surfaces": 0}      # what K8 dropped, and why (write_sweeps_json)
     try:
         with torch.no_grad():
             t_prev = time.perf_counter()
@@ -591,6 +656,9 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
 
             def kept(r, part):
                 c = r["host_kept_counts_" + part].numpy()
+                components["open"] += int(c[4])
+                components["small"] += int(c[5])
+                components["surfaces"] += 1
                 return r["host_kept_verts_" + part][:c[0]], r["host_kept_faces_" + part][:c[1]]
 
             def begin_hand(key, r):
@@ -607,7 +675,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
 
             for (index, name), r in pipelined_two_pass(decoder, specs, samples(), cube_dim, grid_mode, host_copy=True,
                                                         label_out=label_out and hand_on, midpoint=begin_hand if gt is not None else None,
-                                                        report=sweeps):
+                                                        report=sweeps, fast=fast):
                 rec = {"index": index, "name": name, "V_hand": r["V_hand"], "F_hand": r["F_hand"], "V_obj": r["V_obj"],
                        "F_obj": r["F_obj"], "voxel_size": float(r["voxel_size"]), "origin": r["origin"]}
                 # the object is written with the hand's ICP translation / scale as offset / scale whenever the hand branch
@@ -647,7 +715,16 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
                 now = time.perf_counter()
                 rec["seconds"], t_prev = now - t_prev, now
                 records.append(rec)
-    except BaseException:
+    except BaseException as exc:
+        # what was finished before the failure travels with the exception (dist_reconstruct.run_sharded writes it to the shard's
+        # records file and hands it to the gather: VERDICT r05 item 2)
+        exc.partial_records = list(records)
+        if sweeps:
+            try:                                   # the shard's sweep report exists even when the shard did not finish
+                write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components)
+            except Exception as e:
+                import logging
+                logging.error("writing the sweep report of a failed shard failed: %s", e)
         # unwinding: the helpers are closed without letting THEIR errors replace the one in flight
         if gt is not None:
             try:
@@ -661,7 +738,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         gt.close()
     writer.close()                      # every file is on disk (or its error raised) before reconstruct() returns
     if sweeps:
-        write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim)
+        write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components)
     return records
 
 
@@ -682,6 +759,31 @@ def load_experiment(model_directory, device="cuda"):
     return specs, build_decoder(specs, ckpt.get("model_state_dict", ckpt))
 
 
+def add_sweep_arguments(p):
+    """--fast / --coarse / --fine of the reconstruction CLIs.  Round 6: meshes that get scored are produced
+    by ORDINARY sweeps unless the caller opts out - every voxel of both passes in the reference's arithmetic class, like
+    utils/mesh.py:27-115 evaluates every voxel in fp32."""
+    p.add_argument("--fast", action="store_true",
+                   help="opt in to the audited one-plane sweeps (2.8 x the throughput at N = 256): one fp16 plane decides the SIGNS "
+                        "of both lattices, every value the zoom cube or marching cubes reads is re-evaluated at <= 1e-5, and a "
+                        "statistical certificate (audit sample per sweep, periodic whole-lattice comparisons) refuses and repeats a "
+                        "sweep that does not hold; identical meshes on everything measured (DESIGN.md 3c).  Default: ordinary sweeps "
+                        "- every voxel at <= 1e-5")
+    p.add_argument("--coarse", choices=["exact", "box"], default=None,
+                   help="coarse pass one by one: an ordinary sweep (default) or the audited box-only one-plane sweep with exact "
+                        "re-evaluation of the voxels that can move the zoom cube")
+    p.add_argument("--fine", choices=["exact", "band"], default=None,
+                   help="fine pass one by one: an ordinary sweep (default) or the audited narrow-band sweep (one fp16 plane, the "
+                        "corners of every cell that can be active re-evaluated as an ordinary sweep would)")
+
+
+def apply_sweep_arguments(args):
+    if args.coarse:
+        os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
+    if args.fine:
+        os.environ["ASDF_FINE"] = args.fine
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description="Reconstruct hand / object meshes with the MI355X-native hot path.")
     p.add_argument("--model", "-e", dest="model_directory", default="./pretrained_model")
@@ -696,18 +798,9 @@ def main(argv=None):
     p.add_argument("--synthetic", action="store_true", help="deterministic synthetic codes (tests / benchmarks only: the meshes mean nothing)")
     p.add_argument("--allow_missing_gt", action="store_true", help="eval mode: write unaligned meshes when a ground-truth mesh is missing instead of aborting")
     p.add_argument("--cube_dim", type=int, default=128, help="grid resolution (reference CLI hard-codes 128, reconstruct.py:178)")
-    p.add_argument("--coarse", choices=["exact", "box"], default=None,
-                   help="coarse pass: the audited box-only one-plane sweep with exact re-evaluation of the voxels that can move the "
-                        "zoom cube (default; same cubes while its calibrated bound holds, checked on every sweep) or an ordinary sweep")
-    p.add_argument("--fine", choices=["exact", "band"], default=None,
-                   help="fine pass: the audited narrow-band sweep (default: one fp16 plane, the corners of every cell that can be "
-                        "active re-evaluated as an ordinary sweep would - identical meshes while the bound holds, checked on every "
-                        "sweep) or an ordinary sweep")
+    add_sweep_arguments(p)
     args = p.parse_args(argv)
-    if args.coarse:
-        os.environ["ASDF_COARSE"] = args.coarse          # read when the decoder is packed
-    if args.fine:
-        os.environ["ASDF_FINE"] = args.fine
+    apply_sweep_arguments(args)
     split = args.split_filename or {"obman": "input/obman.json", "dexycb": "input/dexycb.json"}[args.task]
     output_dir = os.path.join(args.model_directory, "Eval_" + args.task)
     os.makedirs(output_dir, exist_ok=True)
@@ -718,7 +811,7 @@ def main(argv=None):
     source = code_source_from_args(args, specs, p)
     return reconstruct(decoder, specs, split, output_dir, args.start_point, args.end_point, task=args.task, cube_dim=args.cube_dim,
                        label_out=args.label_out, viz=args.viz, eval_mode=args.eval_mode, code_source=source,
-                       allow_missing_gt=args.allow_missing_gt)
+                       allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None)
 
 
 if __name__ == "__main__":

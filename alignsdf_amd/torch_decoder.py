@@ -157,9 +157,21 @@ class TorchModuleDecoder:
         return self._copy[1]
 
     def set_sample(self, latent_vec, mano_results=None, obj_results=None, cam_intr=None):
-        dev = lambda d: None if d is None else {k: v.to(self.device) for k, v in d.items()}
-        self._sample = (None if latent_vec is None else latent_vec.detach().to(self.device, torch.float32), dev(mano_results),
-                        dev(obj_results), None if cam_intr is None else cam_intr.to(self.device))
+        # (codes that arrive on the host - the code sources leave them there - go through the pinned ring + side stream: a plain
+        # .to(device) of pageable memory waits for everything queued on the stream)
+        def up(t):
+            if t is None:
+                return None
+            t = t.detach()
+            if t.device.type == "cpu" and self.device.type == "cuda":
+                if getattr(self, "_uploader", None) is None:
+                    from .reconstruct import CodeUploader
+                    self._uploader = CodeUploader(self.device)
+                return self._uploader(t.to(torch.float32).numpy())
+            return t.to(self.device)
+        dev = lambda d: None if d is None else {k: up(v) for k, v in d.items()}
+        lat = up(latent_vec)
+        self._sample = (None if lat is None else lat.to(torch.float32), dev(mano_results), dev(obj_results), up(cam_intr))
 
     def fall_back_if_overflowed(self, bbox_host, epoch=None):
         return False

@@ -87,6 +87,13 @@ void asdf_decoder_destroy(asdf_decoder_t* dec);
  * Replaces latent.expand + cat (utils/utils.py:568-569) and utils.utils.kinematic_embedding
  * (utils/utils.py:376-430), which is affine in xyz. */
 int asdf_decoder_set_sample(asdf_decoder_t* dec, const float* latent_dev, const float* embed_host, void* stream);
+/* The same for a caller whose codes are on the HOST (the reference's codes come out of the encoder once per sample,
+ * reconstruct.py:83-84; a run from saved codes has them in host memory): latent_pinned [latent_size] and embed_pinned (or NULL) are
+ * PINNED, device-addressable host memory (hipHostMalloc / a pinned torch tensor) that stays untouched until the call's kernels have
+ * run; one workgroup reads them over the link, in stream order, in front of the fold.  No copy engine and no runtime blit kernel
+ * takes part (such a blit cannot get a wave slot while a persistent sweep owns every compute unit: 21.5 ms per sample resident in
+ * the round-5 eval-mode trace). */
+int asdf_decoder_set_sample_host(asdf_decoder_t* dec, const float* latent_pinned, const float* embed_pinned, void* stream);
 
 /* Evaluate both heads on the N^3 lattice
  *     coord[a] = idx[a] * voxel_size + origin[a]     (fp32 mul then add, a = 0,1,2; axis 2 fastest)
@@ -240,6 +247,14 @@ int asdf_decoder_set_short_list(asdf_decoder_t* dec, int32_t max_points);
  * longest dependent chain is 642 MFMAs instead of 2064 (0.10 -> about 0.04 ms per launch; two launches per sample, which is a
  * sixth of a 64^3 sample).  Bit-identical to the other two forms (per-tile instruction sequence unchanged). */
 int asdf_decoder_set_cluster_list(asdf_decoder_t* dec, int32_t max_points);
+/* The cluster form's members wait for each other inside ONE ordinary launch; that they all become resident is an assumption (in-order
+ * dispatch, free workgroup slots), so the wait is bounded: a member that waits longer than `ticks` of the 100 MHz s_memrealtime
+ * counter (0 = the default, 1 s) raises word [11] of the decoder's status record - sticky until asdf_decoder_set_cluster_list
+ * switches the form on again - the cluster writes nothing, and the tile form enqueued behind the launch evaluates the list instead
+ * (bit-identical results, about 0.2 ms later).  Bit 29 of word 7 of a sweep's bbox record and word [16 + 11] of a one-plane sweep's
+ * record carry the report to the host, which switches the form off (asdf_decoder_set_cluster_list(dec, 0)).  Until round 5 the wave
+ * trapped instead, which costs the whole HIP context.  A tiny `ticks` is the test hook that provokes the failure. */
+int asdf_decoder_set_cluster_timeout(asdf_decoder_t* dec, uint64_t ticks);
 
 /* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed
  * as void*, created by the caller with timing enabled) immediately before and after the launch of its dominant kernel
@@ -254,7 +269,8 @@ int asdf_decoder_time_next_sweep(asdf_decoder_t* dec, void* event_start, void* e
  * voxels (asdf_decode_grid_box: candidates) beyond the re-evaluation list's capacity, [2] = scratch flag of the last
  * re-evaluation (a voxel left the negative set), [3] = largest |new - old| value of the last re-evaluation (float bits), [4..6] / [8..10] = the largest fp16-plane value x S_x handed to the
  * conversion for the activation vectors h0 / h1 / h2 of MLP 0 / MLP 1, as float bit patterns, [12..13] / [14..15] = shader-clock stamps (s_memtime, 64 bit) of workgroup 0 at the first / last instruction of the
- * last whole-lattice split-half or one-plane sweep, the rest reserved),
+ * last whole-lattice split-half or one-plane sweep, [11] = non-zero once the short-list kernel's cluster form has reported a member that
+ * never arrived (sticky: `clear` leaves it, see asdf_decoder_set_cluster_timeout), the rest reserved),
  * optionally clears it, and synchronises `stream`.  A caller that sweeps without a bbox buffer (deep_sdf/mesh.py:14-61
  * has no zoom pass) checks this once per volume and repeats the sweep under ASDF_MATH_F32 when the count is non-zero. */
 int asdf_decoder_status(asdf_decoder_t* dec, int32_t out_host[16], int32_t clear, void* stream);
@@ -313,8 +329,11 @@ int asdf_mc_result_status(const uint32_t result[4], double level);
  * number of faces other than two; with fewer than two qualifying components the mesh comes back unchanged, otherwise the
  * qualifying component of largest area - measured, like the reference, on origin + voxel_size * v - with its vertices
  * compacted in ascending original order and its faces in original order.  Outputs (device): out_verts_dev [V][3],
- * out_faces_dev [F][3] (capacity of the input), counts_dev int32[4] = kept vertices, kept faces, qualifying components,
- * first face of the kept component.  No host synchronisation.  Workspace: asdf_mesh_cc_workspace_bytes(V, F). */
+ * out_faces_dev [F][3] (capacity of the input), counts_dev int32[8] (round 6; it was [4]) = kept vertices, kept faces, qualifying
+ * components, first face of the kept component, [4] components of >= 4 faces that did NOT qualify because they are open or
+ * non-manifold - the only place where trimesh's `fill_holes` (submesh(repair=True); not reproduced, this row is PARITY UNPINNED)
+ * could have changed the outcome: expected 0 on every closed marching-cubes surface, and a run reports the sum next to its meshes -,
+ * [5] components of fewer than 4 faces, [6..7] zero.  No host synchronisation.  Workspace: asdf_mesh_cc_workspace_bytes(V, F). */
 int asdf_mesh_cc_workspace_bytes(int32_t num_verts, int32_t num_faces, size_t* bytes);
 int asdf_mesh_largest_component(const float* verts_dev, int32_t num_verts, const int32_t* faces_dev, int32_t num_faces,
                                 float voxel_size, const float origin[3], void* workspace_dev, size_t workspace_bytes,

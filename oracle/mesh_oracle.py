@@ -47,6 +47,33 @@ def split_watertight(verts, faces):
     return [np.flatnonzero(label == c) for c in keep]
 
 
+def component_census(faces):
+    """(qualifying, open_dropped, small_dropped): components of >= 4 faces that are watertight; components of >= 4 faces with an edge
+    that is not shared by exactly two faces (where trimesh's fill_holes - not restated - could have repaired and kept them); components of
+    fewer than 4 faces.  Same adjacency as split_watertight (utils/mesh.py:371 -> trimesh.graph.split)."""
+    faces = np.asarray(faces, dtype=np.int64)
+    F = len(faces)
+    if F == 0:
+        return 0, 0, 0
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 0)
+    e.sort(axis=1)
+    owner = np.tile(np.arange(F), 3)
+    key = e[:, 0] * (int(faces.max()) + 1) + e[:, 1]
+    order = np.argsort(key, kind="stable")
+    key_s, owner_s = key[order], owner[order]
+    start = np.flatnonzero(np.r_[True, key_s[1:] != key_s[:-1]])
+    count = np.diff(np.r_[start, len(key_s)])
+    pair = start[count == 2]
+    adj = coo_matrix((np.ones(len(pair), dtype=np.int8), (owner_s[pair], owner_s[pair + 1])), shape=(F, F))
+    _, label = connected_components(adj, directed=False)
+    bad_face = np.zeros(F, dtype=bool)
+    bad_face[owner_s[np.repeat(count, count) != 2]] = True
+    ncomp = label.max() + 1
+    size = np.bincount(label, minlength=ncomp)
+    bad = np.bincount(label, weights=bad_face, minlength=ncomp) > 0
+    return int(((size >= 4) & ~bad).sum()), int(((size >= 4) & bad).sum()), int((size < 4).sum())
+
+
 def face_areas(verts, faces):
     v = np.asarray(verts, dtype=np.float64)
     a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]

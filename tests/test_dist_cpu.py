@@ -257,3 +257,133 @@ def test_sweeps_json_is_written_and_merged(tmp_path):
     assert t["fell_back_to_fp32_chain"] is True and len(t["modes_switched_off"]) == 1 and t["modes_switched_off"][0].startswith("samples 10..20: fine")
     m2 = json.load(open(rc.merge_sweeps_json(d)))                      # idempotent: the merged file is not taken for a shard
     assert m2["totals"] == t and len(m2["shards"]) == 2
+
+
+# ---- round 6: a rank failure has a path to the other ranks ----------------------------------------------------
+FAILING_WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+from alignsdf_amd import dist_reconstruct as dr
+n, out_dir, mode = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+def process(start, end, rank):
+    recs = []
+    for i in range(start, end):
+        if rank == 1 and i == start + 2:
+            if mode == "raise":
+                e = RuntimeError("synthetic failure at sample %%d" %% i)
+                e.partial_records = list(recs)                  # (what reconstruct() attaches to the exception it lets through)
+                raise e
+            os._exit(7)                                          # mode "die": the process is gone, no exception, no collective
+        recs.append(dict(index=i, V_hand=10 * i + 1, F_hand=20 * i + 2, V_obj=3 * i, F_obj=4 * i, milliseconds=1.0 + rank, name="s%%04d" %% i))
+    return recs
+t0 = time.time()
+code = 0
+try:
+    merged = dr.run_sharded(n, process, backend="gloo", shard_dir=out_dir)
+    shards = [{"rank": r, "range": list(dr.shard_range(n, world, r)), "status": "ok", "error": None, "samples": 0} for r in range(world)]
+    if rank == 0:
+        dr.write_summary(out_dir, merged, shards)
+except dr.ShardFailure as e:
+    code = 3
+    if rank == 0:
+        if e.merged is not None:
+            bad = {f["rank"] for f in e.failed}
+            shards = [{"rank": r, "range": list(dr.shard_range(n, world, r)), "status": "failed" if r in bad else "ok", "error": None,
+                       "samples": sum(1 for m in e.merged if m["rank"] == r)} for r in range(world)]
+            dr.write_summary(out_dir, e.merged, shards)
+        else:
+            dr.write_summary(out_dir, *dr.merge_shard_files(out_dir, n, world))
+json.dump({"rank": rank, "seconds": time.time() - t0, "code": code}, open(os.path.join(out_dir, "done_%%d.json" %% rank), "w"))
+sys.exit(code)
+"""
+
+
+def _spawn_plain_ranks(script, world, args, timeout, extra_env=None):
+    """One process per rank WITHOUT an elastic agent (torchrun tears every worker down as soon as one exits non-zero; the reference's
+    launcher, dist_reconstruct.py:80-84, is fire-and-forget Popen - survivors finish)."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", ASDF_NO_CORE_BINDING="1")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, str(script)] + [str(a) for a in args], env=env, cwd=ROOT,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+    return [p.wait(timeout=timeout) for p in procs]
+
+
+def test_a_rank_that_raises_mid_shard_does_not_take_the_others_along(tmp_path):
+    """World 3 over gloo, rank 1 raises after two samples of its shard: ranks 0 and 2 finish their ranges, every rank enters the flag
+    exchange and the record gather (so nobody sits in a collective until a watchdog), the job ends within seconds with a non-zero
+    exit code on every rank, and reconstruct_summary.json holds the two complete shards, rank 1's two finished samples, and NAMES the
+    failed shard; rank 1's records file says why."""
+    import time
+    script = tmp_path / "worker.py"
+    script.write_text(FAILING_WORKER % {"root": ROOT})
+    out = tmp_path / "Eval"
+    out.mkdir()
+    t0 = time.time()
+    codes = _spawn_plain_ranks(script, 3, [12, out, "raise"], timeout=120)
+    assert time.time() - t0 < 60
+    assert codes == [3, 3, 3]
+    summary = json.load(open(out / "reconstruct_summary.json"))
+    assert summary["complete"] is False
+    assert [(s["rank"], s["range"], s["status"], s["samples"]) for s in summary["shards"]] == [(0, [0, 4], "ok", 4), (1, [4, 8], "failed", 2), (2, [8, 12], "ok", 4)]
+    assert [r["index"] for r in summary["records"]] == [0, 1, 2, 3, 4, 5, 8, 9, 10, 11]
+    shard = json.load(open(out / "records_4_8.json"))
+    assert shard["status"] == "failed" and "synthetic failure at sample 6" in shard["error"] and [r["index"] for r in shard["records"]] == [4, 5]
+    assert json.load(open(out / "records_0_4.json"))["status"] == "ok" and json.load(open(out / "records_8_12.json"))["status"] == "ok"
+    # the same summary can be rebuilt from the shard files alone (`dist_reconstruct --merge-only 3` after a job that was torn down)
+    from alignsdf_amd.dist_reconstruct import merge_shard_files
+    recs, shards = merge_shard_files(str(out), 12, 3)
+    assert [r["index"] for r in recs] == [0, 1, 2, 3, 4, 5, 8, 9, 10, 11] and [s["status"] for s in shards] == ["ok", "failed", "ok"]
+    assert "synthetic failure" in shards[1]["error"] and recs[4]["name"] == "s0004" and recs[4]["rank"] == 1
+
+
+def test_a_rank_that_dies_leaves_its_peers_records_on_disk(tmp_path):
+    """Rank 1 of 3 DIES mid-shard (os._exit: no exception, no collective).  The survivors finish their ranges, find the gather broken
+    within seconds (gloo notices a closed peer at once; RCCL within ASDF_DIST_TIMEOUT), raise ShardFailure, and rank 0 builds the
+    summary from the records files on disk: two complete shards, the third named as missing."""
+    import time
+    script = tmp_path / "worker.py"
+    script.write_text(FAILING_WORKER % {"root": ROOT})
+    out = tmp_path / "Eval"
+    out.mkdir()
+    t0 = time.time()
+    codes = _spawn_plain_ranks(script, 3, [12, out, "die"], timeout=180, extra_env={"ASDF_DIST_TIMEOUT": "20"})
+    assert time.time() - t0 < 120
+    assert codes[1] == 7 and codes[0] == 3 and codes[2] == 3
+    summary = json.load(open(out / "reconstruct_summary.json"))
+    assert summary["complete"] is False
+    assert [(s["rank"], s["status"], s["samples"]) for s in summary["shards"]] == [(0, "ok", 4), (1, "missing", 0), (2, "ok", 4)]
+    assert [r["index"] for r in summary["records"]] == [0, 1, 2, 3, 8, 9, 10, 11]
+    assert not os.path.exists(out / "records_4_8.json")
+
+
+def test_merge_only_ignores_other_runs_shards(tmp_path):
+    """merge_shard_files / merge_sweeps_json(ranges=...) look at THIS run's ranges only (a glob also merged what an
+    earlier run with another world size had left in the directory)."""
+    from alignsdf_amd import dist_reconstruct as dr
+    from alignsdf_amd import reconstruct as rc
+    d = str(tmp_path)
+    rec = lambda i: dict(index=i, V_hand=1, F_hand=2, V_obj=3, F_obj=4, milliseconds=5.0, icp_skipped=0, name="n%d" % i, extra="dropped")
+    dr.write_shard_records(d, 0, 10, 0, [rec(i) for i in range(10)])              # an earlier run: world 1
+    dr.write_shard_records(d, 0, 5, 0, [rec(i) for i in range(5)])                # this run: world 2
+    dr.write_shard_records(d, 5, 10, 1, [rec(i) for i in range(5, 8)], error=ValueError("boom"))
+    recs, shards = dr.merge_shard_files(d, 10, 2)
+    assert [r["index"] for r in recs] == list(range(8)) and "extra" not in recs[0] and recs[0]["name"] == "n0"
+    assert [(s["status"], s["samples"]) for s in shards] == [("ok", 5), ("failed", 3)] and shards[1]["error"] == "ValueError: boom"
+    for a, b, audited in ((0, 10, 1000), (0, 5, 4), (5, 10, 6)):
+        json.dump({"range": [a, b], "samples": b - a, "cube_dim": 64, "sweeps": {"sweeps_audited": audited, "sweeps_refused": 0, "sweeps_repeated": 0,
+                   "min_tau_over_sigma": 30.0 + a, "tail_ratio_max": {"coarse_lattice": 1.4, "zoom_lattice": 1.3 + 0.01 * a},
+                   "coarse_pass": {"ordinary_sweeps": 1}, "fine_pass": {"ordinary_sweeps": 1}}, "dropped_open_components": a},
+                  open(os.path.join(d, "sweeps_%d_%d.json" % (a, b)), "w"))
+    t = json.load(open(rc.merge_sweeps_json(d, ranges=[(0, 5), (5, 10), (10, 12)])))["totals"]
+    assert t["sweeps_audited"] == 10 and t["samples"] == 10 and t["shards_missing"] == 1 and t["ordinary_sweeps"] == 4
+    assert t["min_tau_over_sigma"] == 30.0 and abs(t["tail_ratio_max"] - 1.4) < 1e-12 and t["dropped_open_components"] == 5
+    line = rc.sweeps_summary_line(t)
+    assert "10 audited" in line and "0 REFUSED" in line and "1 shard report(s) missing" in line and "5 open components" in line
+    assert json.load(open(rc.merge_sweeps_json(d)))["totals"]["sweeps_audited"] == 1010          # (no ranges: everything present)
+    plain = rc.sweeps_summary_line({"sweeps_audited": 0, "sweeps_refused": 0, "ordinary_sweeps": 24})
+    assert "24 ordinary" in plain and "--fast" in plain

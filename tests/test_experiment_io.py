@@ -53,8 +53,16 @@ def test_reconstruct_cli_writes_reference_layout(tmp_path):
     specs, split = make_experiment(str(tmp_path), "nerf3", names)
     with pytest.raises(SystemExit):       # no silent default: without --codes / --synthetic there is nothing to reconstruct
         rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32"])
+    import json
+    # round 6: WITHOUT --fast every voxel of both passes is evaluated at <= 1e-5 (ordinary sweeps), like utils/mesh.py:27-115
+    recs0 = rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32",
+                     "--synthetic"])
+    sw0 = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "sweeps_1_3.json")))["sweeps"]
+    assert sw0["sweeps_audited"] == 0 and sw0["coarse_pass"]["mode_now"] == "exact" and sw0["fine_pass"]["mode_now"] == "exact"
+    assert sw0["coarse_pass"]["ordinary_sweeps"] == 2 and sw0["fine_pass"]["ordinary_sweeps"] == 2 and sw0["whole_lattice_comparisons"] == {"coarse_lattice": 0, "zoom_lattice": 0}
     recs = rc.main(["-e", str(tmp_path), "-s", split, "-t", "obman", "--start_point", "1", "--end_point", "3", "--cube_dim", "32",
-                    "--synthetic"])
+                    "--synthetic", "--fast"])
+    assert [(r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"]) for r in recs] == [(r["V_hand"], r["F_hand"], r["V_obj"], r["F_obj"]) for r in recs0]
     assert [r["name"] for r in recs] == names[1:] and [r["index"] for r in recs] == [1, 2]
     mesh_dir = os.path.join(str(tmp_path), "Eval_obman", "meshes")
     assert sorted(os.listdir(mesh_dir)) == sorted(["%s_%s.ply" % (n, p) for n in names[1:] for p in ("hand", "obj")])
@@ -62,9 +70,10 @@ def test_reconstruct_cli_writes_reference_layout(tmp_path):
         v, f = read_ply(os.path.join(mesh_dir, r["name"] + "_hand.ply"))
         assert len(f) > 100 and f.max() < len(v) and r["F_hand"] >= len(f)
     # round 5: next to meshes/ the run says which sweeps produced the volumes behind its files
-    import json
     rep = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "sweeps_1_3.json")))
     assert rep["range"] == [1, 3] and rep["samples"] == 2 and rep["cube_dim"] == 32
+    # f1 (parity unpinned against trimesh): what the largest-component filter dropped as open - the only place fill_holes could differ
+    assert rep["dropped_open_components"] == 0 and rep["surfaces_filtered"] == 4 and rep["dropped_small_components"] >= 0
     sw = rep["sweeps"]
     assert sw["evaluator"].startswith("hip kernels") and sw["arithmetic"] == {"at_start": "f16x3", "now": "f16x3", "fell_back_to_fp32_chain": False}
     assert sw["sweeps_refused"] == 0 and sw["sweeps_repeated"] == 0 and sw["modes_switched_off"] == []
@@ -85,10 +94,21 @@ def test_dist_reconstruct_cli_two_ranks(tmp_path):
     env = dict(os.environ, ASDF_DIST_BACKEND="gloo", ASDF_SHARE_DEVICE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", "-m", "alignsdf_amd.dist_reconstruct", "-e", str(tmp_path), "-t", "obman", "--split", split,
-           "--cube_dim", "32", "--synthetic", "--allow_missing_gt", "--data_root", str(tmp_path / "no_such_data")]
+           "--cube_dim", "32", "--synthetic", "--allow_missing_gt", "--data_root", str(tmp_path / "no_such_data"), "--fast"]
+    # (a stale shard report of an earlier run with another world size must not enter this run's totals: ADVICE r05)
+    os.makedirs(os.path.join(str(tmp_path), "Eval_obman"), exist_ok=True)
+    json.dump({"range": [0, 5], "samples": 5, "cube_dim": 32, "sweeps": {"sweeps_audited": 1000, "sweeps_refused": 7, "sweeps_repeated": 7}},
+              open(os.path.join(str(tmp_path), "Eval_obman", "sweeps_0_5.json"), "w"))
     subprocess.run(cmd, check=True, timeout=600, env=env)
-    summary = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "reconstruct_summary.json")))
+    whole = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "reconstruct_summary.json")))
+    assert whole["complete"] is True and whole["samples"] == 5
+    assert [(s["rank"], s["range"], s["status"], s["samples"]) for s in whole["shards"]] == [(0, [0, 2], "ok", 2), (1, [2, 5], "ok", 3)]
+    summary = whole["records"]
     assert [r["index"] for r in summary] == [0, 1, 2, 3, 4]
+    # every rank left its records next to the meshes BEFORE the gather
+    for a, b, n in ((0, 2, 2), (2, 5, 3)):
+        shard = json.load(open(os.path.join(str(tmp_path), "Eval_obman", "records_%d_%d.json" % (a, b))))
+        assert shard["status"] == "ok" and shard["range"] == [a, b] and [r["index"] for r in shard["records"]] == list(range(a, b)) and len(shard["records"]) == n
     assert [r["rank"] for r in summary] == [0, 0, 1, 1, 1]                 # len // W per rank, remainder to the last
     meshes = sorted(os.listdir(os.path.join(str(tmp_path), "Eval_obman", "meshes")))
     assert meshes == sorted(["%s_%s.ply" % (n, p) for n in names for p in ("hand", "obj")])
@@ -125,7 +145,7 @@ def test_sweeps_json_counts_a_provoked_refusal(tmp_path, monkeypatch):
         return base(name, index)
 
     out = str(tmp_path / "Eval_obman")
-    recs = rc.reconstruct(decoder, specs, split, out, 0, 6, cube_dim=64, code_source=sabotaging_source)
+    recs = rc.reconstruct(decoder, specs, split, out, 0, 6, cube_dim=64, code_source=sabotaging_source, fast=True)
     monkeypatch.setattr(hd, "BAND_CAP", real_cap)
     rep = json.load(open(os.path.join(out, "sweeps_0_6.json")))["sweeps"]
     assert 1 <= rep["sweeps_refused"] <= 2 and rep["sweeps_repeated"] >= rep["sweeps_refused"], rep
@@ -134,9 +154,8 @@ def test_sweeps_json_counts_a_provoked_refusal(tmp_path, monkeypatch):
     assert rep["modes_switched_off"] == [] and rep["coarse_pass"]["mode_now"] == "box" and rep["fine_pass"]["mode_now"] == "band"
     assert rep["fine_pass"]["one_plane_band_sweeps_accepted"] >= 2 and rep["arithmetic"]["fell_back_to_fp32_chain"] is False
     # the files are the ordinary sweeps' files
-    hip.coarse_mode = hip.fine_mode = "exact"
     out2 = str(tmp_path / "Eval_plain")
-    recs2 = rc.reconstruct(decoder, specs, split, out2, 0, 6, cube_dim=64, code_source=base)
+    recs2 = rc.reconstruct(decoder, specs, split, out2, 0, 6, cube_dim=64, code_source=base, fast=False)
     rep2 = json.load(open(os.path.join(out2, "sweeps_0_6.json")))["sweeps"]
     assert rep2["sweeps_audited"] == 0 and rep2["coarse_pass"]["ordinary_sweeps"] == 6 and rep2["fine_pass"]["ordinary_sweeps"] == 6
     assert rep2["coarse_pass"]["mode_now"] == "exact"
@@ -146,7 +165,7 @@ def test_sweeps_json_counts_a_provoked_refusal(tmp_path, monkeypatch):
             va, fa = read_ply(os.path.join(out, "meshes", "%s_%s.ply" % (a["name"], part)))
             vb, fb = read_ply(os.path.join(out2, "meshes", "%s_%s.ply" % (a["name"], part)))
             assert np.array_equal(va, vb) and np.array_equal(fa, fb)
-    hip.coarse_mode, hip.fine_mode = "box", "band"
+    assert (hip.coarse_mode, hip.fine_mode) == ("exact", "exact")
 
 
 def test_reconstruct_requires_a_code_source(tmp_path):
@@ -217,7 +236,11 @@ def test_code_upload_does_not_wait_for_the_queued_passes(tmp_path):
     # the product's code source goes through it
     np.savez(tmp_path / "s.npz", latent=arrays[0], global_trans=np.tile(np.eye(4, dtype=np.float32), (1, 16, 1, 1)),
              rot_center=np.zeros((1, 1, 3), np.float32), obj_trans=np.eye(4, dtype=np.float32)[None])
+    # (round 6: by default the code sources leave host-side codes on the HOST - the HIP decoder reads them from pinned memory;
+    # on_host=False asks for device tensors through the uploader)
     lat, mano, obj = npz_code_source(str(tmp_path))("s", 0)
+    assert lat.device.type == "cpu" and lat.dtype == torch.float32 and np.array_equal(lat.numpy(), arrays[0]) and mano["global_trans"].device.type == "cpu"
+    lat, mano, obj = npz_code_source(str(tmp_path), on_host=False)("s", 0)
     torch.cuda.synchronize()
     assert lat.is_cuda and np.array_equal(lat.cpu().numpy(), arrays[0]) and mano["global_trans"].shape == (1, 16, 4, 4) and obj["obj_trans"].shape == (1, 4, 4)
 

@@ -12,6 +12,13 @@ from alignsdf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fast_sweeps(monkeypatch):
+    """This file is about the OPT-IN audited one-plane sweeps (round 6: the product's default is ordinary sweeps on every voxel;
+    ASDF_FAST=1 / --fast / HipSdfDecoder.set_fast select these)."""
+    monkeypatch.setenv("ASDF_FAST", "1")
+
+
 def _decoder(tag):
     from alignsdf_amd.hip_decoder import HipSdfDecoder
     specs = syn.specs_for(tag)

@@ -33,6 +33,9 @@ def _check(vol, vs=0.013, origin=(-0.6, -0.35, -0.3)):
     comps = mesh_oracle.split_watertight(mesh_points, faces)
     hv, hf = mesh_oracle.keep_largest_component(mesh_points, faces)
     assert c[2] == len(comps)
+    # round 6: what was dropped, and why - [4] components of >= 4 faces that are open / non-manifold (the only place where trimesh's
+    # fill_holes, which is not reproduced, could have changed the outcome), [5] components of fewer than 4 faces
+    assert len(c) == 8 and (int(c[2]), int(c[4]), int(c[5])) == mesh_oracle.component_census(faces) and c[6] == 0 and c[7] == 0
     assert got_f.shape == hf.shape and np.array_equal(got_f, hf)
     # kept vertices: the placed versions of the device's lattice vertices are the host's kept vertices
     placed = place_vertices(torch.from_numpy(got_v), torch.from_numpy(got_f), list(origin), torch.tensor(vs, dtype=torch.float32))[2]
@@ -55,7 +58,7 @@ def test_single_component_and_open_surfaces_return_the_mesh_unchanged():
     assert c[2] == 1 and (c[0], c[1]) == (V, F)
     # a sphere cut by the volume boundary is not watertight: no qualifying component at all
     c, V, F = _check(_volume(48, [(0.9, 0.0, 0.0, 0.4)]))
-    assert c[2] == 0 and (c[0], c[1]) == (V, F)
+    assert c[2] == 0 and (c[0], c[1]) == (V, F) and c[4] == 1 and c[5] == 0
     # one closed + one open: a single qualifying component -> unchanged as well (the reference's `len(split) > 1`)
     c, V, F = _check(_volume(48, [(0.9, 0.0, 0.0, 0.3), (-0.3, 0.0, 0.0, 0.3)]))
     assert c[2] == 1 and (c[0], c[1]) == (V, F)
@@ -121,6 +124,7 @@ def _compare_raw(verts, faces, vs=1.0, origin=(0.0, 0.0, 0.0)):
     c = counts.cpu().numpy()
     hv, hf = mesh_oracle.keep_largest_component(np.asarray(verts, np.float32), np.asarray(faces, np.int32))
     assert np.array_equal(of[:c[1]].cpu().numpy(), hf) and np.array_equal(ov[:c[0]].cpu().numpy(), hv)
+    assert (int(c[2]), int(c[4]), int(c[5])) == mesh_oracle.component_census(faces)
     return c
 
 
@@ -166,3 +170,10 @@ def test_the_documented_deviation_from_trimesh_fill_holes():
     c = _compare_raw(big_v + mid_v + small_v, big_f[:3] + mid_f + small_f)
     assert c[2] == 2                                   # two watertight components: the open one does not count
     assert c[0] == 4 and c[1] == 4                     # kept: the middle tetrahedron
+    assert c[4] == 0 and c[5] == 1                     # (three faces: below graph.split's min_len, not even a candidate for repair)
+    # a component trimesh COULD have repaired - an octahedron (8 faces) with one face removed - is what counts[4] reports: a run sums
+    # it into `dropped_open_components` of its sweeps.json, so a maintainer sees when the deviation can matter (0 on MC33 surfaces)
+    o = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32) * 3.0 + 60.0
+    of = [[12 + a, 12 + b, 12 + c_] for a, b, c_ in ((0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5))]
+    c = _compare_raw(big_v + mid_v + small_v + [list(map(float, x)) for x in o], big_f + mid_f + small_f + of[:7])
+    assert c[2] == 3 and c[4] == 1 and c[5] == 0 and c[1] == 4 and c[3] == 0      # the holed octahedron is dropped; the big tetrahedron wins

@@ -14,6 +14,13 @@ from alignsdf_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _fast_sweeps(monkeypatch):
+    """This file is about the OPT-IN audited one-plane sweeps (round 6: the product's default is ordinary sweeps on every voxel;
+    ASDF_FAST=1 / --fast / HipSdfDecoder.set_fast select these)."""
+    monkeypatch.setenv("ASDF_FAST", "1")
+
 # SeparateDecoder tags of alignsdf_amd.synthetic, and CombinedDecoders built on the same hidden layers (networks/model.py:79-188: one
 # MLP, a 2-row last layer): column 0 = the fitted hand row of the SeparateDecoder, column 1 = the same shape shrunk by 0.04
 CASES = ["nerf9", "nerf15", "comb9", "comb15"]

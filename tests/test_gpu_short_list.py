@@ -175,3 +175,85 @@ def test_single_head_and_the_pipeline_default():
             if on:
                 assert torch.equal(a["vol_" + part], b["vol_" + part])
     _short(hip, 4096, 2048)
+
+
+def test_cluster_timeout_is_recoverable_and_bit_identical():
+    """Round 6 (VERDICT r05 item 4 / ADVICE r05): a member of a cluster that waits longer than its bound for another member used to
+    TRAP - which costs the whole HIP context and every sample in flight on the rank.  Now it raises a sticky word in the decoder's
+    status record, the cluster writes nothing, and the tile form enqueued behind the launch evaluates the list.  Forced here with a
+    bound of ONE tick of the 100 MHz counter (asdf_decoder_set_cluster_timeout): every wait that is not already satisfied gives up.
+
+    - volumes and records are bit-identical to the tile form's, for refinement lists and box candidates, both heads;
+    - the report reaches the host through bit 29 of word 7 of the bbox record / word 27 of the box sweep's record and through
+      asdf_decoder_status word 11, and survives a status clear;
+    - the Python layer switches the form off once and says so; the context is alive and later sweeps are right;
+    - switched on again (which withdraws the report) with the default bound, the cluster form works again: the arrival counters
+      stayed multiples of four through the failed launches."""
+    from alignsdf_amd import hip_decoder as hd
+    hip = _bound("nerf3", 2)
+    N = 96
+    origin, vs = [-0.62, -0.36, -0.37], 1.21 / (N - 1)
+    hip.set_refine(2e-4)
+    _short(hip, 0, 0)
+    want = hip.decode_grid(N, origin, vs)                                  # the tile form
+    listed = int((want[0].abs() < 2e-4).sum() + (want[1].abs() < 2e-4).sum())
+    assert 32 < listed, listed
+    _short(hip, 4096, 2048)
+    _native.check(hip._L.asdf_decoder_set_cluster_timeout(hip._h, ctypes.c_uint64(1)), "asdf_decoder_set_cluster_timeout")
+    faults = 0
+    for _ in range(6):                                                     # (a launch whose four members happen to arrive together does not fault)
+        got = hip.decode_grid(N, origin, vs)
+        for k in (0, 1):
+            assert torch.equal(want[k], got[k]), float((want[k] - got[k]).abs().max())
+        b = got[2].cpu().numpy()
+        w = want[2].cpu().numpy()
+        assert np.array_equal(b[:7], w[:7]) and np.array_equal(b[8:15], w[8:15])
+        faults += int(bool(int(b[7]) & hd.CLUSTER_FAULT_BIT))
+        if faults:
+            break
+    assert faults, "a one-tick bound did not make any member give up: the hook does not reach the kernel"
+    st = hip._status(clear=True)
+    assert int(st[11]) != 0
+    assert int(hip._status(clear=False)[11]) != 0                          # sticky: a status clear leaves the report
+    # the Python layer: notes it on the record it reads anyway, switches the form off - the sweep itself is NOT repeated
+    assert hip.fall_back_if_overflowed(b) is False and hip._cluster_off
+    assert any("cluster form" in m for m in hip.events["modes_switched_off"])
+    got = hip.decode_grid(N, origin, vs)                                   # short form now
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    # a box sweep's candidates with the form forced on again and the one-tick bound: word 27 of its record carries the report
+    hip.set_audit(0)
+    N2 = 64
+    org = (ctypes.c_float * 3)(-1.0, -1.0, -1.0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def box(tau):
+        vh = torch.empty((N2, N2, N2), dtype=torch.float32, device="cuda")
+        vo = torch.empty((N2, N2, N2), dtype=torch.float32, device="cuda")
+        rec = torch.zeros(48, dtype=torch.int32, device="cuda")
+        _native.check(hip._L.asdf_decode_grid_box(hip._h, N2, org, ctypes.c_float(2.0 / (N2 - 1)), 0, ctypes.c_float(tau), vh.data_ptr(),
+                                                  vo.data_ptr(), rec.data_ptr(), stream), "asdf_decode_grid_box")
+        return vh, vo, rec.cpu().numpy()
+
+    hip.decode_grid(N2, [-1.0] * 3, 2.0 / (N2 - 1))
+    _short(hip, 0, 0)
+    # (two MLPs: the cluster form takes lists of up to 2048 / 2 candidates - find an allowance whose list is that short)
+    tau_box = next(t for t in (3e-4, 1e-4, 5e-5, 2e-5, 1e-5, 3e-6) if 0 < int(box(t)[2][32]) <= 1024)
+    a = box(tau_box)
+    _short(hip, 4096, 2048)                                                # (on again: withdraws the report)
+    assert int(hip._status(clear=False)[11]) == 0
+    _native.check(hip._L.asdf_decoder_set_cluster_timeout(hip._h, ctypes.c_uint64(1)), "asdf_decoder_set_cluster_timeout")
+    seen = 0
+    for _ in range(6):
+        c = box(tau_box)
+        assert 0 < int(a[2][32]) == int(c[2][32]) <= 1024
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and np.array_equal(a[2][:7], c[2][:7]) and int(a[2][19]) == int(c[2][19])
+        seen += int(c[2][27] != 0)
+    assert seen, "no fault reported in a box sweep's record"
+    # default bound again, report withdrawn: the cluster form runs and delivers the same bits (counters still multiples of four)
+    _native.check(hip._L.asdf_decoder_set_cluster_timeout(hip._h, ctypes.c_uint64(0)), "asdf_decoder_set_cluster_timeout")
+    _short(hip, 4096, 2048)
+    for _ in range(4):
+        c = box(tau_box)
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and int(c[2][27]) == 0
+    assert int(hip._status(clear=False)[11]) == 0
+    hip.close()

@@ -13,6 +13,13 @@ from alignsdf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fast_sweeps(monkeypatch):
+    """This file is about the OPT-IN audited one-plane sweeps (round 6: the product's default is ordinary sweeps on every voxel;
+    ASDF_FAST=1 / --fast / HipSdfDecoder.set_fast select these)."""
+    monkeypatch.setenv("ASDF_FAST", "1")
+
+
 def _module(tag="nerf3"):
     from alignsdf_amd.networks.model import build_decoder
     specs = syn.specs_for(tag)

@@ -17,6 +17,13 @@ from alignsdf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fast_sweeps(monkeypatch):
+    """This file is about the OPT-IN audited one-plane sweeps (round 6: the product's default is ordinary sweeps on every voxel;
+    ASDF_FAST=1 / --fast / HipSdfDecoder.set_fast select these)."""
+    monkeypatch.setenv("ASDF_FAST", "1")
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -174,4 +181,40 @@ def test_a_second_run_on_a_calibrated_decoder_starts_speculating_without_sizes(m
         assert a[0] == b[0] and a[1] == b[1]
         for k in (2, 3, 4, 5):
             assert torch.equal(a[k], b[k]), (s, k)
+    assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0
+
+
+@pytest.mark.parametrize("branches", [(True, False), (False, True)])
+def test_combined_decoder_with_one_branch_off_keeps_its_zoom_cube_when_enqueued_in_one_go(branches, monkeypatch):
+    """two_pass_begin forced hand = obj = True for a CombinedDecoder BEFORE asdf_zoom_cube, so samples enqueued in
+    one go took the zoom cube over BOTH columns' boxes even with HandBranch / ObjectBranch off - while the step-by-step path and the
+    reference (get_higher_res_cube, utils/mesh.py:239-247) use the enabled branches only: within one run the first samples and the
+    later ones got different fine lattices.  Here: a CombinedDecoder, one branch off, samples that ARE enqueued in one go - zoom cubes
+    and meshes equal the step-by-step run's (ASDF_SPECULATE=0), and differ from the both-branches cube (so the test can tell)."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass
+    from alignsdf_amd.utils.utils import decoder_for
+    N, tag = 64, "comb3"
+    hb, ob = branches
+    part = "hand" if hb else "obj"
+    sd = {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()}
+
+    def run(specs, samples):
+        dec = build_decoder(specs, sd)
+        items = [(s, torch.from_numpy(syn.latent_code(s)), None, None) for s in samples]
+        out = {s: (r["origin"], float(r["voxel_size"]), r["verts_" + part], r["faces_" + part]) for s, r in pipelined_two_pass(dec, specs, iter(items), N)}
+        return out, decoder_for(dec, specs)
+
+    one = dict(syn.specs_for(tag), HandBranch=hb, ObjectBranch=ob)
+    monkeypatch.setenv("ASDF_SPECULATE", "0")
+    want, hip0 = run(one, range(8))
+    assert hip0.events["samples_in_one_go"] == 0
+    both, _ = run(syn.specs_for(tag), range(8))
+    monkeypatch.setenv("ASDF_SPECULATE", "1")
+    got, hip = run(one, range(8))
+    assert hip.combined and hip.events["samples_in_one_go"] >= 4, hip.events
+    assert any(want[s][:2] != both[s][:2] for s in range(8)), "the one-branch and the two-branch zoom cubes coincide: the test cannot tell"
+    for s in range(8):
+        assert want[s][0] == got[s][0] and want[s][1] == got[s][1], (s, want[s][:2], got[s][:2])
+        assert torch.equal(want[s][2], got[s][2]) and torch.equal(want[s][3], got[s][3]), s
     assert hip.box_stats["fallback"] == 0 and hip.band_stats["fallback"] == 0

@@ -151,8 +151,9 @@ def test_split_half_kernel_round5_form(compiled):
 def test_short_list_kernel_cluster_form(compiled):
     """The short-list kernel (csrc/sdf_mlp_short_kernel.h) with its cluster form (round 5): scratch-free; the exchange between the four
     workgroups of a cluster is the memory model's own - an agent-scope release (L2 write-back) in front of each arrival, an
-    acquire (invalidate) behind each wait - on returning atomics, with a bounded spin that traps instead of hanging the queue; and
-    the fp32 MFMA of the tile form, nothing else."""
+    acquire (invalidate) behind each wait - on returning atomics, with a spin that is bounded by the 100 MHz real-time counter and,
+    round 6, NO trap (a member that gives up raises the decoder's fault word and the tile form behind the launch takes the list: a
+    trap costs the whole HIP context); and the fp32 MFMA of the tile form, nothing else."""
     remarks, isa = compiled
     for frag in ("20sdf_mlp_short_kernelE", "29sdf_mlp_short_combined_kernelE"):
         block = [b for b in re.split(r"remark: Function Name: ", remarks)[1:] if frag in b.split()[0]]
@@ -160,10 +161,10 @@ def test_short_list_kernel_cluster_form(compiled):
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block[0]).group(1)) == 0
         assert int(re.search(r"VGPRs: (\d+)", block[0]).group(1)) <= 256
     body = isa[isa.index("_ZN4asdf20sdf_mlp_short_kernelENS_12DecodeParamsENS_11ShortParamsE:"):]
-    body = body[:body.index(".Lfunc_end")]             # (the trap sits in a cold block behind the last s_endpgm)
+    body = body[:body.index(".Lfunc_end")]
     # (the compiler merges the code of the second and third exchange: two arrival sites, one shared spin loop)
     assert body.count("buffer_wbl2 sc1") >= 2 and body.count("buffer_inv sc1") >= 3, "release / acquire around the exchanges"
     assert len(re.findall(r"global_atomic_add\S* v\d+, v\d+, v\d+, .* sc0", body)) >= 2, "arrivals are returning atomics (the wait needs the value seen)"
-    assert "s_sleep" in body and "s_trap" in body
+    assert "s_sleep" in body and "s_memrealtime" in body and "s_trap" not in body
     mfma = set(re.findall(r"v_mfma_\w+", body))
     assert mfma == {"v_mfma_f32_32x32x2_f32"}, mfma

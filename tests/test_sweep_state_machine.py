@@ -16,6 +16,14 @@ import torch
 
 from alignsdf_amd import hip_decoder as hd
 
+
+@pytest.fixture(autouse=True)
+def _fast_sweeps(monkeypatch):
+    """This file is about the OPT-IN audited one-plane sweeps (round 6: the product's default is ordinary sweeps on every voxel;
+    ASDF_FAST=1 / --fast / HipSdfDecoder.set_fast select these)."""
+    monkeypatch.setenv("ASDF_FAST", "1")
+
+
 N = 32
 ARGS = (N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
 F = lambda x: int(np.float32(x).view(np.int32))
@@ -485,3 +493,74 @@ def test_a_speculative_ticket_launched_under_old_scales_is_not_judged(machine):
     ok, b, cal = dec.coarse_judge(t["coarse"])
     assert not ok and cal and dec._box_failures == 0 and dec.cert["refusals_for_error"] == 0
     assert dec.fine_needs_repeat(t["fine"]) and dec._band_failures == 0
+
+
+# ---- round 6: ordinary sweeps are the default, the audited one-plane sweeps an opt-in ---------------------
+def _bare_decoder():
+    dec = hd.HipSdfDecoder.__new__(hd.HipSdfDecoder)
+    dec.combined, dec.nerf_features, dec.point_feat_size = False, False, 3
+    dec.device, dec._h = torch.device("cpu"), None
+    dec._L = FakeLib(dec)
+    dec._stream = lambda: None
+    dec._init_sweep_state()
+    dec._calibrated = True
+    dec._status = lambda clear: np.zeros(16, dtype=np.int32)
+    return dec
+
+
+def test_default_modes_are_ordinary_sweeps_and_fast_is_an_opt_in(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE", "ASDF_FAST"):
+        monkeypatch.delenv(k, raising=False)
+    assert (hd.DEFAULT_COARSE, hd.DEFAULT_FINE) == ("exact", "exact")
+    dec = _bare_decoder()
+    assert (dec.coarse_mode, dec.fine_mode, dec.math) == ("exact", "exact", "f16x3")
+    assert not dec._box_usable() and not dec._band_usable() and not dec.can_speculate(N)
+    # a mesh-producing sample under the defaults: two ordinary sweeps, no one-plane launch, no whole-lattice comparison
+    b = dec.coarse_finish(dec.coarse_begin(*ARGS))
+    vh, vo, t = dec.fine_begin(N, [-0.5] * 3, 0.01, mc_only=True)
+    assert not dec.fine_needs_repeat(t)
+    assert [k for k, _ in dec._L.log] == ["grid", "grid"] and dec.cert["calibrations"] == 0 and dec.cert["fine_calibrations"] == 0
+    assert dec.box_stats["exact"] == 1 and dec.band_stats["exact"] == 1 and dec.box_stats["box"] == 0
+    dec.set_fast(True)
+    assert (dec.coarse_mode, dec.fine_mode) == ("box", "band") and dec._box_usable() and dec._band_usable()
+    dec.set_fast(False)
+    assert (dec.coarse_mode, dec.fine_mode) == ("exact", "exact")
+    for value, want in (("1", ("box", "band")), ("0", ("exact", "exact")), ("", ("exact", "exact")), ("yes", ("box", "band"))):
+        monkeypatch.setenv("ASDF_FAST", value)
+        d2 = _bare_decoder()
+        assert (d2.coarse_mode, d2.fine_mode) == want, value
+    monkeypatch.setenv("ASDF_FAST", "1")
+    monkeypatch.setenv("ASDF_FINE", "exact")                        # the pass-by-pass switches override the pair
+    d3 = _bare_decoder()
+    assert (d3.coarse_mode, d3.fine_mode) == ("box", "exact")
+
+
+def test_one_zoom_lattice_comparison_in_flight(machine):
+    """with the software pipeline the next samples' fine_begin run before the first whole-zoom-lattice comparison has been
+    judged - each used to enqueue its own plain one-plane sweep (4 x N^3 fp32 volumes apiece) and calibrate again."""
+    dec, calls = machine
+    dec._fine_epoch = -1                                             # (what a refusal for error does: the zoom lattice is measured again)
+    tickets = [dec.fine_begin(N, [-0.5] * 3, 0.01, mc_only=True)[2] for _ in range(3)]      # three samples' fine passes in flight
+    assert [k for k, _ in dec._L.log].count("plain") == 1 and "compare" in tickets[0] and "compare" not in tickets[1] and "compare" not in tickets[2]
+    for t in tickets:
+        assert not dec.fine_needs_repeat(t)
+    assert calls.count("calibrate_fine") == 1 and not dec._fine_compare_in_flight and dec._fine_valid(N)
+    dec._L.script = [good_record(dec._box_tau)]
+    assert dec.fine_begin(N, [-0.5] * 3, 0.01, mc_only=True)[2]["kind"] == "band"      # the certificate is there: band sweeps from now on
+
+
+def test_cluster_fault_report_switches_the_form_off_once(machine):
+    """Bit 29 of word 7 of a bbox record (or word 27 of a one-plane record): a member of the short-list kernel's cluster form did not
+    arrive in time.  The sweep is complete (the tile form evaluated the list); the host switches the form off, once, and says so."""
+    dec, calls = machine
+    off = []
+    dec._L.asdf_decoder_set_cluster_list = lambda h, n: off.append(n) or 0
+    dec._h = 1
+    r = np.zeros(16, dtype=np.int32)
+    r[7] = hd.CLUSTER_FAULT_BIT
+    assert dec._range_words(r) == (0, False)                         # not a range violation, not a list overflow
+    assert dec.fall_back_if_overflowed(r) is False and off == [0] and dec._cluster_off
+    assert dec.fall_back_if_overflowed(r) is False and off == [0]    # once
+    assert any("cluster form" in m for m in dec.events["modes_switched_off"])
+    dec._h = None
