@@ -166,6 +166,7 @@ def test_three_refused_band_sweeps_in_a_row_switch_the_mode_off_and_lists_beyond
     def run(force):
         for k in ("ASDF_COARSE", "ASDF_FINE", "ASDF_MATH"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("ASDF_FAST", "1")            # (the undo() below also undoes this file's autouse fixture)
         dec, specs = _module()
         hip = _hip(dec, specs)
         if force:

@@ -10,11 +10,13 @@ for f in glob.glob("$O/t/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
 rows.sort()
-# the timed reconstruct() call = the last S samples' worth of one-plane sweeps (two per sample).  Steady state: the window from the
+# the timed reconstruct() call = the last S samples' worth of lattice sweeps (two per sample).  Steady state: the window from the
 # first sweep of the call's 3rd sample to the first sweep of its last sample - the first samples fill the pipeline and the last one's
 # post-processing has no next sample to hide behind (both are in the whole-call figures printed after it)
 S = ${SAMPLES:-24}
-p1 = [i for i, r in enumerate(rows) if "f16p1" in r[2]]
+# (the sweep kernel of the flow: the split-half kernel under the product's default - ordinary sweeps - and the one-plane kernel under ASDF_FAST=1)
+KEY = "f16p1" if "${ASDF_FAST:-0}" not in ("", "0") else "sdf_mlp_f16_kernel"
+p1 = [i for i, r in enumerate(rows) if KEY in r[2] and "subset" not in r[2]]
 def window(first, last, samples, label):
     win = rows[first:last]
     t0, t1 = win[0][0], max(r[1] for r in win)
