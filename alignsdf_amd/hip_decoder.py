@@ -550,21 +550,24 @@ class HipSdfDecoder:
                 slot[2] = ev
 
     def decode_grid(self, N, origin3, voxel_size, grid_mode=_native.GRID_REFERENCE, want_bbox=True, hand=True, obj=True,
-                    check_range=None):
+                    check_range=None, lattice=None):
         """Heads on the N^3 lattice. Returns (sdf_hand [N,N,N], sdf_obj [N,N,N], bbox int32[16] or None), all device
         tensors; a head switched off (`hand` / `obj` False, SeparateDecoder only) is not evaluated and returns None.
 
         Under the split-half arithmetic a sweep WITH a bbox reports fp16 range violations in words 7 / 15 of the record
         (the caller reads it anyway: fall_back_if_overflowed).  A sweep WITHOUT one is guarded here: the decoder's status
         word is read behind the launch (one stream synchronisation) and, if it is non-zero, the decoder switches to the
-        fp32 kernel and the sweep is repeated.  check_range=False skips that for callers that know the range is safe."""
+        fp32 kernel and the sweep is repeated.  check_range=False skips that for callers that know the range is safe.
+
+        `lattice` (device float32[4] = origin, voxel size; origin3 / voxel_size are then ignored): the lattice is read on the device
+        (asdf_decode_grid_dev) - the fine pass of a sample enqueued in one go, behind asdf_zoom_cube."""
         if self.combined:
             hand = obj = True
         want_hand, want_obj = hand, obj
         hand = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if hand else None
         obj = torch.empty((N, N, N), dtype=torch.float32, device=self.device) if obj else None
         bbox = torch.empty(16, dtype=torch.int32, device=self.device) if want_bbox else None
-        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3])
+        org = (ctypes.c_float * 3)(*[float(np.float32(o)) for o in origin3]) if lattice is None else None
         guard = self.math == "f16x3" and not want_bbox and (check_range is None or check_range)
         once_f32 = self._force_f32_once and self.math == "f16x3"
         self._force_f32_once = False
@@ -583,11 +586,18 @@ class HipSdfDecoder:
                     ev[1].record()
                     _native.check(self._L.asdf_decoder_time_next_sweep(self._h, ctypes.c_void_p(ev[0].cuda_event),
                                                                        ctypes.c_void_p(ev[1].cuda_event)), "asdf_decoder_time_next_sweep")
-                _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
-                                                       int(grid_mode), hand.data_ptr() if hand is not None else None,
-                                                       obj.data_ptr() if obj is not None else None,
-                                                       bbox.data_ptr() if want_bbox else None, self._stream()),
-                              "asdf_decode_grid")
+                if lattice is not None:
+                    _native.check(self._L.asdf_decode_grid_dev(self._h, int(N), lattice.data_ptr(), int(grid_mode),
+                                                               hand.data_ptr() if hand is not None else None,
+                                                               obj.data_ptr() if obj is not None else None,
+                                                               bbox.data_ptr() if want_bbox else None, self._stream()),
+                                  "asdf_decode_grid_dev")
+                else:
+                    _native.check(self._L.asdf_decode_grid(self._h, int(N), org, ctypes.c_float(float(np.float32(voxel_size))),
+                                                           int(grid_mode), hand.data_ptr() if hand is not None else None,
+                                                           obj.data_ptr() if obj is not None else None,
+                                                           bbox.data_ptr() if want_bbox else None, self._stream()),
+                                  "asdf_decode_grid")
             return ev
 
         # A split-half sweep that evaluates an MLP whose activation scales are still at their default calibrates them from
@@ -817,6 +827,18 @@ class HipSdfDecoder:
         import logging
         N = ticket["args"][0]
         r = self._record_of(ticket)
+        if ticket["kind"] == "exact":
+            # the ORDINARY coarse sweep of a sample that was enqueued in one go (round 6): its only guards are the split-half
+            # arithmetic's own - fp16 range (re-calibrate, or at last the fp32 chain) and the near-level list (one sweep on the fp32
+            # chain).  A clean record is the pass; otherwise the recovery is booked here and the caller repeats the sample step by step
+            if self.fall_back_if_overflowed(r, ticket["epoch"]):
+                self.events["repeated_sweeps"] += 1
+                return False, None, False
+            self.box_stats["exact"] += 1
+            b = r[:16].copy()
+            b[7] &= CLUSTER_FAULT_BIT - 1
+            b[15] &= CLUSTER_FAULT_BIT - 1
+            return True, b, False
         if ticket["epoch"] != self._recalibrations:
             ok, bad, reason = False, 0, "launched under activation scales that have been re-calibrated since"
         else:
@@ -850,7 +872,9 @@ class HipSdfDecoder:
         a speculative coarse pass first and re-binds the sample only when it has to be repeated)."""
         N, origin3, voxel_size, grid_mode, hand, obj = ticket["args"]
         calibrate_allowance = True
-        if ticket["kind"] == "box":
+        if ticket["kind"] == "box" or judged is not None:
+            # (judged is given for an ordinary speculative coarse pass as well: refused there = its range / near-level guards fired and
+            # the recovery has been booked by coarse_judge - launch it again)
             ok, b, calibrate_allowance = judged if judged is not None else self.coarse_judge(ticket)
             if ok:
                 return b
@@ -884,12 +908,41 @@ class HipSdfDecoder:
         return (self._box_usable() and self._band_usable() and self._allowance_valid(N) and self._fine_valid(N) and
                 not self._force_f32_once and not self._band_skip and self._coarse_since_cal + 1 <= RECAL_EVERY)
 
+    def can_speculate_ordinary(self, hand=True, obj=True):
+        """Round 6: ORDINARY sweeps in both passes (the product's default) may be enqueued back to back as well - coarse sweep, zoom cube
+        on the device, fine sweep on that lattice (asdf_decode_grid_dev), marching cubes - whenever nothing can ask for a host decision
+        in between: both passes are ordinary, the activation scales of the MLPs that run are calibrated, and no sweep has been ordered
+        onto the fp32 chain.  What can still go wrong is reported in the two bbox records (fp16 range, near-level list) and handled
+        when the sample is finished: the sample is then repeated step by step."""
+        if self.coarse_mode == "box" and self.math == "f16x3" and self._one_plane_ok():
+            return False
+        if self._band_usable() or self._force_f32_once or self._band_skip:
+            return False
+        return not self._needs_calibration(hand, obj) or self.math == "f32"
+
     def two_pass_begin(self, N, voxel_size, grid_mode=_native.GRID_REFERENCE, hand=True, obj=True):
         """Enqueue coarse pass -> device zoom cube -> fine pass (mc_only) of the bound sample.  Returns None when the sample has to go
-        step by step (can_speculate), else a ticket: `coarse` / `fine` (tickets for coarse_judge / fine_needs_repeat), `lattice` (device
-        float32[4]: origin, voxel size), `lattice_host` (pinned copy + event), `vol_hand` / `vol_obj` (the fine volumes)."""
+        step by step (can_speculate / can_speculate_ordinary), else a ticket: `coarse` / `fine` (tickets for coarse_judge /
+        fine_needs_repeat), `lattice` (device float32[4]: origin, voxel size), `lattice_host` (pinned copy + event), `vol_hand` /
+        `vol_obj` (the fine volumes)."""
         if not self.can_speculate(N):
-            return None
+            if not self.can_speculate_ordinary(hand, obj):
+                return None
+            # ---- ordinary sweeps in both passes, enqueued in one go
+            self.events["samples_in_one_go"] += 1
+            org = [-1.0, -1.0, -1.0]
+            args = (N, org, voxel_size, grid_mode, hand, obj)
+            h, o, bbox = self.decode_grid(N, org, voxel_size, grid_mode, hand=hand, obj=obj)
+            coarse = {"kind": "exact", "args": args, "rec": bbox, "keep": (h, o), "epoch": self._recalibrations, "host": self._record_to_host(bbox)}
+            lattice = torch.empty(4, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(self._L.asdf_zoom_cube(bbox.data_ptr(), int(N), ctypes.c_float(float(np.float32(voxel_size))), int(bool(hand)),
+                                                     int(bool(obj)), lattice.data_ptr(), self._stream()), "asdf_zoom_cube")
+            lattice_host = self._record_to_host(lattice.view(torch.int32))
+            vh, vo, bbox2 = self.decode_grid(N, None, None, grid_mode, want_bbox=self.math == "f16x3", hand=hand, obj=obj, lattice=lattice)
+            fine = {"kind": "exact", "args": (N, None, None, grid_mode, hand, obj), "rec": bbox2, "epoch": self._recalibrations,
+                    "host": self._record_to_host(bbox2)}
+            return {"coarse": coarse, "fine": fine, "lattice": lattice, "lattice_host": lattice_host, "vol_hand": vh, "vol_obj": vo}
         # (a CombinedDecoder evaluates both columns whatever the flags say - the launches force that themselves - but the ZOOM CUBE and
         # the marching-cubes parts follow the caller's HandBranch / ObjectBranch like get_higher_res_cube, utils/mesh.py:239-247, and the
         # step-by-step path: ADVICE r05)

@@ -129,6 +129,48 @@ def test_pipelined_samples_equal_one_at_a_time(tag):
             assert torch.equal(r["verts_" + part], ref["verts_" + part]) and torch.equal(r["faces_" + part], ref["faces_" + part])
 
 
+@pytest.mark.parametrize("tag,branches", [("nerf3", (True, True)), ("nerf3", (True, False)), ("both9", (False, True)), ("comb3", (True, True))])
+def test_ordinary_sweeps_enqueued_in_one_go_equal_the_step_by_step_run(tag, branches, monkeypatch):
+    """Round 6: the product's DEFAULT (ordinary sweeps, every voxel) takes the one-go form too - coarse sweep, zoom cube on the device
+    (asdf_zoom_cube), fine sweep reading its lattice from those words (asdf_decode_grid_dev), capacity-bounded marching cubes - from the
+    second sample of a decoder on (the first calibrates the activation scales).  Zoom cubes, VOLUMES and meshes equal the step-by-step
+    run's (ASDF_SPECULATE=0) bit for bit, for both branches, one branch alone, and a CombinedDecoder."""
+    from alignsdf_amd.networks.model import build_decoder
+    from alignsdf_amd.reconstruct import pipelined_two_pass, synthetic_code_source
+    from alignsdf_amd.utils.utils import decoder_for
+    for k in ("ASDF_FAST", "ASDF_COARSE", "ASDF_FINE", "ASDF_MATH"):
+        monkeypatch.delenv(k, raising=False)
+    hb, ob = branches
+    specs = dict(syn.specs_for(tag), HandBranch=hb, ObjectBranch=ob)
+    sd = {k: torch.from_numpy(v) for k, v in syn.full_state_dict(tag).items()}
+    N = 64
+    src = synthetic_code_source(tag if tag != "comb3" else "nerf3", "cuda")
+
+    def run():
+        dec = build_decoder(specs, sd)
+        items = [(i,) + src("s%d" % i, i) for i in range(7)]
+        out = {}
+        for k, r in pipelined_two_pass(dec, specs, iter(items), N):
+            out[k] = {key: (r[key].clone() if torch.is_tensor(r[key]) else r[key]) for key in r
+                      if key.startswith(("verts_", "faces_", "vol_")) or key in ("origin", "voxel_size")}
+        return out, decoder_for(dec, specs, items[0][2])
+
+    monkeypatch.setenv("ASDF_SPECULATE", "0")
+    want, hip0 = run()
+    assert hip0.events["samples_in_one_go"] == 0 and (hip0.coarse_mode, hip0.fine_mode) == ("exact", "exact")
+    monkeypatch.setenv("ASDF_SPECULATE", "1")
+    got, hip = run()
+    assert hip.events["samples_in_one_go"] == 6 and hip.box_stats["exact"] == 7 and hip.band_stats["exact"] == 7, (hip.events, hip.box_stats)
+    assert hip.box_stats["box"] == 0 and hip.band_stats["band"] == 0 and hip.events["repeated_sweeps"] == 0
+    for k in want:
+        a, b = want[k], got[k]
+        assert a["origin"] == b["origin"] and float(a["voxel_size"]) == float(b["voxel_size"]), k
+        for part, on in (("hand", hb), ("obj", ob)):
+            if on:
+                assert torch.equal(a["vol_" + part], b["vol_" + part]), (k, part)
+                assert torch.equal(a["verts_" + part], b["verts_" + part]) and torch.equal(a["faces_" + part], b["faces_" + part]), (k, part)
+
+
 def test_eval_mode_icp_in_file_flow(tmp_path):
     """convert_sdf_samples_to_ply(eval_mode=True): the written hand mesh is aligned to data/<task>/test/mesh_hand/<id>.obj
     and (trans, scale) are returned like utils/mesh.py:385-395."""

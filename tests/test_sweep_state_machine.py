@@ -73,6 +73,12 @@ class FakeLib:
             self._write(bbox, good_record(1.0)[:16])
         return 0
 
+    def asdf_decode_grid_dev(self, h, n, lattice, mode, hand, obj, bbox, stream):
+        self.log.append(("grid_dev", self.dec.math))
+        if bbox:
+            self._write(bbox, self.grid_dev_record if getattr(self, "grid_dev_record", None) is not None else good_record(1.0)[:16])
+        return 0
+
     def _one_plane(self, name, rec):
         self.log.append((name, self.dec.math))
         self._write(rec, self.script.pop(0))
@@ -564,3 +570,73 @@ def test_cluster_fault_report_switches_the_form_off_once(machine):
     assert dec.fall_back_if_overflowed(r) is False and off == [0]    # once
     assert any("cluster form" in m for m in dec.events["modes_switched_off"])
     dec._h = None
+
+
+def test_ordinary_sweeps_are_enqueued_in_one_go_too(monkeypatch):
+    """Round 6: the product's default - ordinary sweeps in both passes - takes the one-go form as well: coarse sweep, zoom cube on the
+    device, fine sweep reading its lattice from those words (asdf_decode_grid_dev).  Nothing is read in between; the two bbox records are
+    judged when the sample is finished."""
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE", "ASDF_FAST"):
+        monkeypatch.delenv(k, raising=False)
+    dec = _bare_decoder()
+    assert not dec.can_speculate(N) and dec.can_speculate_ordinary()
+    t = dec.two_pass_begin(N, 2.0 / (N - 1))
+    assert [k for k, _ in dec._L.log] == ["grid", "zoom", "grid_dev"] and dec.events["samples_in_one_go"] == 1
+    assert t["coarse"]["kind"] == "exact" and t["fine"]["kind"] == "exact" and t["fine"]["rec"] is not None
+    ok, b, _ = dec.coarse_judge(t["coarse"])
+    assert ok and b[:7].tolist() == good_record(1.0)[:7].tolist() and dec.box_stats["exact"] == 1
+    assert dec.lattice_of(t)[0] == [-0.5, -0.25, -0.125] and float(dec.lattice_of(t)[1]) == 0.0078125
+    assert not dec.fine_needs_repeat(t["fine"]) and dec.band_stats["exact"] == 1
+    # an uncalibrated MLP, a sweep ordered onto the fp32 chain, or a one-plane mode switched on: step by step (resp. the audited form)
+    dec._calibrated = False
+    assert not dec.can_speculate_ordinary() and dec.two_pass_begin(N, 2.0 / (N - 1)) is None
+    dec._calibrated = True
+    dec._force_f32_once = True
+    assert not dec.can_speculate_ordinary()
+    dec._force_f32_once = False
+    dec.fine_mode = "band"
+    assert not dec.can_speculate_ordinary()
+    dec.fine_mode = "exact"
+    dec.set_math("f32")
+    dec._calibrated = False                                          # (the fp32 chain has no activation scales to calibrate)
+    t = dec.two_pass_begin(N, 2.0 / (N - 1))
+    assert t is not None and t["fine"]["rec"] is None and not dec.fine_needs_repeat(t["fine"])
+
+
+def test_a_range_violation_in_a_speculative_ordinary_coarse_pass_is_recovered_once(monkeypatch):
+    """The coarse record of a sample enqueued in one go reports activations outside the fp16 range: coarse_judge books the recovery
+    (new activation scales - once), the caller repeats the pass through coarse_finish(ticket, judged), which launches it again and does
+    NOT recover a second time for the same record."""
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    for k in ("ASDF_MATH", "ASDF_COARSE", "ASDF_FINE", "ASDF_FAST"):
+        monkeypatch.delenv(k, raising=False)
+    dec = _bare_decoder()
+    recovered = []
+
+    def fake_recover(bad, status=None):
+        recovered.append(bad)
+        dec._recalibrations += 1
+
+    dec._recover = fake_recover
+    bad = good_record(1.0)[:16].copy()
+    bad[7] = 12
+    real = dec._L.asdf_decode_grid
+    first = []
+
+    def grid(h, n, org, vs, mode, hand, obj, bbox, stream):
+        rc = real(h, n, org, vs, mode, hand, obj, bbox, stream)
+        if not first and bbox:
+            first.append(1)
+            dec._L._write(bbox, bad)
+        return rc
+
+    dec._L.asdf_decode_grid = grid
+    t = dec.two_pass_begin(N, 2.0 / (N - 1))
+    judged = dec.coarse_judge(t["coarse"])
+    assert judged[0] is False and recovered == [12] and dec.events["repeated_sweeps"] == 1
+    dec._L.log.clear()
+    b = dec.coarse_finish(t["coarse"], judged=judged)
+    assert [k for k, _ in dec._L.log] == ["grid"] and recovered == [12] and b[7] == 0 and dec.box_stats["exact"] == 1
+    # the fine pass of that sample was launched under the old scales: its record is judged as stale and it is repeated
+    assert dec.fine_needs_repeat(dict(t["fine"], rec=torch.from_numpy(bad.copy()), host=None)) is True
