@@ -27,6 +27,23 @@ def shard_range(num_items, world_size, rank):
     return start, end
 
 
+SHARD_MODES = ("contiguous", "strided")
+
+
+def shard_slice(num_items, world_size, rank, mode="contiguous"):
+    """(start, end, stride) of `rank`'s samples.  "contiguous" = the reference's ranges (shard_range; the default: a maintainer finds the
+    same samples on the same rank).  "strided" = rank, rank + W, rank + 2 W, ... (SURVEY 8 e2's build option): where the cost of a sample
+    drifts along the split - ObMan's is ordered by object, and marching cubes / eval-mode ICP cost follows the surface size - contiguous
+    ranges give one rank the expensive stretch; interleaving spreads it.  With the default's 150 ms per sample +- 3 % it is worth little;
+    it is there for splits where it is not."""
+    if mode == "strided":
+        return int(rank), int(num_items), int(world_size)
+    if mode != "contiguous":
+        raise ValueError("shard mode %r (one of %s)" % (mode, ", ".join(SHARD_MODES)))
+    a, b = shard_range(num_items, world_size, rank)
+    return a, b, 1
+
+
 def physical_cores():
     """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo restricted to the CPUs this process may
     run on; falls back to the logical count)."""
@@ -310,14 +327,14 @@ def write_shard_records(shard_dir, start, end, rank, records, error=None):
     return path
 
 
-def merge_shard_files(shard_dir, num_items, world_size):
+def merge_shard_files(shard_dir, num_items, world_size, mode="contiguous"):
     """(records sorted by index, shards) from the records_<start>_<end>.json files of THIS run's ranges (shard_range per rank - files
     of an earlier run with another world size are not looked at).  `shards` = one entry per rank: {"rank", "range", "status":
     "ok" | "failed" | "missing", "samples", "error"}.  What rank 0 falls back to when the gather could not complete, and what
     `--merge-only` runs after a job that was torn down."""
     records, shards = [], []
     for r in range(int(world_size)):
-        a, b = shard_range(num_items, world_size, r)
+        a, b, _ = shard_slice(num_items, world_size, r, mode)
         entry = {"rank": r, "range": [a, b], "status": "missing", "samples": 0, "error": None}
         try:
             with open(shard_records_path(shard_dir, a, b)) as f:
@@ -343,7 +360,7 @@ def _group_timeout():
     return datetime.timedelta(seconds=max(sec, 1.0))
 
 
-def run_sharded(num_items, process_range, backend=None, shard_dir=None):
+def run_sharded(num_items, process_range, backend=None, shard_dir=None, mode="contiguous"):
     """Initialise the process group from the torchrun environment, run `process_range(start, end, rank)` on this
     rank's shard and gather the records on rank 0 (returned there, None elsewhere).
 
@@ -372,11 +389,12 @@ def run_sharded(num_items, process_range, backend=None, shard_dir=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_group_timeout())
         created = True
-    start, end = shard_range(num_items, world, rank)
+    start, end, stride = shard_slice(num_items, world, rank, mode)
     error, failed, merged = None, [], None
     try:
         try:
-            records = process_range(start, end, rank)
+            # (strided shards: the callable takes the stride as a keyword; contiguous ones keep the three-argument form)
+            records = process_range(start, end, rank) if stride == 1 else process_range(start, end, rank, stride=stride)
         except Exception as e:                     # (KeyboardInterrupt / SystemExit end the rank: the others time out on it)
             error = e
             records = list(getattr(e, "partial_records", []) or [])
@@ -391,7 +409,7 @@ def run_sharded(num_items, process_range, backend=None, shard_dir=None):
                 dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
                 flags = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
                 dist.all_gather(flags, torch.tensor([0 if error is None else 1], dtype=torch.int64, device=dev))
-                failed = [{"rank": r, "range": list(shard_range(num_items, world, r)), "error": None} for r, f in enumerate(flags) if int(f.item())]
+                failed = [{"rank": r, "range": list(shard_slice(num_items, world, r, mode)[:2]), "error": None} for r, f in enumerate(flags) if int(f.item())]
                 merged = gather_records(records)
                 if created:
                     dist.barrier()
@@ -439,6 +457,9 @@ def main(argv=None):
     p.add_argument("--merge-only", dest="merge_only", type=int, default=None, metavar="WORLD_SIZE",
                    help="no reconstruction: build reconstruct_summary.json / sweeps.json from the records_*.json / sweeps_*.json the "
                         "ranks of a WORLD_SIZE-rank run left in Eval_<task>/ (after a job that was torn down before its gather)")
+    p.add_argument("--shard", choices=list(SHARD_MODES), default="contiguous",
+                   help="how the split is dealt to the ranks: the reference's contiguous ranges (default; dist_reconstruct.py:63-76) or "
+                        "strided (rank, rank + W, ...: spreads a stretch of expensive samples over the ranks)")
     rc.add_sweep_arguments(p)       # --fast / --coarse / --fine: ordinary sweeps (every voxel at <= 1e-5) unless the caller opts in
     args = p.parse_args(argv)
     rc.apply_sweep_arguments(args)
@@ -465,17 +486,17 @@ def main(argv=None):
         return 1 if bad else 0
 
     if args.merge_only is not None:
-        sys.exit(finish(*merge_shard_files(output_dir, len(names), world)))
+        sys.exit(finish(*merge_shard_files(output_dir, len(names), world, args.shard)))
 
     specs, decoder = rc.load_experiment(args.experiment_directory)
     source = rc.code_source_from_args(args, specs, p)
 
-    def process(start, end, rank):
-        print("rank %d: samples %d to %d" % (rank, start, end - 1), flush=True)
+    def process(start, end, rank, stride=1):
+        print("rank %d: samples %d to %d%s" % (rank, start, end - 1, "" if stride == 1 else " in steps of %d" % stride), flush=True)
         try:
             recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
                                   eval_mode=True, label_out=args.optim, code_source=source, data_root=args.data_root,
-                                  allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None)
+                                  allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None, stride=stride)
         except Exception as e:
             for r in getattr(e, "partial_records", []) or []:
                 r["milliseconds"] = 1e3 * r.get("seconds", 0.0)
@@ -485,10 +506,10 @@ def main(argv=None):
         return recs
 
     try:
-        merged = run_sharded(len(names), process, shard_dir=output_dir)
+        merged = run_sharded(len(names), process, shard_dir=output_dir, mode=args.shard)
         code = 0
         if merged is not None:
-            shards = [{"rank": r, "range": list(shard_range(len(names), world, r)), "status": "ok", "error": None,
+            shards = [{"rank": r, "range": list(shard_slice(len(names), world, r, args.shard)[:2]), "status": "ok", "error": None,
                        "samples": sum(1 for m in merged if m.get("rank", 0) == r)} for r in range(world)]
             code = finish(merged, shards)
     except ShardFailure as e:
@@ -496,7 +517,7 @@ def main(argv=None):
         if rank == 0:
             if e.merged is not None:
                 bad = {f["rank"]: f for f in e.failed}
-                shards = [{"rank": r, "range": list(shard_range(len(names), world, r)), "status": "failed" if r in bad else "ok",
+                shards = [{"rank": r, "range": list(shard_slice(len(names), world, r, args.shard)[:2]), "status": "failed" if r in bad else "ok",
                            "error": bad[r]["error"] if r in bad else None, "samples": sum(1 for m in e.merged if m.get("rank", 0) == r)}
                           for r in range(world)]
                 # (the failing rank's own message is in its records file; rank 0 only knows its own)
@@ -508,7 +529,7 @@ def main(argv=None):
                             pass
                 finish(e.merged, shards)
             else:
-                finish(*merge_shard_files(output_dir, len(names), world))      # a peer is gone: what the ranks left on disk
+                finish(*merge_shard_files(output_dir, len(names), world, args.shard))      # a peer is gone: what the ranks left on disk
         else:
             print("rank %d: %s" % (rank, e), flush=True)
     if code:

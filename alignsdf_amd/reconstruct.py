@@ -491,7 +491,7 @@ class FileWriter:
             raise first
 
 
-def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim, components=None):
+def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim, components=None, stride=1):
     """`<output_dir>/sweeps_<start>_<end>.json` - next to `meshes/`, whose listing stays the reference's (reconstruct.py:34-35) -: which
     sweeps produced the volumes behind this shard's meshes.
     The default sweeps of a mesh-producing run rest on a measured, statistical certificate; a run whose sweeps
@@ -500,6 +500,8 @@ def write_sweeps_json(out_dir, start_point, end_point, report, samples, cube_dim
     hip = report.get("evaluator")
     body = {"range": [int(start_point), int(end_point)], "samples": int(samples), "cube_dim": int(cube_dim),
             "sweeps": hip.sweep_report(report.get("snapshot")) if hip is not None else None}
+    if int(stride) != 1:
+        body["stride"] = int(stride)               # (a strided shard: samples start, start + stride, ... below end)
     if components is not None:
         # f1, the largest-component filter (K8; PARITY UNPINNED against trimesh): how many components of >= 4 faces it dropped as open /
         # non-manifold - the only place where trimesh's fill_holes (utils/mesh.py:371 -> graph.split -> submesh(repair=True); not
@@ -616,14 +618,16 @@ def reconstruct_sample(decoder, specs, latent, mano_results, obj_results, N, mes
 
 def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, end_point, task="obman", device="cuda", scale=None,
                 cube_dim=128, label_out=False, viz=False, eval_mode=False, code_source=None, grid_mode="reference",
-                data_root="data", allow_missing_gt=False, fast=None):
+                data_root="data", allow_missing_gt=False, fast=None, stride=1):
     """Reconstruct samples [start_point, end_point) of a split file (reconstruct.py:33-95).  `loaded_model` is the
     decoder module, or any wrapper exposing it as `.module.decoder` / `.decoder` like the reference's DataParallel model.
-    `fast`: see pipelined_two_pass (default: ordinary sweeps, every voxel at <= 1e-5).  Returns the list of per-sample records."""
+    `fast`: see pipelined_two_pass (default: ordinary sweeps, every voxel at <= 1e-5).  `stride` > 1: every stride-th sample of the
+    range (the strided shards of dist_reconstruct --shard strided).  Returns the list of per-sample records."""
     mesh_dir = os.path.join(output_dir, "meshes")
     os.makedirs(mesh_dir, exist_ok=True)
+    stride = max(1, int(stride))
     with open(split_filename, "r") as f:
-        names = json.load(f)["filenames"][int(start_point):int(end_point)]
+        names = json.load(f)["filenames"][int(start_point):int(end_point):stride]
     decoder = loaded_model
     for attr in ("module", "decoder"):
         decoder = getattr(decoder, attr, decoder)
@@ -641,8 +645,8 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
             name = path.split("/")[-1].split(".")[0]                       # reconstruct.py:78
             if gt is not None:
                 gt.prefetch(os.path.join(mesh_dir, "%s_hand.ply" % name))  # parsed + sampled by the time the ICP hook wants it
-            latent, mano_results, obj_results = code_source(name, int(start_point) + k)
-            yield (int(start_point) + k, name), latent, mano_results, obj_results
+            latent, mano_results, obj_results = code_source(name, int(start_point) + k * stride)
+            yield (int(start_point) + k * stride, name), latent, mano_results, obj_results
 
     records = []
     sweeps = {}
@@ -721,7 +725,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         exc.partial_records = list(records)
         if sweeps:
             try:                                   # the shard's sweep report exists even when the shard did not finish
-                write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components)
+                write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components, stride)
             except Exception as e:
                 import logging
                 logging.error("writing the sweep report of a failed shard failed: %s", e)
@@ -738,7 +742,7 @@ def reconstruct(loaded_model, specs, split_filename, output_dir, start_point, en
         gt.close()
     writer.close()                      # every file is on disk (or its error raised) before reconstruct() returns
     if sweeps:
-        write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components)
+        write_sweeps_json(output_dir, start_point, end_point, sweeps, len(records), cube_dim, components, stride)
     return records
 
 

@@ -342,6 +342,13 @@ def short_line(full, details_path):
         roof["fp32_peak"] = PEAK_FP32_MFMA_TFLOPS
         roof["fp32_achieved"] = o.get("achieved")
         roof["fp32_frac"] = o.get("frac")
+    o = full.get("sustained")
+    if o:          # (--fast in the timed region: the same pipeline over enough samples to contain the periodic whole-lattice comparisons)
+        cfg["sustained_ms_per_step_incl_recalibration"] = o["ms_per_step"]
+        cfg["sustained_meshes_per_s"] = o["value"]
+        cfg["sustained_steps"] = o["steps"]
+        cfg["sustained_recalibrations"] = o["recalibrations"]
+        cfg["sustained_refused_sweeps"] = o["refused_sweeps"]
     mc = full.get("roofline_marching_cubes")
     if mc:
         roof["mc_bound"] = mc.get("bound")

@@ -387,3 +387,47 @@ def test_merge_only_ignores_other_runs_shards(tmp_path):
     assert json.load(open(rc.merge_sweeps_json(d)))["totals"]["sweeps_audited"] == 1010          # (no ranges: everything present)
     plain = rc.sweeps_summary_line({"sweeps_audited": 0, "sweeps_refused": 0, "ordinary_sweeps": 24})
     assert "24 ordinary" in plain and "--fast" in plain
+
+
+# ---- round 6: SURVEY 8 e2's build option - strided shards ----------------------------------------------------------------------------
+def test_strided_shards_cover_every_sample_once():
+    from alignsdf_amd.dist_reconstruct import shard_slice
+    for n, w in ((6285, 8), (29464, 8), (10, 3), (7, 8), (0, 2), (5, 1)):
+        seen = []
+        for r in range(w):
+            a, b, st = shard_slice(n, w, r, "strided")
+            assert (a, b, st) == (r, n, w)
+            seen += list(range(a, b, st))
+        assert sorted(seen) == list(range(n))
+        assert [shard_slice(n, w, r) for r in range(w)] == [shard_range(n, w, r) + (1,) for r in range(w)]       # the default is the reference's rule
+    with pytest.raises(ValueError):
+        shard_slice(10, 2, 0, "round-robin")
+
+
+STRIDED_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+from alignsdf_amd import dist_reconstruct as dr
+n, out_dir = int(sys.argv[1]), sys.argv[2]
+def process(start, end, rank, stride=1):
+    return [dict(index=i, V_hand=10 * i + 1, F_hand=20 * i + 2, V_obj=3 * i, F_obj=4 * i, milliseconds=1.0 + rank) for i in range(start, end, stride)]
+merged = dr.run_sharded(n, process, backend="gloo", shard_dir=out_dir, mode="strided")
+if merged is not None:
+    json.dump(merged, open(os.path.join(out_dir, "merged.json"), "w"))
+"""
+
+
+def test_strided_shards_over_gloo(tmp_path):
+    """World 3, 10 samples, `mode="strided"`: rank r processes r, r + 3, ...; the gather returns every sample once in index order with
+    the rank that produced it, and the records files / merge_shard_files follow the strided ranges."""
+    script = tmp_path / "worker.py"
+    script.write_text(STRIDED_WORKER % {"root": ROOT})
+    out = tmp_path / "Eval"
+    out.mkdir()
+    assert _spawn_plain_ranks(script, 3, [10, out], timeout=120) == [0, 0, 0]
+    merged = json.load(open(out / "merged.json"))
+    assert [m["index"] for m in merged] == list(range(10)) and [m["rank"] for m in merged] == [i % 3 for i in range(10)]
+    from alignsdf_amd.dist_reconstruct import merge_shard_files
+    recs, shards = merge_shard_files(str(out), 10, 3, "strided")
+    assert [r["index"] for r in recs] == list(range(10)) and [(s["range"], s["samples"], s["status"]) for s in shards] == [([0, 10], 4, "ok"), ([1, 10], 3, "ok"), ([2, 10], 3, "ok")]
+    assert sorted(os.path.basename(p) for p in map(str, out.glob("records_*.json"))) == ["records_0_10.json", "records_1_10.json", "records_2_10.json"]

@@ -51,5 +51,7 @@ for i in range(n):
         checked += 1
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("%d box sweeps at N = %d in %.1f s (%.1f us each), %d comparisons with the tile form equal; last candidate count %d" % (
-    n, N, dt, 1e6 * dt / n, checked, int(rec.cpu()[32])))
+fault = int(hip._status(clear=False)[11])          # round 6: the cluster form's sticky report of a member that did not arrive within its bound
+print("%d box sweeps at N = %d in %.1f s (%.1f us each), %d comparisons with the tile form equal; last candidate count %d; cluster fault word %d" % (
+    n, N, dt, 1e6 * dt / n, checked, int(rec.cpu()[32]), fault))
+assert fault == 0, "a member of a cluster did not arrive within the default bound during the soak"
