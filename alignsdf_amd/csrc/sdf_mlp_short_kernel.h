@@ -248,10 +248,13 @@ __device__ __forceinline__ void sdf_mlp_short_body(const DecodeParams& p, const 
         // fault word - BEFORE its remaining arrivals, which it still makes, so that the counters stay multiples of four and nobody
         // else waits for it - and stops waiting; whoever runs the last layer of a cluster sees the word behind its acquire and writes
         // nothing; the tile form enqueued behind this launch then evaluates the list (DecodeParams::short_fault), same bits.
+        // (A bound of ONE tick is the test hook: the member gives up at its first wait WITHOUT looking at the counter - whether four
+        // members that start together ever find each other missing is a matter of timing, and a test must not depend on that.)
+        const bool forced = sp.timeout_ticks == 1;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int)(__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all) < 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > sp.timeout_ticks) {
+        while (forced || (int)(__hip_atomic_load(arrivals + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - all) < 0) {
+          if (!forced) __builtin_amdgcn_s_sleep(1);
+          if (forced || __builtin_amdgcn_s_memrealtime() - t0 > sp.timeout_ticks) {
             __hip_atomic_store(sp.fault, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_gave_up = 1;
             break;

@@ -310,13 +310,16 @@ def shard_records_path(shard_dir, start, end):
     return os.path.join(shard_dir, "records_%d_%d.json" % (int(start), int(end)))
 
 
-def write_shard_records(shard_dir, start, end, rank, records, error=None):
+def write_shard_records(shard_dir, start, end, rank, records, error=None, running=False):
     """`<shard_dir>/records_<start>_<end>.json`, written by every rank BEFORE it enters any collective: whatever
     happens to the gather - a peer that raised, a peer that died, a watchdog timeout - what this shard produced is on disk.  Only
-    the RECORD_FIELDS (+ name) of each record; written to a temporary name and renamed, so a reader never sees half a file."""
+    the RECORD_FIELDS (+ name) of each record; written to a temporary name and renamed, so a reader never sees half a file.
+    `running`: the shard is still at work (status "running": run_sharded writes an EMPTY one before the first sample, which also
+    replaces whatever an earlier run left under this name, and shard_progress rewrites it as samples finish) - a rank that is killed
+    from outside (torchrun tears every worker down when one exits non-zero) leaves what it had finished, marked as unfinished."""
     os.makedirs(shard_dir, exist_ok=True)
     keep = RECORD_FIELDS + ("name",)
-    body = {"rank": int(rank), "range": [int(start), int(end)], "status": "ok" if error is None else "failed",
+    body = {"rank": int(rank), "range": [int(start), int(end)], "status": "running" if running else ("ok" if error is None else "failed"),
             "error": None if error is None else "%s: %s" % (type(error).__name__, error),
             "records": [{k: r[k] for k in keep if k in r} for r in records]}
     path = shard_records_path(shard_dir, start, end)
@@ -327,10 +330,33 @@ def write_shard_records(shard_dir, start, end, rank, records, error=None):
     return path
 
 
+def shard_progress(shard_dir, start, end, rank, every=2.0, getter=None):
+    """A per-sample callback for a shard's process_range (reconstruct(..., on_record=...)): keeps the finished records and rewrites
+    the shard's records file with status "running" at most every `every` seconds.  The final file (status ok / failed) is
+    run_sharded's; this one is for the rank that never gets there - killed by the launcher, by the OOM killer, by a node failure:
+    its finished samples are then in the file that `--merge-only` and rank 0's fallback read, marked as an unfinished shard.
+    `getter(rec)` maps what the caller is handed to the stored record (default: as it is)."""
+    import time
+    done, last = [], [time.monotonic()]
+
+    def on_record(rec):
+        done.append(getter(rec) if getter is not None else rec)
+        now = time.monotonic()
+        if now - last[0] >= every:
+            last[0] = now
+            try:
+                write_shard_records(shard_dir, start, end, rank, done, running=True)
+            except OSError:
+                pass                               # (progress only: the final write reports its own failure)
+
+    on_record.records = done
+    return on_record
+
+
 def merge_shard_files(shard_dir, num_items, world_size, mode="contiguous"):
     """(records sorted by index, shards) from the records_<start>_<end>.json files of THIS run's ranges (shard_range per rank - files
     of an earlier run with another world size are not looked at).  `shards` = one entry per rank: {"rank", "range", "status":
-    "ok" | "failed" | "missing", "samples", "error"}.  What rank 0 falls back to when the gather could not complete, and what
+    "ok" | "failed" | "running" (the rank never wrote its final file: killed, or still at work) | "missing", "samples", "error"}.  What rank 0 falls back to when the gather could not complete, and what
     `--merge-only` runs after a job that was torn down."""
     records, shards = [], []
     for r in range(int(world_size)):
@@ -391,6 +417,13 @@ def run_sharded(num_items, process_range, backend=None, shard_dir=None, mode="co
         created = True
     start, end, stride = shard_slice(num_items, world, rank, mode)
     error, failed, merged = None, [], None
+    if shard_dir is not None:
+        # an EMPTY "running" file before the first sample: a file an earlier run left under this range's name can no longer be taken
+        # for this run's result when the rank is killed before its final write
+        try:
+            write_shard_records(shard_dir, start, end, rank, [], running=True)
+        except OSError as e:
+            logging.error("rank %d: cannot write its shard records to %s: %s", rank, shard_dir, e)
     try:
         try:
             # (strided shards: the callable takes the stride as a keyword; contiguous ones keep the three-argument form)
@@ -493,10 +526,12 @@ def main(argv=None):
 
     def process(start, end, rank, stride=1):
         print("rank %d: samples %d to %d%s" % (rank, start, end - 1, "" if stride == 1 else " in steps of %d" % stride), flush=True)
+        progress = shard_progress(output_dir, start, end, rank, getter=lambda r: dict(r, milliseconds=1e3 * r.get("seconds", 0.0)))
         try:
             recs = rc.reconstruct(decoder, specs, split, output_dir, start, end, task=args.task, cube_dim=args.cube_dim,
                                   eval_mode=True, label_out=args.optim, code_source=source, data_root=args.data_root,
-                                  allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None, stride=stride)
+                                  allow_missing_gt=args.allow_missing_gt, fast=True if args.fast else None, stride=stride,
+                                  on_record=progress)
         except Exception as e:
             for r in getattr(e, "partial_records", []) or []:
                 r["milliseconds"] = 1e3 * r.get("seconds", 0.0)

@@ -253,7 +253,8 @@ int asdf_decoder_set_cluster_list(asdf_decoder_t* dec, int32_t max_points);
  * switches the form on again - the cluster writes nothing, and the tile form enqueued behind the launch evaluates the list instead
  * (bit-identical results, about 0.2 ms later).  Bit 29 of word 7 of a sweep's bbox record and word [16 + 11] of a one-plane sweep's
  * record carry the report to the host, which switches the form off (asdf_decoder_set_cluster_list(dec, 0)).  Until round 5 the wave
- * trapped instead, which costs the whole HIP context.  A tiny `ticks` is the test hook that provokes the failure. */
+ * trapped instead, which costs the whole HIP context.  `ticks` = 1 is the test hook that provokes the failure deterministically:
+ * every member gives up at its first wait without looking at the counter. */
 int asdf_decoder_set_cluster_timeout(asdf_decoder_t* dec, uint64_t ticks);
 
 /* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed

@@ -268,6 +268,7 @@ n, out_dir, mode = int(sys.argv[1]), sys.argv[2], sys.argv[3]
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 def process(start, end, rank):
     recs = []
+    progress = dr.shard_progress(out_dir, start, end, rank, every=0.0)      # (what dist_reconstruct.main hands to reconstruct(on_record=...))
     for i in range(start, end):
         if rank == 1 and i == start + 2:
             if mode == "raise":
@@ -276,6 +277,7 @@ def process(start, end, rank):
                 raise e
             os._exit(7)                                          # mode "die": the process is gone, no exception, no collective
         recs.append(dict(index=i, V_hand=10 * i + 1, F_hand=20 * i + 2, V_obj=3 * i, F_obj=4 * i, milliseconds=1.0 + rank, name="s%%04d" %% i))
+        progress(recs[-1])
     return recs
 t0 = time.time()
 code = 0
@@ -344,21 +346,26 @@ def test_a_rank_that_raises_mid_shard_does_not_take_the_others_along(tmp_path):
 def test_a_rank_that_dies_leaves_its_peers_records_on_disk(tmp_path):
     """Rank 1 of 3 DIES mid-shard (os._exit: no exception, no collective).  The survivors finish their ranges, find the gather broken
     within seconds (gloo notices a closed peer at once; RCCL within ASDF_DIST_TIMEOUT), raise ShardFailure, and rank 0 builds the
-    summary from the records files on disk: two complete shards, the third named as missing."""
+    summary from the records files on disk: two complete shards, and the third as the unfinished shard it is - status "running", with
+    the two samples it had finished (its progress file), NOT the complete-looking file an earlier run had left under the same name."""
     import time
     script = tmp_path / "worker.py"
     script.write_text(FAILING_WORKER % {"root": ROOT})
     out = tmp_path / "Eval"
     out.mkdir()
+    from alignsdf_amd import dist_reconstruct as dr
+    dr.write_shard_records(str(out), 4, 8, 1, [dict(index=i, V_hand=-1, F_hand=-1, V_obj=-1, F_obj=-1, milliseconds=0.0) for i in range(4, 8)])   # a stale, complete-looking file
     t0 = time.time()
     codes = _spawn_plain_ranks(script, 3, [12, out, "die"], timeout=180, extra_env={"ASDF_DIST_TIMEOUT": "20"})
     assert time.time() - t0 < 120
     assert codes[1] == 7 and codes[0] == 3 and codes[2] == 3
     summary = json.load(open(out / "reconstruct_summary.json"))
     assert summary["complete"] is False
-    assert [(s["rank"], s["status"], s["samples"]) for s in summary["shards"]] == [(0, "ok", 4), (1, "missing", 0), (2, "ok", 4)]
-    assert [r["index"] for r in summary["records"]] == [0, 1, 2, 3, 8, 9, 10, 11]
-    assert not os.path.exists(out / "records_4_8.json")
+    assert [(s["rank"], s["status"], s["samples"]) for s in summary["shards"]] == [(0, "ok", 4), (1, "running", 2), (2, "ok", 4)]
+    assert [r["index"] for r in summary["records"]] == [0, 1, 2, 3, 4, 5, 8, 9, 10, 11]
+    assert all(r["V_hand"] == 10 * r["index"] + 1 for r in summary["records"])          # nothing of the stale file
+    shard = json.load(open(out / "records_4_8.json"))
+    assert shard["status"] == "running" and [r["index"] for r in shard["records"]] == [4, 5]
 
 
 def test_merge_only_ignores_other_runs_shards(tmp_path):
