@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libalignsdf_hip.so")
-SOURCES = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip", "mc33.hip", "icp.hip", "mesh_cc.hip", "surface_sample.hip"]
+SOURCES = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1hw_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip", "mc33.hip", "icp.hip", "mesh_cc.hip", "surface_sample.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # MFMA accumulators in VGPRs (the compiler's default heuristic puts them in AGPRs at this register pressure and the epilogues then read
@@ -18,7 +18,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # time (1 862 -> 70 reads per tile body), the fp32 chain -0.4 % and no scratch left in its CombinedDecoder form; the split-half kernels
 # (k1h_kernels.hip) +0.5 % and k1h_nerf_kernels.hip crashes this compiler in that form: both stay on the default.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-TU_FLAGS = {"k1s_kernels.hip": VGPR_FORM, "k1s_nerf_kernels.hip": VGPR_FORM, "k1_kernels.hip": VGPR_FORM, "k1_cls_kernels.hip": VGPR_FORM}
+# the W form's K-blocks carry more IR (sub-accumulator extracts / inserts around six MFMAs): at the default threshold the layer loops of
+# k1hw_kernels.hip come out ROLLED, with indexed registers (s_set_gpr_idx_on) - 87 instead of 72 ms per sweep
+UNROLL_ALL = ["-mllvm", "-pragma-unroll-threshold=200000"]
+TU_FLAGS = {"k1hw_kernels.hip": UNROLL_ALL, "k1s_kernels.hip": VGPR_FORM, "k1s_nerf_kernels.hip": VGPR_FORM, "k1_kernels.hip": VGPR_FORM, "k1_cls_kernels.hip": VGPR_FORM}
 
 
 def _stale(target, deps):

@@ -888,8 +888,11 @@ int asdf_decoder_create(const asdf_decoder_spec_t* spec, const asdf_head_params_
   if (e == hipSuccess) {
     if (!pack_decoder_f16(*spec, heads, hp)) { asdf_decoder_destroy(d); return ASDF_ENOMEM; }
     up(&d->cst16, hp.cst16);
-    if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, hp.stream16.size() * sizeof(uint16_t));
+    // (one allocation: the 32x32x16 image, and behind it the W form's - its kernels add the offset themselves)
+    if (e == hipSuccess) e = hipMalloc((void**)&d->stream16, (hp.stream16.size() + hp.stream16w.size()) * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(d->stream16, hp.stream16.data(), hp.stream16.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<uint16_t*>(d->stream16) + hp.stream16.size(), hp.stream16w.data(),
+                                       hp.stream16w.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
       // records of [plane hi / lo][lane][8 halves] -> the hi halves alone, same record order
       const size_t nrec = hp.stream16.size() / 1024;

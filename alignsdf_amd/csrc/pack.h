@@ -19,6 +19,7 @@ struct HostPack {
   std::vector<float> emb;      // [heads][ASDF_MAX_POINT_FEATS][4]  identity-on-xyz default
   // split-half image (ASDF_MATH_F16X3; see sdf_mlp_f16_kernel.h)
   std::vector<uint16_t> stream16;   // [kStagesAll][kStageFloats * 2] fp16 bits: stage = [kblock 8][plane 2][lane 64][8]
+  std::vector<uint16_t> stream16w;  // the same weights for the W form (16x16x32 MFMAs): records (tile, K32-block, feature half)
   std::vector<float> cst16;         // the constants block with the scaled entries of the split-half kernel
   float s2[kHeads];                 // scale of the layer-2 accumulator (K0 applies it to c2 / A2)
   float sw[kHeads][3];              // S_w of layers 1..3 (max |w| S_w in [512, 1024))
@@ -86,6 +87,7 @@ inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_pa
   const CstOffsets co = cst_offsets(hp.kp);
   try {
     hp.stream16.assign((size_t)kStagesAll * kStageFloats * 2, 0);
+    hp.stream16w.assign((size_t)kStagesAll * kStageFloats * 2, 0);
     hp.cst16 = hp.cst;
   } catch (...) {
     return false;
@@ -118,6 +120,29 @@ inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_pa
     pack(kTilesL1, 4, sw1, [&](int row, int feat) { return row < n1 ? W1[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 2, sw2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 4, sw3, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
+    // The W form's image (sdf_mlp_f16_kernel.h, "the W form"): the same planes, the same record count and stage structure, but a
+    // record i of a tile is (K32-block i >> 1, feature half i & 1) as the A operand of v_mfma_f32_16x16x32_f16 - lane l: row
+    // 32 t + 16 (i & 1) + (l & 15), slot (q = l >> 4, e) = input feature 32 (i >> 1) + 16 (e >> 2) + 4 q + (e & 3), the feature
+    // the producing layer's epilogue leaves in that slot of the B operand.
+    uint16_t* wp = &hp.stream16w[(size_t)h * kStagesHead * kStageFloats * 2];
+    auto pack_w = [&](int ntiles, int records_per_tile, float sw, auto weight_at) {
+      for (int t = 0; t < ntiles; ++t)
+        for (int i = 0; i < records_per_tile; ++i) {
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int row = 32 * t + 16 * (i & 1) + (lane & 15);
+              const int feat = 32 * (i >> 1) + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+              const float w = weight_at(row, feat) * sw;
+              const float hi = f16_round(w);
+              wp[(0 * 64 + lane) * 8 + e] = f16_bits(hi);
+              wp[(1 * 64 + lane) * 8 + e] = f16_bits(w - hi);
+            }
+          wp += 1024;
+        }
+    };
+    pack_w(kTilesL1, 32, sw1, [&](int row, int feat) { return row < n1 ? W1[(size_t)row * kHidden + feat] : 0.0f; });
+    pack_w(kTilesHidden, 16, sw2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
+    pack_w(kTilesHidden, 32, sw3, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
     hp.sw[h][0] = sw1; hp.sw[h][1] = sw2; hp.sw[h][2] = sw3;
   }
   const float sx_default[kHeads][3] = {{kActScale, kActScale, kActScale}, {kActScale, kActScale, kActScale}};

@@ -40,6 +40,48 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
+// ---- round 6: the W form (template parameter W of the body) - the same GEMMs on v_mfma_f32_16x16x32_f16 ----------------------------
+// Under real operands the part is power-managed and a launch takes the time its ENERGY takes (profiles/r06_k1h_front_ab.txt), and the
+// bare instruction streams differ: on K1h's operand pattern and split-half data the matrix pipe SUSTAINS 2.04-2.08 PFLOP/s with
+// 16x16x32 where it sustains 1.80-1.82 with 32x32x16 (tools/mfma_f16_energy_bench.hip, profiles/r06_mfma_shape_energy.txt).
+// Operand maps: A lane l holds A[i = l & 15][k-slot (l >> 4, e)], B lane l holds B[k-slot (l >> 4, e)][j = l & 15], e = 0..7 (the
+// SAME slot in both, so which k the hardware gives a slot never matters: the host packs the weight of the input feature that sits in
+// that slot of B); D lane l, register r holds D[row = 4 (l >> 4) + r][col = l & 15].
+// A wave's 32 points are two GROUPS of 16 (g = 0, 1); an output tile stays 32 features = two HALVES of 16 (fh = 0, 1); its accumulator
+// stays ONE f32x16 = four 16x16 tiles, register 8 g + 4 fh + r <-> (feature 32 T + 16 fh + 4 (l >> 4) + r, point 16 g + (l & 15)).
+// split_part's access pattern (acc[e], acc[8 + e] -> element e of two operands) then needs NO change: element e = 4 fh + r of
+// xh[2 T + g] = the B operand of K32-block T of the next layer for group g, whose slot (q, e) holds feature 32 T + 16 (e >> 2) + 4 q
+// + (e & 3).  A record of the stream (2 KiB, [plane][lane][8 halves]) = (tile, K32-block j, feature half fh), in the order
+// (j, fh) = (0, 0) (0, 1) (1, 0) ...: record i of a tile reads the B operands xh / xl[(i & ~1) + g] and feeds accumulator registers
+// 8 g + 4 (i & 1) .. + 3 with six 16-clock MFMAs (three per group, the groups alternating) - the same 96 matrix-pipe clocks, the same
+// LDS and L2 -> LDS traffic, the same stage structure as the 32x32x16 form.  The point-feature products of layers 0 / 2 run on
+// v_mfma_f32_16x16x4_f32 (K = 4 = x, y, z, pad in ONE instruction per feature half and group).  Biases, w4 and the point fragments
+// are read from the SAME constants image (another gather of the same words); only the weight stream has its own image
+// (pack.h: pack_decoder_f16w).
+#define ASDF_MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define ASDF_MFMA4W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 acc_get4(const f32x16& a, int o) {
+  f32x4 v;
+  v[0] = a[o]; v[1] = a[o + 1]; v[2] = a[o + 2]; v[3] = a[o + 3];
+  return v;
+}
+__device__ __forceinline__ void acc_set4(f32x16& a, int o, const f32x4& v) { a[o] = v[0]; a[o + 1] = v[1]; a[o + 2] = v[2]; a[o + 3] = v[3]; }
+// a tile's 32 bias-like words ([lane half][16 registers] of the 32x32 D layout) gathered for the W form's accumulator: feature
+// 16 fh + 4 q + r of the tile sits in register 4 (2 fh + (q >> 1)) + r of lane half q & 1
+__device__ __forceinline__ f32x16 load_bias16w(const float* tile_words, int lane) {
+  const int q = lane >> 4;
+  // FOUR reads, one per accumulator quad (the two groups start from the same words): a read lands in the quad it is for, where two
+  // reads + copies cost 16 v_accvgpr_write per tile.  (The second pointer is opaque so that the reads are not merged.)
+  const float* w0 = tile_words + (q & 1) * 16 + 4 * (q >> 1);
+  int dup = 0;
+  asm volatile("" : "+v"(dup));      // (an opaque ZERO, not an opaque pointer: the address stays an LDS address)
+  const float* w1 = w0 + dup;
+  f32x16 r;
+  acc_set4(r, 0, *reinterpret_cast<const f32x4*>(w0)); acc_set4(r, 4, *reinterpret_cast<const f32x4*>(w0 + 8));
+  acc_set4(r, 8, *reinterpret_cast<const f32x4*>(w1)); acc_set4(r, 12, *reinterpret_cast<const f32x4*>(w1 + 8));
+  return r;
+}
+
 // relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
 // v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
 // v_pack per register on top)
@@ -155,6 +197,9 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #endif
 #ifndef ASDF16_DMA_PER_KB
 #define ASDF16_DMA_PER_KB 1      // split-half kernel: ONE LDS-DMA piece per K-block (behind its last MFMA) over K-blocks BARRIER_KB .. + 7, not three per K-block
+#endif
+#ifndef ASDF16_W_ORDER
+#define ASDF16_W_ORDER 0         // W form: order of a record's six MFMAs (0 = product-sum outer, point group inner: the shipped one)
 #endif
 #ifndef ASDF16_FAST_TANH
 #define ASDF16_FAST_TANH 1       // tanh as 1 - 2 / (1 + exp(2 x)) on the hardware exp / rcp (absolute error ~1e-7; the values carry ~1e-4)
@@ -323,8 +368,22 @@ typedef NoOp16 NoEpilogue16;
 #ifndef ASDF16_PIN_ACC_P1
 #define ASDF16_PIN_ACC_P1 0
 #endif
-template <int PL = 2>
+// (W form: the accumulator is four independent quads - pinned one by one, or the 512-bit constraint makes the compiler gather them
+// into one aligned tuple through 16 v_accvgpr_read / write pairs per tile)
+template <int PL = 2, bool W = false>
 __device__ __forceinline__ void pin_acc(f32x16& acc) {
+  if (W) {
+    if (ASDF16_PIN_ACC) {
+#pragma unroll
+      for (int o = 0; o < 16; o += 4) {
+        f32x4 q;
+        q[0] = acc[o]; q[1] = acc[o + 1]; q[2] = acc[o + 2]; q[3] = acc[o + 3];
+        asm volatile("" : "+a"(q));
+        acc[o] = q[0]; acc[o + 1] = q[1]; acc[o + 2] = q[2]; acc[o + 3] = q[3];
+      }
+    }
+    return;
+  }
   if (PL == 2 ? ASDF16_PIN_ACC : ASDF16_PIN_ACC_P1) asm volatile("" : "+a"(acc));
 }
 
@@ -347,7 +406,7 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 // s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
 // ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, int PL, int G, bool STEPS, class Pre, class Epi>
+template <int KB, int Q, int SLOT, int ABL, int PL, int G, bool STEPS, bool W, class Pre, class Epi>
 __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
                                         h8 (&ah)[S16<PL, G>::kPrefetch], h8 (&al)[S16<PL, G>::kPrefetch], Pre&& pre, Epi&& epi) {
@@ -379,6 +438,28 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
     constexpr int base = Q * kS16Kb;
 #pragma unroll
     for (int j = 0; j < SG::kMfmas; ++j) {
+      if (W) {
+        // W form: record kb = feature half kb & 1 of K32-block (base + kb) >> 1; (W_hi, x_lo), (W_lo, x_hi), (W_hi, x_hi) for the two
+        // point groups in turn - every MFMA has an independent one between itself and the next on its accumulator
+        const int xb = (base + kb) & ~1, o = (kb & 1) * 4;
+        f32x4 s0 = acc_get4(acc, o), s1 = acc_get4(acc, 8 + o);
+#if ASDF16_W_ORDER == 0
+        const h8& af = j == 1 ? bufl[kb] : bufh[kb];
+        s0 = ASDF_MFMA16W(af, j == 0 ? xl[xb] : xh[xb], s0);
+        s1 = ASDF_MFMA16W(af, j == 0 ? xl[xb + 1] : xh[xb + 1], s1);
+#elif ASDF16_W_ORDER == 2
+        // (W_hi, x_lo), (W_hi, x_hi), (W_lo, x_hi): four MFMAs in a row on the same A operand (timing experiment)
+        const h8& af = j == 2 ? bufl[kb] : bufh[kb];
+        s0 = ASDF_MFMA16W(af, j == 0 ? xl[xb] : xh[xb], s0);
+        s1 = ASDF_MFMA16W(af, j == 0 ? xl[xb + 1] : xh[xb + 1], s1);
+#else
+        // group-outer (timing experiment): the three MFMAs of a group back to back on its accumulator
+        if (j == 0) { s0 = ASDF_MFMA16W(bufh[kb], xl[xb], s0); s0 = ASDF_MFMA16W(bufl[kb], xh[xb], s0); }
+        if (j == 1) { s0 = ASDF_MFMA16W(bufh[kb], xh[xb], s0); s1 = ASDF_MFMA16W(bufh[kb], xl[xb + 1], s1); }
+        if (j == 2) { s1 = ASDF_MFMA16W(bufl[kb], xh[xb + 1], s1); s1 = ASDF_MFMA16W(bufh[kb], xh[xb + 1], s1); }
+#endif
+        acc_set4(acc, o, s0); acc_set4(acc, 8 + o, s1);
+      } else
       if (PL == 1 && j == 0) acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
       else if (PL == 1) accb = ASDF_MFMA16(bufh[kb], xl[base + kb], accb);       // the second point group, same A fragment
       else
@@ -447,8 +528,9 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
 // constants block is 40 / 75 KiB).
 // SUB: the kGridSubset form of sdf_mlp_kernel.h - the points are the lattice voxels listed in p.idx (p.count_dev of them, a
 // device word; p.P is the list's capacity), coordinates from the voxel index, outputs scattered in place, no box.
-template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1, bool SUB = false>
+template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1, bool SUB = false, bool W = false>
 __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
+  static_assert(!W || (PL == 2 && G == 1 && KP == 2 && !TWO_OUT), "W form: split-half, affine point features, SeparateDecoder");
   using CL = CstLayout<KP>;
   using SG = S16<PL, G>;
   static_assert(G == 1 || !TWO_OUT, "two point groups: SeparateDecoder");
@@ -508,7 +590,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int i = tid; i < kA16Floats / 4; i += 256)
         if (i < kA16LayerFloats / 4 || i >= 2 * kA16LayerFloats / 4) reinterpret_cast<f32x4*>(a16s)[i] = src4[i];      // (layer 2's operands are not used: see the tuning log)
     }
-    const float* sbase0 = p.stream + (size_t)head * kS16Head * SG::kFloats;
+    // (W form: its image lies behind the 32x32x16 one in the same allocation)
+    const float* sbase0 = p.stream + (W ? (size_t)kStagesAll * kStageFloats : 0) + (size_t)head * kS16Head * SG::kFloats;
 #pragma unroll
     for (int s = 0; s < ((ABL & 33) ? kRing : kRing - 1); ++s) {
       const float* src = sbase0 + (size_t)s * SG::kFloats + wave * SG::kWaveFloats + lane * 4;
@@ -532,6 +615,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     // subset mode: list positions from here on are audit picks (see DecodeParams::audit)
     int audit_from = 0x7fffffff;
     if (SUB && p.audit) audit_from = p.audit_from ? *p.audit_from : 0;
+    // a tile's bias row as the accumulator's initial value (W form: gathered for the 16x16 tiles)
+    auto bias_at = [&](int off, int t) -> f32x16 {
+      if (W) return load_bias16w(hc + off + t * 32, lane);
+      return load_bias16(hc + off + (t * 2 + half) * 16);
+    };
+    // the fp32 A-fragment word of point-feature step s of tile t (W form: s = the feature half, k = lane >> 4 in ONE K = 4 step)
+    auto pt_word = [&](int off, int t, int s) -> float {
+      if (W) return hc[off + (t * 2 + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + 16 * s + (lane & 15)];
+      return hc[off + (t * KP + s) * 64 + lane];
+    };
 
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -583,6 +676,31 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
       }
+      // W form: the point operand of v_mfma_f32_16x16x4_f32 per group - lane l carries component l >> 4 of (x, y, z, 0) of point
+      // 16 g + (l & 15); a lane computed the coordinates of ITS point l & 31, the other group's come from lane l ^ 16
+      float bq[2] = {0.0f, 0.0f};
+      if (W) {
+        // component q = l >> 4 of point 16 g + (l & 15): the source lane is (l & 15) + 16 g (any lane with that l & 31)
+        const int q = lane >> 4;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int src = (lane & 15) + 16 * g;
+          const float c0 = __shfl(x0, src), c1 = __shfl(x1, src), c2 = __shfl(x2, src);
+          bq[g] = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : 0.0f;
+        }
+      }
+      // point-feature products of one tile into its accumulator: af[s] = pt_word(.., t, s)
+      auto pt_mfma = [&](f32x16& a, const float* af) {
+        if (W) {
+#pragma unroll
+          for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc_set4(a, 8 * g + 4 * fh, ASDF_MFMA4W(af[fh], bq[g], acc_get4(a, 8 * g + 4 * fh)));
+        } else {
+#pragma unroll
+          for (int s = 0; s < KP; ++s) a = ASDF_MFMA(af[s], bp[s], a);
+        }
+      };
       // one-plane kernels: the points as the fp16 B operand of layers 0 / 2 (sdf_layout.h: kA16Floats) - x T in two planes, T twice
       // (the bias planes' multiplier) on lane half 0; the high planes again on lane half 1 (they meet the weights' low planes)
       auto point_operand = [&](float c0, float c1, float c2, float T) -> h8 {
@@ -633,10 +751,14 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       auto load_pf2 = [&](int t) {
         if (!kPreloadPf) return;
 #pragma unroll
-        for (int s = 0; s < KP; ++s) pf2[s] = hc[CL::kA2 + (t * KP + s) * 64 + lane];
+        for (int s = 0; s < KP; ++s) pf2[s] = pt_word(CL::kA2, t, s);
       };
       auto load_w4 = [&](int t, int c) {        // accumulator registers 2 c, 2 c + 1 of tile t
-        const float* w4 = hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
+        // (W form: register 2 c = group c >> 2, feature half (c >> 1) & 1, r = 2 (c & 1): feature 16 fh + 4 q + r of the tile sits in
+        // register 4 (2 fh + (q >> 1)) + r of lane half q & 1 of the 32x32 D-layout image)
+        const int wq = lane >> 4;
+        const float* w4 = W ? hc + CL::kW4 + (t * 2 + (wq & 1)) * 16 + 4 * (2 * ((c >> 1) & 1) + (wq >> 1)) + 2 * (c & 1)
+                            : hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
         const float* w4b = hc + CL::kW4b + (t * 2 + half) * 16 + 2 * c;
         w4n[0] = w4[0]; w4n[1] = w4[1];
         if (TWO_OUT) { w4bn[0] = w4b[0]; w4bn[1] = w4b[1]; }
@@ -652,15 +774,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       float pf0[2][KP];
       auto l0_load = [&](int t) {
         if (!kPreloadPf) return;
-        acc0[t & 1] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+        acc0[t & 1] = bias_at(CL::kC0, t);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) pf0[t & 1][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
+        for (int s = 0; s < KP; ++s) pf0[t & 1][s] = pt_word(CL::kA0, t, s);
       };
       auto l0_compute = [&](int t, int g = -1) {
-        f32x16 acc = kPreloadPf ? acc0[t & 1] : load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+        f32x16 acc = kPreloadPf ? acc0[t & 1] : bias_at(CL::kC0, t);
         f32x16 accb = acc;
+        if (W) pt_mfma(acc, pf0[t & 1]);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) {
+        for (int s = 0; s < (W ? 0 : KP); ++s) {
           const float af = kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane];
           if (g != 1) acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s], accb);
@@ -682,8 +805,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         h8 lq[3];
         auto l0p_load = [&](int t) {
           if (kPt16) { lq[t % 3] = a16_frag(0, t); return; }      // bias and point-feature columns in one fp16 operand
-          la[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
-          if (G == 2) lb[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+          la[t % 3] = bias_at(CL::kC0, t);
+          if (G == 2) lb[t % 3] = bias_at(CL::kC0, t);
 #pragma unroll
           for (int s = 0; s < KP; ++s) lf[t % 3][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
         };
@@ -701,7 +824,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         };
         l0p_load(0);
         l0p_load(1);
-        acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+        acc1[0] = bias_at(CL::kB1, 0);
         if (G == 2) acc1b[0] = acc1[0];
         __builtin_amdgcn_sched_barrier(0);
         l0p_mfma(0);
@@ -715,7 +838,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         }
       } else {
       l0_load(0);
-      acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+      acc1[0] = bias_at(CL::kB1, 0);
       if (G == 2) acc1b[0] = acc1[0];
 #pragma unroll
       for (int t = 0; t < kL0Front; ++t) {
@@ -727,7 +850,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
-  stage16<KB, Q, SLOT, ABL, PL, G, kSteps>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
+  stage16<KB, Q, SLOT, ABL, PL, G, kSteps, W>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       ASDF16_MARK(1);
       // (split-half kernel: the second argument of an epilogue callback is the PIECE of the part - stage16 calls it behind each of
@@ -740,7 +863,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
         f32x16& accb = (G == 2 ? acc1b : acc1)[t & 1];
-        if (!ASDF16_PRELOAD && t > 0) acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
+        if (!ASDF16_PRELOAD && t > 0) acc = bias_at(CL::kB1, t);
         auto pre = [&](int kb) {       // first stage: the layer-0 tile of the NEXT K-block's epilogue slot
           const int c = kb - kEpiShift;
           if (t == 0 && ASDF16_PRELOAD && kL0Front < kTilesHidden && c >= 0 && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
@@ -752,10 +875,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             if (kSteps && kPreloadPf && kL0Front < kTilesHidden) {
               // a whole layer-0 tile per K-block: its fp32 MFMAs behind the first MFMA, its eight parts over the three gaps (3 + 3 + 2)
               const int T = kL0Front + c;
-              if (g == 0) {
-#pragma unroll
-                for (int s = 0; s < KP; ++s) acc0[T & 1] = ASDF_MFMA(pf0[T & 1][s], bp[s], acc0[T & 1]);
-              }
+              if (g == 0) pt_mfma(acc0[T & 1], pf0[T & 1]);
 #pragma unroll
               for (int e = 0; e < 8; ++e)
                 if (e / 3 == g) split_part<PL, G, kMix>(acc0[T & 1], acc0[T & 1], mul0, h0h[2 * T], h0l[2 * T], h0h[2 * T + 1], h0l[2 * T + 1], amax, e);
@@ -769,15 +889,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(t - 1) & 1]);
-          if (G == 2 && g != 0) pin_acc<PL>(acc1b[(t - 1) & 1]);
+          if (kSteps ? g <= 0 : g != 1) pin_acc<PL, W>(acc1[(t - 1) & 1]);
+          if (G == 2 && g != 0) pin_acc<PL, W>(acc1b[(t - 1) & 1]);
           split_part<PL, G, kMix>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
                             h1l[2 * (t - 1) + 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != kPreKb) return;
-          if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
-          else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
+          if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = bias_at(CL::kB1, (t + 1)); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
+          else { acc2[0] = bias_at(CL::kC2, 0); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, pre, epi);
@@ -804,9 +924,10 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
         f32x16& accb = (G == 2 ? acc2b : acc2)[t & 1];
-        if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
+        if (!ASDF16_PRELOAD) { acc = bias_at(CL::kC2, t); load_pf2(t); }
+        if (W) pt_mfma(acc, pf2);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) {
+        for (int s = 0; s < (W ? 0 : KP); ++s) {
           const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
           acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2) accb = ASDF_MFMA(af, bpb[s], accb);
@@ -816,13 +937,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL, W>(acc2[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL, W>(acc2b[(t - 1) & 1]);
             split_part<PL, G, kMix>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
                               h2l[2 * (t - 1) + 1], amax2, c, kSteps ? -1 : g, kSteps ? g : -1, er);
           } else {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(kTilesL1 - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc1b[(kTilesL1 - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL, W>(acc1[(kTilesL1 - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL, W>(acc1b[(kTilesL1 - 1) & 1]);
             split_part<PL, G, kMix>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
                               h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
@@ -830,11 +951,11 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {
           if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesHidden) {
-            acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
+            acc2[(t + 1) & 1] = bias_at(CL::kC2, (t + 1));
             if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
             load_pf2(t + 1);
           } else {
-            acc3[0] = load_bias16(hc + CL::kB3 + half * 16);
+            acc3[0] = bias_at(CL::kB3, 0);
             if (G == 2) acc3b[0] = acc3[0];
           }
         };
@@ -881,6 +1002,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             if (G == 2 && g != 0) { const float v = ab[2 * c + r]; partg = fmaf(fabsf(v), w, fmaf(v, w, partg)); }
             continue;
           }
+          if (W) {        // registers 8 .. 15 are the second point group's: its own dot product
+            const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
+            if (c < 4) part = fmaf(v, w, part);
+            else partg = fmaf(v, w, partg);
+            continue;
+          }
           if (g != 1) {
             const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
             part = fmaf(v, w, part);
@@ -895,7 +1022,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
         f32x16& accb = (G == 2 ? acc3b : acc3)[t & 1];
-        if (!ASDF16_PRELOAD) acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
+        if (!ASDF16_PRELOAD) acc = bias_at(CL::kB3, t);
         auto pre = [&](int kb) {       // first stage: w4 of the next epilogue part
           const int c = kb - kEpiShift;
           if (!kW4Tile && t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
@@ -905,8 +1032,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc3[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc3b[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL, W>(acc3[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL, W>(acc3b[(t - 1) & 1]);
             if (kSteps) {        // piece 0 / 1: one register of the pair each; piece 2: the next pair's weights
               if (g < 2) dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, -1, g);
               if (!kW4Tile && (g == 2 || g < 0)) next_w4();
@@ -915,8 +1042,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
               if (!kW4Tile && g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
             }
           } else {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(kTilesHidden - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(kTilesHidden - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc<PL, W>(acc2[(kTilesHidden - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc<PL, W>(acc2b[(kTilesHidden - 1) & 1]);
             split_part<PL, G, kMix>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
                               h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, kSteps ? -1 : g,
                               kSteps ? g : -1, er);  // K-blocks 30, 31: end of this tile
@@ -925,7 +1052,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
           if (c != kPreKb) return;
           if (ASDF16_PRELOAD && t + 1 < kTilesHidden) {
-            acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
+            acc3[(t + 1) & 1] = bias_at(CL::kB3, (t + 1));
             if (G == 2) acc3b[(t + 1) & 1] = acc3[(t + 1) & 1];
           }
           if (kW4Tile) { w4t = load_bias16(hc + CL::kW4 + (t * 2 + half) * 16); return; }
@@ -963,6 +1090,13 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #endif
         return tanhf(x);
       };
+      if (W) {
+        // the four lane groups hold the four quarters of every feature half: sum them, then every lane takes the sum of ITS point
+        // l & 31 (group (l >> 4) & 1) - everything below is the 32x32 form's
+        part += __shfl_xor(part, 16); partg += __shfl_xor(partg, 16);
+        part += __shfl_xor(part, 32); partg += __shfl_xor(partg, 32);
+        part = (lane & 16) ? partg : part;
+      } else
       part += __shfl_xor(part, 32);
       const float pre = part + hc[CL::kB4];           // (pre-activations: the strict range report below looks at THESE)
       const float sdf = tanh_out(pre);

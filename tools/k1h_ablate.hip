@@ -28,10 +28,13 @@ using namespace asdf;
 #ifndef GROUPS
 #define GROUPS 1        // 2 = two point groups per wave (one-plane kernel only)
 #endif
+#ifndef WIDE
+#define WIDE 0          // 1 = the W form (16x16x32 MFMAs; timing only here: it is fed the 32x32x16 image - the same values in another order)
+#endif
 constexpr int kLds = PLANES == 1 ? kLdsBytesF16P1 : kLdsBytesF16;
 __device__ unsigned long long g_ticks[2];
 #define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { \
-    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES, GROUPS>(p); \
+    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES, GROUPS, false, WIDE != 0>(p); \
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
@@ -74,7 +77,8 @@ int main(int argc, char** argv) {
     if (!f || fread(h.data(), 2, h.size(), f) != h.size() || fread(c.data(), 4, c.size(), f) != c.size()) { printf("cannot read %s\n", data); return 1; }
     fclose(f);
   }
-  (void)hipMalloc(&stream, h.size() * 2); (void)hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMalloc(&stream, h.size() * 4); (void)hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(reinterpret_cast<char*>(stream) + h.size() * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice);      // (where the W form looks for its image)
   (void)hipMalloc(&cst, c.size() * 4); (void)hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice);
   (void)hipMalloc(&o0, P * 4); (void)hipMalloc(&o1, P * 4);
   int* bbox; (void)hipMalloc(&bbox, 64); (void)hipMemset(bbox, 0, 64);
