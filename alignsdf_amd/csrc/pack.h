@@ -121,17 +121,19 @@ inline bool pack_decoder_f16(const asdf_decoder_spec_t& spec, const asdf_head_pa
     pack(kTilesHidden, 2, sw2, [&](int row, int feat) { return feat < n1 ? W2[(size_t)row * kHidden + feat] : 0.0f; });
     pack(kTilesHidden, 4, sw3, [&](int row, int feat) { return W3[(size_t)row * kHidden + feat]; });
     // The W form's image (sdf_mlp_f16_kernel.h, "the W form"): the same planes, the same record count and stage structure, but a
-    // record i of a tile is (K32-block i >> 1, feature half i & 1) as the A operand of v_mfma_f32_16x16x32_f16 - lane l: row
-    // 32 t + 16 (i & 1) + (l & 15), slot (q = l >> 4, e) = input feature 32 (i >> 1) + 16 (e >> 2) + 4 q + (e & 3), the feature
-    // the producing layer's epilogue leaves in that slot of the B operand.
+    // record i of a tile is (feature half fh, K32-block j) = (i / 16, i % 16) in layers 1 and 3, (i % 2, i / 2) in layer 2, as the A operand of
+    // v_mfma_f32_16x16x32_f16 - lane l: row 32 t + 16 fh + (l & 15), slot (q = l >> 4, e) = input feature 32 j + 16 (e >> 2) + 4 q
+    // + (e & 3), the feature the producing layer's epilogue leaves in that slot of the B operand.
     uint16_t* wp = &hp.stream16w[(size_t)h * kStagesHead * kStageFloats * 2];
     auto pack_w = [&](int ntiles, int records_per_tile, float sw, auto weight_at) {
       for (int t = 0; t < ntiles; ++t)
         for (int i = 0; i < records_per_tile; ++i) {
           for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < 8; ++e) {
-              const int row = 32 * t + 16 * (i & 1) + (lane & 15);
-              const int feat = 32 * (i >> 1) + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+              // (feature half outer for the 32-record tiles of layers 1 and 3, K32-block outer for layer 2's 16)
+              const int fh = records_per_tile == 32 ? i / 16 : (i & 1), j = records_per_tile == 32 ? i % 16 : (i >> 1);
+              const int row = 32 * t + 16 * fh + (lane & 15);
+              const int feat = 32 * j + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
               const float w = weight_at(row, feat) * sw;
               const float hi = f16_round(w);
               wp[(0 * 64 + lane) * 8 + e] = f16_bits(hi);

@@ -51,10 +51,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // stays ONE f32x16 = four 16x16 tiles, register 8 g + 4 fh + r <-> (feature 32 T + 16 fh + 4 (l >> 4) + r, point 16 g + (l & 15)).
 // split_part's access pattern (acc[e], acc[8 + e] -> element e of two operands) then needs NO change: element e = 4 fh + r of
 // xh[2 T + g] = the B operand of K32-block T of the next layer for group g, whose slot (q, e) holds feature 32 T + 16 (e >> 2) + 4 q
-// + (e & 3).  A record of the stream (2 KiB, [plane][lane][8 halves]) = (tile, K32-block j, feature half fh), in the order
-// (j, fh) = (0, 0) (0, 1) (1, 0) ...: record i of a tile reads the B operands xh / xl[(i & ~1) + g] and feeds accumulator registers
-// 8 g + 4 (i & 1) .. + 3 with six 16-clock MFMAs (three per group, the groups alternating) - the same 96 matrix-pipe clocks, the same
-// LDS and L2 -> LDS traffic, the same stage structure as the 32x32x16 form.  The point-feature products of layers 0 / 2 run on
+// + (e & 3).  A record of the stream (2 KiB, [plane][lane][8 halves]) = (tile, feature half fh, K32-block j), feature half OUTER in
+// layers 1 and 3 (32 records per tile: fh = i / 16, j = i % 16) and K32-block outer in layer 2 (16 records: j = i / 2, fh = i % 2 - the
+// deferred epilogue of layer 1's last tile finishes the last K32-block's operands only in K-block 8 of layer 2's first tile); record i reads the B operands xh / xl[2 j + g] and feeds accumulator
+// registers 8 g + 4 fh .. + 3 with six 16-clock MFMAs - three per group back to back (W_hi x_lo, W_lo x_hi, W_hi x_hi), the groups in
+// snake order from record to record, so that five of six MFMAs continue the accumulator of the MFMA in front of them.  The same 96
+// matrix-pipe clocks, the same LDS and L2 -> LDS traffic, the same stage structure as the 32x32x16 form.  The point-feature products of layers 0 / 2 run on
 // v_mfma_f32_16x16x4_f32 (K = 4 = x, y, z, pad in ONE instruction per feature half and group).  Biases, w4 and the point fragments
 // are read from the SAME constants image (another gather of the same words); only the weight stream has its own image
 // (pack.h: pack_decoder_f16w).
@@ -199,7 +201,10 @@ constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
 #define ASDF16_DMA_PER_KB 1      // split-half kernel: ONE LDS-DMA piece per K-block (behind its last MFMA) over K-blocks BARRIER_KB .. + 7, not three per K-block
 #endif
 #ifndef ASDF16_W_ORDER
-#define ASDF16_W_ORDER 0         // W form: order of a record's six MFMAs (0 = product-sum outer, point group inner: the shipped one)
+#define ASDF16_W_ORDER 3         // W form: order of a tile's records and of a record's six MFMAs.  3 (shipped): feature half outer, the
+                                 // groups' three MFMAs back to back, snake order of the groups; 0 / 1 / 2: (K32-block, feature half) records with
+                                 // product sum outer + group inner / group outer / A-operand reuse - timing experiments against the image of
+                                 // order 3 (wrong results), profiles/r06_k1h_shape_ab.txt
 #endif
 #ifndef ASDF16_FAST_TANH
 #define ASDF16_FAST_TANH 1       // tanh as 1 - 2 / (1 + exp(2 x)) on the hardware exp / rcp (absolute error ~1e-7; the values carry ~1e-4)
@@ -441,9 +446,32 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
       if (W) {
         // W form: record kb = feature half kb & 1 of K32-block (base + kb) >> 1; (W_hi, x_lo), (W_lo, x_hi), (W_hi, x_hi) for the two
         // point groups in turn - every MFMA has an independent one between itself and the next on its accumulator
+#if ASDF16_W_ORDER == 3
+        // feature-half OUTER over the tile's records, the groups' three MFMAs back to back, the groups in snake order from record to
+        // record: record i = (fh = i / (KB / 2), K32-block i % (KB / 2)); every MFMA but one per record continues the accumulator of
+        // the MFMA right in front of it (the matrix pipe forwards it: no accumulator read), which the part rewards with a higher
+        // clock - measured against product-sum-outer / group-inner: 71.9 against 73.8 ms per N = 256 sweep, same box
+        // (Layer 2 - 16 records per tile - keeps K32-block outer: the epilogue of layer 1's LAST tile rides in K-blocks 1 .. 8 of layer
+        // 2's first tile and finishes the operands of the last K32-block there; feature half outer would read them at record 7.)
+        const int ri = base + kb;
+        const int xb = KB == 32 ? 2 * (ri % 16) : (ri & ~1), o = (KB == 32 ? ri / 16 : (ri & 1)) * 4;
+        f32x4 s0 = acc_get4(acc, o), s1 = acc_get4(acc, 8 + o);
+        {
+          const bool snake = ri & 1;
+          f32x4& sa = snake ? s1 : s0; f32x4& sb = snake ? s0 : s1;
+          const int xa = xb + (snake ? 1 : 0), xc = xb + (snake ? 0 : 1);
+          if (j == 0) { sa = ASDF_MFMA16W(bufh[kb], xl[xa], sa); sa = ASDF_MFMA16W(bufl[kb], xh[xa], sa); }
+          // (the SAME order of the three products for both groups and every record: a voxel's bits must not depend on the lane it
+          // happens to sit in - the voxel lists of the subset form place it anywhere)
+          if (j == 1) { sa = ASDF_MFMA16W(bufh[kb], xh[xa], sa); sb = ASDF_MFMA16W(bufh[kb], xl[xc], sb); }
+          if (j == 2) { sb = ASDF_MFMA16W(bufl[kb], xh[xc], sb); sb = ASDF_MFMA16W(bufh[kb], xh[xc], sb); }
+        }
+#else
         const int xb = (base + kb) & ~1, o = (kb & 1) * 4;
         f32x4 s0 = acc_get4(acc, o), s1 = acc_get4(acc, 8 + o);
-#if ASDF16_W_ORDER == 0
+#endif
+#if ASDF16_W_ORDER == 3
+#elif ASDF16_W_ORDER == 0
         const h8& af = j == 1 ? bufl[kb] : bufh[kb];
         s0 = ASDF_MFMA16W(af, j == 0 ? xl[xb] : xh[xb], s0);
         s1 = ASDF_MFMA16W(af, j == 0 ? xl[xb + 1] : xh[xb + 1], s1);
