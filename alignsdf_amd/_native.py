@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 127        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 128        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -30,7 +30,7 @@ EXPORTS = (
     "asdf_mesh_cc_workspace_bytes", "asdf_mesh_largest_component", "asdf_decoder_status", "asdf_debug_grid_coords", "asdf_decoder_set_refine", "asdf_decoder_time_next_sweep", "asdf_decoder_set_act_scales", "asdf_decoder_get_act_scales", "asdf_mc_count_enqueue", "asdf_mc_result_status", "asdf_decoder_set_audit", "asdf_decoder_set_short_list", "asdf_decoder_set_cluster_list", "asdf_decoder_one_plane_usable", "asdf_icp_set_search", "asdf_icp_ts_enqueue_range",
     "asdf_zoom_cube", "asdf_decode_grid_band_dev", "asdf_decode_grid_dev", "asdf_mc_emit_bounded",
     "asdf_sample_surface_workspace_bytes", "asdf_sample_surface", "asdf_icp_normalise",
-    "asdf_decoder_set_sample_host", "asdf_decoder_set_cluster_timeout",
+    "asdf_decoder_set_sample_host", "asdf_decoder_set_cluster_timeout", "asdf_set_mfma_shape", "asdf_get_mfma_shape",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -88,6 +88,10 @@ def lib():
     L.asdf_decoder_set_sample.argtypes = [vp, vp, vp, vp]
     L.asdf_decoder_set_sample_host.argtypes = [vp, vp, vp, vp]
     L.asdf_decoder_set_cluster_timeout.argtypes = [vp, ctypes.c_uint64]
+    L.asdf_set_mfma_shape.argtypes = [ctypes.c_int]
+    L.asdf_set_mfma_shape.restype = ctypes.c_int
+    L.asdf_get_mfma_shape.argtypes = []
+    L.asdf_get_mfma_shape.restype = ctypes.c_int
     L.asdf_decode_grid.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, vp, vp, vp, vp]
     L.asdf_decode_grid_box.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]
     L.asdf_decode_grid_band.argtypes = [vp, i32, ctypes.POINTER(f32), f32, i32, f32, vp, vp, vp, vp]

@@ -789,7 +789,13 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 127; }
+int asdf_version(void) { return 128; }
+
+int asdf_set_mfma_shape(int shape) {
+  if (shape != 0 && shape != 16 && shape != 32) return ASDF_EINVAL;
+  return k1h_set_shape(shape);
+}
+int asdf_get_mfma_shape(void) { return k1h_shape(); }
 
 const char* asdf_strerror(int code) {
   switch (code) {

@@ -42,7 +42,8 @@ void k1h_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream
 hipError_t k1hw_prepare();
 void k1hw_launch(const DecodeParams& p, int grid, hipStream_t st);
 void k1hw_subset_launch(const DecodeParams& p, int grid, hipStream_t st);
-int k1h_shape();      // 16 = the W form is selected (default), 32 = ASDF_K1H_SHAPE=32
+int k1h_shape();      // 16 = the W form is selected (default), 32 = ASDF_K1H_SHAPE=32 / asdf_set_mfma_shape(32)
+int k1h_set_shape(int shape);
 void k1h_box_launch(bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // one-plane kernel (k1s_kernels.hip), kp == 2 only; p.stream = high planes
 void k1h_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);   // split-half kernel over a voxel list
 void k1h_nerf_subset_launch(int kp, bool two_out, const DecodeParams& p, int grid, hipStream_t st);      // ... kp 5 / 8 (k1h_nerf_kernels.hip)

@@ -18,14 +18,20 @@ __global__ __launch_bounds__(256, 1) void sdf_mlp_f16_subset_combined_kernel(con
 // ASDF_K1H_SHAPE=32 selects the 32x32x16 kernels (A/B runs; the CombinedDecoder and NeRF forms are 32x32x16 only).
 // (the kernels live in k1hw_kernels.hip: their own translation unit, their own compiler flags)
 
-static bool k1h_wide() {
-  static const bool wide = [] {
+static int g_k1h_shape = 0;      // 0 = not decided yet (the environment decides at the first question), 16, 32
+int k1h_shape() {
+  if (g_k1h_shape == 0) {
     const char* e = getenv("ASDF_K1H_SHAPE");
-    return !(e && e[0] == '3' && e[1] == '2');
-  }();
-  return wide;
+    g_k1h_shape = (e && e[0] == '3' && e[1] == '2') ? 32 : 16;
+  }
+  return g_k1h_shape;
 }
-int k1h_shape() { return k1h_wide() ? 16 : 32; }
+int k1h_set_shape(int shape) {      // 16 / 32; 0 = back to the environment's choice; returns the shape in force before the call
+  const int before = k1h_shape();
+  if (shape == 16 || shape == 32 || shape == 0) g_k1h_shape = shape;
+  return before;
+}
+static bool k1h_wide() { return k1h_shape() == 16; }
 
 hipError_t k1h_prepare() {
   hipError_t e = k1h_nerf_prepare();

@@ -2,13 +2,13 @@
 // default arithmetic of every grid sweep of a decoder with affine point features.  Their own translation unit: their own compiler flags
 // (alignsdf_amd/build_native.py).
 #include "k1_launch.h"
-#include "sdf_mlp_f16_kernel.h"
+#include "sdf_mlp_f16w_kernel.h"
 
 namespace asdf {
 
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16w_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 2, 1, false, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16w_kernel(const DecodeParams p) { sdf_mlp_f16w_body<0, false>(p); }
 // ... over a voxel list (the exact values of the narrow-band fine sweep, the audit picks)
-__global__ __launch_bounds__(256, 1) void sdf_mlp_f16w_subset_kernel(const DecodeParams p) { sdf_mlp_f16_body<false, 0, 2, 2, 1, true, true>(p); }
+__global__ __launch_bounds__(256, 1) void sdf_mlp_f16w_subset_kernel(const DecodeParams p) { sdf_mlp_f16w_body<0, true>(p); }
 
 hipError_t k1hw_prepare() {
   hipError_t e = hipSuccess;

@@ -1,339 +1,85 @@
-// K1h: the fused SDF decoder with split-half arithmetic - the structure of sdf_mlp_kernel.h (register-resident
-// activations, head-outer / tile-inner loop, 16 KiB weight stages through a 4-slot LDS-DMA ring, deferred epilogues),
-// but the three hidden GEMMs run on v_mfma_f32_32x32x16_f16 instead of v_mfma_f32_32x32x2_f32:
-//
-//   every operand x is carried as two fp16 planes of x * S (S a power of two):  hi = fp16(x S),  lo = fp16(x S - hi),
-//   i.e. 22 significand bits, and a product sum is three MFMAs into ONE fp32 accumulator:
-//       acc += W_hi . x_lo + W_lo . x_hi + W_hi . x_hi          (the lo.lo term is < 2^-22 of the product)
-//   fp16 x fp16 products are exact in fp32 and the accumulation is fp32, so the result is fp32-class (measured on the
-//   synthetic decoders: max |error| vs fp64 2.8e-7, the same as the fp32 MFMA chain) at 3/16 of the MFMA time of the
-//   fp32 instruction.  Scales: weights S_w per layer (max |w| S_w in [512, 1024)), activations S_x per MLP and layer,
-//   calibrated by the host from the peak plane values a sweep leaves in the decoder's status record (default 8); biases and
-//   the fp32 point-feature products enter the accumulator pre-multiplied by S_w S_x (pack.h, K0), and the accumulator is
-//   rescaled by an exact power of two when it is split into the next layer's planes (the multipliers travel in the
-//   constants block).  fp16 subnormal inputs are honoured by the MFMA (tools/mfma_f16_probe.hip), so small low planes
-//   degrade gracefully.
-//
-// One body, four forms (template parameters of sdf_mlp_f16_body):
-//   PL = 2            the split-half kernel above - the default arithmetic of every grid sweep;
-//   PL = 2, SUB       the same over a list of lattice voxels (the values of the narrow-band fine sweep);
-//   PL = 1, G = 1 | 2 one fp16 plane per operand, one MFMA per product sum, one or two 32-point groups per wave: the sweeps whose
-//                     values are consumed through signs only (asdf_decode_grid_box / _band);
-//   KP = 5 | 8        NeRF-encoded point features (k1h_nerf_kernels.hip).
-//
-// Operand maps (tools/mfma_f16_probe.hip): A lane l holds A[i = l & 31][k = 8 (l >> 5) + e], B lane l holds
-// B[k = 8 (l >> 5) + e][j = l & 31], e = 0..7 packed in 4 VGPRs; D as the fp32 form.  Registers 8 s .. 8 s + 7 of an
-// output tile are therefore, after the split, the B operand of K-block 2 tile + s of the next layer (the host packs
-// the weight columns in that order).
+// K1h, the W form (round 6): the split-half SeparateDecoder kernel of sdf_mlp_f16_kernel.h with its three hidden GEMMs on
+// v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 - affine point features (KP = 2), two fp16 planes, one group of 32
+// points per wave, full lattice or voxel list.  Its OWN copy of the stage and of the body: the 32-wide forms sit at the 512-register
+// limit, and the same W paths as a template parameter of their body - every one of them `if constexpr` - still cost the
+// CombinedDecoder form 60 B and the subset form 20 B of scratch.  Everything that is not the matrix instruction (plane split,
+// LDS-DMA ring, constants image, range guard, box fold, status record) is sdf_mlp_f16_kernel.h's and is used from there; the
+// dead branches of the other forms (PL = 1, G = 2, TWO_OUT, NeRF features) are still spelled out in the copy - PL, G, KP, TWO_OUT are
+// constants here - so that the two bodies can be compared line by line.
 #pragma once
-#include <type_traits>
-
-#include "sdf_mlp_kernel.h"
+#include "sdf_mlp_f16_kernel.h"
 
 namespace asdf {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-#define ASDF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-// relu(a0, a1) * mul -> one packed fp16 register (word `w` of an h8), as explicit 2-vectors: one v_pk_mul_f32 and one
-// v_cvt_pk_f16_f32 per pair (left to the SLP vectoriser the pairs came out shifted by one element, with a v_alignbit /
-// v_pack per register on top)
-// (The one-plane kernels' own image - decoder.hip: rebuild_one_plane - is scaled so that an accumulator carries its activation's
-// plane scale: no multiply, and no running maximum either: ASDF16_P1_FOLD.)
-#ifndef ASDF16_P1_FOLD
-#define ASDF16_P1_FOLD 1
-#endif
-// The ReLU of the folded image must PRESERVE a poisoned value.  The matrix pipe's inf - inf is a NEGATIVE NaN (0xffc00000,
-// tools/trapsts_probe.hip), and an integer maximum against 0 - the cheapest ReLU - turns it (and a -inf) into a perfectly finite 0:
-// measured, a layer-2 overflow of 512 x the fp16 range reached the output as a finite value.  So: convert first, then
-//     2 relu(c) = c + |c|        (v_and_b32 0x7fff7fff + v_pk_add_f16)
-// exact for finite halves (0 for negative ones, 2 c otherwise), and NaN + NaN = NaN, -inf + inf = NaN, inf + inf = inf: whatever left
-// the fp16 range stays non-finite through every layer, reaches the output as a NaN or exactly +-1, and is reported there.  The factor
-// 2 lives in the image's scales (decoder.hip: rebuild_one_plane carries S_x / 2 in the accumulators).  Three VALU instructions per
-// register pair (round 3: five, with a running maximum that the 512-register budget has no room for: +39 % time when it spills).
-__device__ __forceinline__ void relu_mul_pack(float a0, float a1, float mul, h8& dst, int w, float& amax) {
-#if ASDF16_P1_FOLD
-  f32x2 raw;
-  raw[0] = a0; raw[1] = a1;
-  const h2 c = __builtin_convertvector(raw, h2);
-  const h2 m = __builtin_bit_cast(h2, __builtin_bit_cast(unsigned, c) & 0x7fff7fffu);
-  const h2 r2 = c + m;
-  u32x4 d0 = __builtin_bit_cast(u32x4, dst);
-  d0[w] = __builtin_bit_cast(unsigned, r2);
-  dst = __builtin_bit_cast(h8, d0);
-  return;
-#endif
-  f32x2 t;
-  t[0] = __int_as_float(max(__float_as_int(a0), 0));
-  t[1] = __int_as_float(max(__float_as_int(a1), 0));
-#if !ASDF16_P1_FOLD
-  t = t * mul;
-#ifndef ASDF16_NO_RANGE_CHECK
-  amax = fmaxf(amax, fmaxf(t[0], t[1]));
-  asm volatile("" : "+v"(amax));
-#endif
-#endif
-  const h2 r = __builtin_convertvector(t, h2);
-  u32x4 d = __builtin_bit_cast(u32x4, dst);
-  d[w] = __builtin_bit_cast(unsigned, r);
-  dst = __builtin_bit_cast(h8, d);
+// ---- round 6: the W form (template parameter W of the body) - the same GEMMs on v_mfma_f32_16x16x32_f16 ----------------------------
+// Under real operands the part is power-managed and a launch takes the time its ENERGY takes (profiles/r06_k1h_front_ab.txt), and the
+// bare instruction streams differ: on K1h's operand pattern and split-half data the matrix pipe SUSTAINS 2.04-2.08 PFLOP/s with
+// 16x16x32 where it sustains 1.80-1.82 with 32x32x16 (tools/mfma_f16_energy_bench.hip, profiles/r06_mfma_shape_energy.txt).
+// Operand maps: A lane l holds A[i = l & 15][k-slot (l >> 4, e)], B lane l holds B[k-slot (l >> 4, e)][j = l & 15], e = 0..7 (the
+// SAME slot in both, so which k the hardware gives a slot never matters: the host packs the weight of the input feature that sits in
+// that slot of B); D lane l, register r holds D[row = 4 (l >> 4) + r][col = l & 15].
+// A wave's 32 points are two GROUPS of 16 (g = 0, 1); an output tile stays 32 features = two HALVES of 16 (fh = 0, 1); its accumulator
+// stays ONE f32x16 = four 16x16 tiles, register 8 g + 4 fh + r <-> (feature 32 T + 16 fh + 4 (l >> 4) + r, point 16 g + (l & 15)).
+// split_part's access pattern (acc[e], acc[8 + e] -> element e of two operands) then needs NO change: element e = 4 fh + r of
+// xh[2 T + g] = the B operand of K32-block T of the next layer for group g, whose slot (q, e) holds feature 32 T + 16 (e >> 2) + 4 q
+// + (e & 3).  A record of the stream (2 KiB, [plane][lane][8 halves]) = (tile, feature half fh, K32-block j), feature half OUTER in
+// layers 1 and 3 (32 records per tile: fh = i / 16, j = i % 16) and K32-block outer in layer 2 (16 records: j = i / 2, fh = i % 2 - the
+// deferred epilogue of layer 1's last tile finishes the last K32-block's operands only in K-block 8 of layer 2's first tile); record i reads the B operands xh / xl[2 j + g] and feeds accumulator
+// registers 8 g + 4 fh .. + 3 with six 16-clock MFMAs - three per group back to back (W_hi x_lo, W_lo x_hi, W_hi x_hi), the groups in
+// snake order from record to record, so that five of six MFMAs continue the accumulator of the MFMA in front of them.  The same 96
+// matrix-pipe clocks, the same LDS and L2 -> LDS traffic, the same stage structure as the 32x32x16 form.  The point-feature products of layers 0 / 2 run on
+// v_mfma_f32_16x16x4_f32 (K = 4 = x, y, z, pad in ONE instruction per feature half and group).  Biases, w4 and the point fragments
+// are read from the SAME constants image (another gather of the same words); only the weight stream has its own image
+// (pack.h: pack_decoder_f16w).
+#define ASDF_MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define ASDF_MFMA4W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 acc_get4(const f32x16& a, int o) {
+  f32x4 v;
+  v[0] = a[o]; v[1] = a[o + 1]; v[2] = a[o + 2]; v[3] = a[o + 3];
+  return v;
+}
+__device__ __forceinline__ void acc_set4(f32x16& a, int o, const f32x4& v) { a[o] = v[0]; a[o + 1] = v[1]; a[o + 2] = v[2]; a[o + 3] = v[3]; }
+// a tile's 32 bias-like words ([lane half][16 registers] of the 32x32 D layout) gathered for the W form's accumulator: feature
+// 16 fh + 4 q + r of the tile sits in register 4 (2 fh + (q >> 1)) + r of lane half q & 1
+__device__ __forceinline__ f32x16 load_bias16w(const float* tile_words, int lane) {
+  const int q = lane >> 4;
+  // FOUR reads, one per accumulator quad (the two groups start from the same words): a read lands in the quad it is for, where two
+  // reads + copies cost 16 v_accvgpr_write per tile.  (The second pointer is opaque so that the reads are not merged.)
+  const float* w0 = tile_words + (q & 1) * 16 + 4 * (q >> 1);
+  int dup = 0;
+  asm volatile("" : "+v"(dup));      // (an opaque ZERO, not an opaque pointer: the address stays an LDS address)
+  const float* w1 = w0 + dup;
+  f32x16 r;
+  acc_set4(r, 0, *reinterpret_cast<const f32x4*>(w0)); acc_set4(r, 4, *reinterpret_cast<const f32x4*>(w0 + 8));
+  acc_set4(r, 8, *reinterpret_cast<const f32x4*>(w1)); acc_set4(r, 12, *reinterpret_cast<const f32x4*>(w1 + 8));
+  return r;
 }
 
-// wave64 maximum of a signed int on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, row_bcast:15 / :31 across them);
-// the result as a wave-uniform value (lane 63 holds it)
-__device__ __forceinline__ int wave_max_i32(int v) {
-#define ASDF16_DPP_MAX(ctrl, rows) v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, (ctrl), (rows), 0xf, false))
-  ASDF16_DPP_MAX(0x111, 0xf); ASDF16_DPP_MAX(0x112, 0xf); ASDF16_DPP_MAX(0x114, 0xf); ASDF16_DPP_MAX(0x118, 0xf);
-  ASDF16_DPP_MAX(0x142, 0xa); ASDF16_DPP_MAX(0x143, 0xc);
-#undef ASDF16_DPP_MAX
-  return __builtin_amdgcn_readlane(v, 63);
-}
 
-constexpr float kActScaleDev = 8.0f;   // S_x (pack.h: kActScale)
-
-// schedule knobs (tools/k1h_ablate.hip sweeps them; the values here are the shipped ones)
-#ifndef ASDF16_STAGE_KB
-#define ASDF16_STAGE_KB 16       // K-blocks per stage: 16 = 32 KiB stages (one barrier per 48 MFMAs), 8 = 16 KiB stages
-#endif
-#ifndef ASDF16_SCHED_KB
-#define ASDF16_SCHED_KB 1        // a scheduling fence every this many K-blocks bounds how far A-fragment reads are hoisted
-#endif
-#ifndef ASDF16_PREFETCH
-#define ASDF16_PREFETCH 1        // A fragments are read from LDS this many K-blocks ahead of their MFMAs
-#endif
-#ifndef ASDF16_BARRIER_KB
-#define ASDF16_BARRIER_KB (ASDF16_STAGE_KB / 2)      // K-block in front of which the stage's wait + barrier sit
-#endif
-#ifndef ASDF16_BARRIER_KB_P1
-#define ASDF16_BARRIER_KB_P1 12      // ... of the one-plane kernel (16 KiB stages: the wait then covers pieces issued 2.75 stages ago)
-#endif
-#ifndef ASDF16_PRE_KB_P1
-#define ASDF16_PRE_KB_P1 (ASDF16_STAGE_KB / 2 + 2)      // ... and the K-block of its last stage that carries the next tile's preloads
-#endif
-#ifndef ASDF16_MFMA_ORDER
-#define ASDF16_MFMA_ORDER 0      // order of the three MFMAs of a K-block (an energy experiment: see the tuning log)
-#endif
-#ifndef ASDF16_LOADS_FIRST
-#define ASDF16_LOADS_FIRST 1     // a scheduling fence BEHIND the LDS reads of a K-block: they issue ahead of its MFMAs (the
-#endif                           // compiler otherwise sinks them to one MFMA in front of their first use)
-#ifndef ASDF16_PRELOAD
-#define ASDF16_PRELOAD 1         // biases / point fragments / w4 of the NEXT tile are read half a tile ahead
-#endif
-#ifndef ASDF16_PIN_ACC
-#define ASDF16_PIN_ACC 1         // deferred epilogues read the finished accumulator part by part (no up-front copy)
-#endif
-#ifndef ASDF16_L0_PIPE
-#define ASDF16_L0_PIPE 1         // one-plane kernel: layer 0 software-pipelined over all 16 tiles in front of layer 1
-#endif
-#ifndef ASDF16_PRE_KB
-#define ASDF16_PRE_KB (ASDF16_STAGE_KB / 2 + 2)      // K-block of a tile's last stage whose region carries the next tile's preloads
-#endif
-// one-plane kernel (PL = 1) only - its K-blocks are 32 / 64 matrix-pipe cycles, not 96, so what hides behind a K-block of the
-// split-half kernel does not hide here:
-#ifndef ASDF16_P1_FP16PT
-#define ASDF16_P1_FP16PT 1       // point features and bias rows of layers 0 / 2 on ONE fp16 MFMA per tile (sdf_layout.h: kA16Floats)
-#endif
-#ifndef ASDF16_W4_TILE
-#define ASDF16_W4_TILE 1         // the 16 last-layer weights of a tile's deferred epilogue read at once, half a tile ahead (not pair by pair one K-block ahead)
-#endif
-#ifndef ASDF16_PF_G2
-#define ASDF16_PF_G2 2           // A-fragment prefetch distance (K-blocks of 64 cycles) of the two-group kernel
-#endif
-#ifndef ASDF16_FOLD_BALLOT
-#define ASDF16_FOLD_BALLOT 1     // the negative-voxel fold of a tile is skipped when no lane of the wave has anything to fold
-#endif
-#ifndef ASDF16_MIX_SPLIT
-#define ASDF16_MIX_SPLIT 1       // split-half kernel: the plane split on v_fma_mix{lo,hi}_f16 (9 instead of 17 VALU instructions per epilogue part)
-#endif
-#ifndef ASDF16_EPI_STEPS
-#define ASDF16_EPI_STEPS 1       // split-half kernel: a deferred epilogue part is issued in three pieces, one behind each MFMA of its K-block
-#endif
-#ifndef ASDF16_DMA_PER_KB
-#define ASDF16_DMA_PER_KB 1      // split-half kernel: ONE LDS-DMA piece per K-block (behind its last MFMA) over K-blocks BARRIER_KB .. + 7, not three per K-block
-#endif
-#ifndef ASDF16_FAST_TANH
-#define ASDF16_FAST_TANH 1       // tanh as 1 - 2 / (1 + exp(2 x)) on the hardware exp / rcp (absolute error ~1e-7; the values carry ~1e-4)
+#ifndef ASDF16_W_ORDER
+#define ASDF16_W_ORDER 3         // W form: order of a tile's records and of a record's six MFMAs.  3 (shipped): feature half outer, the
+                                 // groups' three MFMAs back to back, snake order of the groups; 0 / 1 / 2: (K32-block, feature half) records with
+                                 // product sum outer + group inner / group outer / A-operand reuse - timing experiments against the image of
+                                 // order 3 (wrong results), profiles/r06_k1h_shape_ab.txt
 #endif
 
-// The split-half stream of a head is a flat sequence of (tile, K-block) records of 2 KiB ([plane hi / lo][lane][8 halves]),
-// 1024 of them; a stage is ASDF16_STAGE_KB consecutive records of one tile, so the stage size is the kernel's choice.
-//
-// PL = number of fp16 planes per operand.  2 is the split-half arithmetic above.  1 keeps only the high plane - plain fp16
-// operands, ONE MFMA per product sum, fp16-class results (errors of a few 1e-4 on the synthetic decoders): the kernel of
-// the box-only coarse sweep (asdf_decode_grid_box), whose output is consumed only through the bounding box of its
-// negative voxels and is re-evaluated exactly wherever that box could depend on the error.  Its weight stream is the
-// high planes alone (1 KiB records), so a 16-K-block stage is 16 KiB.
-constexpr int kS16Kb = ASDF16_STAGE_KB;
-constexpr int kS16Head = 1024 / kS16Kb;              // stages per head
-// G = point groups per wave (one-plane kernel only): with G = 2 a wave carries 64 points as two groups of 32 whose
-// activations occupy the registers of the two planes of the split-half kernel; every A fragment read from LDS then feeds two
-// MFMAs (one per group).  The one-plane kernel with one group is LDS-bandwidth-bound: four waves reading 1 KiB of A
-// fragments per 32-cycle MFMA are exactly the 128 B / clk of the LDS, before the LDS-DMA writes.
-template <int PL, int G = 1>
-struct S16 {
-  static constexpr int kFloats = kS16Kb * 256 * PL;        // floats per stage
-  static constexpr int kPieces = kS16Kb * PL / 4;          // 1 KiB LDS-DMA pieces per wave per stage
-  static constexpr int kWaveFloats = kFloats / kWaves;     // a wave's share of a stage
-  static constexpr int kRingFloats = kRing * kFloats;
-  static constexpr int kMfmas = PL == 2 ? 3 : G;           // MFMAs per K-block
-  // A fragments are read from LDS this many K-blocks ahead of their MFMAs: the read latency (~100 cycles) has to fit in the
-  // MFMA time of that distance - one K-block of three MFMAs (96 cycles), or three K-blocks of one
-  static constexpr int kPrefetch = PL == 2 ? ASDF16_PREFETCH : (G == 2 ? ASDF16_PF_G2 : 3) * ASDF16_PREFETCH;
-  static_assert(PL == 2 ? G == 1 : (G == 1 || G == 2), "point groups");
-  static_assert(kPieces == 4 || kPieces == 8, "stage size");
-};
-constexpr int kS16Floats = S16<2>::kFloats;
-constexpr int kS16Pieces = S16<2>::kPieces;
-constexpr int kS16WaveFloats = S16<2>::kWaveFloats;
-constexpr int kRing16Floats = S16<2>::kRingFloats;
-// LDS: ring + constants + two 8-int negative-voxel records per wave (the register file has no room for per-lane ones)
-constexpr int kWrecInts = 20;    // per wave: two 8-int negative-voxel records + the largest plane value of layers 0..2 (+ pad)
-constexpr bool pt16(int kp, int planes) { return ASDF16_P1_FP16PT && planes == 1 && kp == 2; }
-constexpr int lds_bytes_f16(int kp, int planes = 2) {
-  return (kRing * kS16Kb * 256 * planes + cst_offsets(kp).floats + (pt16(kp, planes) ? kA16Floats : 0)) * 4 + kWaves * kWrecInts * 4;
-}
-constexpr int kLdsBytesF16 = lds_bytes_f16(2);
-constexpr int kLdsBytesF16P1 = lds_bytes_f16(2, 1);
-static_assert(kS16Kb == 8 || kS16Kb == 16, "stage size");
-
-// relu(acc) * mul -> the two fp16 planes of K-blocks (2 t, 2 t + 1) of the next layer, element e (0..7) of each;
-// amax tracks the largest value handed to the fp16 conversion (>= 65520 rounds to infinity: the caller reports it)
-// (g: -1 = everything, 0 / 1 = only the first / second point group's part - the two-group kernel issues them behind different MFMAs)
-template <int PL = 2, int G = 1, bool MIX = false>
-__device__ __forceinline__ void split_part(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
-                                           int e, int g = -1, int step = -1, float* rr = nullptr) {
-  if (PL == 1 && G == 2 && g != 0)         // the second point group: its planes live where the low planes of the split-half kernel do
-    relu_mul_pack(accb[2 * e], accb[2 * e + 1], mul, e < 4 ? lo0 : lo1, e & 3, amax);
-  if (PL == 1 && G == 2 && g == 1) return;
-  if (PL == 1) {
-    // one plane: part e converts the NEIGHBOURING accumulator registers 2 e, 2 e + 1 (both land in one packed fp16 register,
-    // one v_cvt_pk), about 5 VALU instructions - a part has to fit the shadow of the ONE MFMA of its K-block here
-    relu_mul_pack(acc[2 * e], acc[2 * e + 1], mul, e < 4 ? hi0 : hi1, e & 3, amax);
-    return;
-  }
-  if (MIX) {
-  // Round 5: the split on the mixed-precision FMA.  v_fma_mix{lo,hi}_f16 computes an fp32 FMA whose sources are fp32 registers or
-  // fp16 halves, rounds ONCE to fp16 and writes one half of the destination (the other half is preserved), so per element
-  //     hi = f16(r mul)                 lo = f16(r mul - hi)        (r mul is exact: mul is a power of two; r mul - hi is exact in fp32)
-  // are two instructions with no conversion back, no subtraction and no packing - the bits of the form below, which took
-  // v_mul + v_fma_mixlo + v_cvt_f32_f16 + v_sub + 2 x 1/2 v_cvt_pk per element (17 VALU instructions per epilogue part, where the
-  // part's K-block has room for ~12 next to its MFMAs, LDS reads and LDS-DMA piece).  The running maximum is taken on r and scaled
-  // by mul once per tile (max and a positive power of two commute).
-  // `step` (-1 = the whole part) issues the part in three pieces, one behind each MFMA of the part's K-block - [0] the two ReLUs (the
-  // accumulator reads), [1] the high planes and the running maximum, [2] the low planes; rr[2] carries the ReLUs across.  A K-block is
-  // three DEPENDENT MFMAs on one accumulator: an MFMA that finds more than ~5 issue slots between itself and its predecessor misses
-  // the back-to-back window and pays ~43 clocks on top of the slots (MI355X_MICROARCH.md, "one EXTRA issue slot between two MFMAs on
-  // the SAME accumulator"), which is why the instruction count of a part hardly matters while the part sits in ONE gap.
-  {
-    float r0 = rr ? rr[0] : 0.0f, r1 = rr ? rr[1] : 0.0f;
-    if (step <= 0) {
-      r0 = __int_as_float(max(__float_as_int(acc[e]), 0));
-      r1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0));
-      if (rr) { rr[0] = r0; rr[1] = r1; }
-      if (step == 0) return;
-    }
-    u32x4 H0 = __builtin_bit_cast(u32x4, hi0), L0 = __builtin_bit_cast(u32x4, lo0);
-    u32x4 H1 = __builtin_bit_cast(u32x4, hi1), L1 = __builtin_bit_cast(u32x4, lo1);
-    unsigned a = H0[e >> 1], b = L0[e >> 1], c = H1[e >> 1], d = L1[e >> 1];
-    // the two high planes, the running maximum behind them, then the low planes (a half-register write needs two wait states in
-    // front of its first read: the maximum and the sibling's instruction are those two)
-#ifndef ASDF16_NO_RANGE_CHECK
-#define ASDF16_AMAX_LINE "v_max3_f32 %2, %2, %3, %4\n\t"
-#else
-#define ASDF16_AMAX_LINE "s_nop 0\n\t"
-#endif
-    if (step != 2) {
-      if (e & 1)
-        asm("v_fma_mixhi_f16 %0, %3, %5, 0\n\t"
-            "v_fma_mixhi_f16 %1, %4, %5, 0\n\t"
-            ASDF16_AMAX_LINE
-            : "+v"(a), "+v"(c), "+v"(amax) : "v"(r0), "v"(r1), "v"(mul));
-      else        // (the even element defines the register: nothing of the previous tile's value is read)
-        asm("v_fma_mixlo_f16 %0, %3, %5, 0\n\t"
-            "v_fma_mixlo_f16 %1, %4, %5, 0\n\t"
-            ASDF16_AMAX_LINE
-            : "=&v"(a), "=&v"(c), "+v"(amax) : "v"(r0), "v"(r1), "v"(mul));
-      H0[e >> 1] = a; H1[e >> 1] = c;
-      hi0 = __builtin_bit_cast(h8, H0); hi1 = __builtin_bit_cast(h8, H1);
-    }
-    if (step != 1) {
-      if (e & 1)
-        asm("v_fma_mixhi_f16 %0, %2, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %3, %4, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "+v"(b), "+v"(d) : "v"(r0), "v"(r1), "v"(mul), "v"(a), "v"(c));
-      else
-        asm("v_fma_mixlo_f16 %0, %2, %4, -%5 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixlo_f16 %1, %3, %4, -%6 op_sel_hi:[0,0,1]"
-            : "=&v"(b), "=&v"(d) : "v"(r0), "v"(r1), "v"(mul), "v"(a), "v"(c));
-      L0[e >> 1] = b; L1[e >> 1] = d;
-      lo0 = __builtin_bit_cast(h8, L0); lo1 = __builtin_bit_cast(h8, L1);
-    }
-#undef ASDF16_AMAX_LINE
-    return;
-  }
-  }
-  const float t0 = __int_as_float(max(__float_as_int(acc[e]), 0)) * mul;
-  const float t1 = __int_as_float(max(__float_as_int(acc[8 + e]), 0)) * mul;
-#ifndef ASDF16_NO_RANGE_CHECK
-  amax = fmaxf(amax, fmaxf(t0, t1));
-#endif
-  const _Float16 a = (_Float16)t0, b = (_Float16)t1;
-  hi0[e] = a;
-  hi1[e] = b;
-  if (PL == 2) {
-    lo0[e] = (_Float16)(t0 - (float)a);
-    lo1[e] = (_Float16)(t1 - (float)b);
-  }
-#ifndef ASDF16_NO_RANGE_CHECK
-  asm volatile("" : "+v"(amax));      // keep the running maximum where it is computed (see dot_w4's pin in sdf_mlp_kernel.h)
-#endif
-}
-
-template <int PL = 2, int G = 1, bool MIX = false>
-__device__ __forceinline__ void split_tile(const f32x16& acc, const f32x16& accb, float mul, h8& hi0, h8& lo0, h8& hi1, h8& lo1, float& amax,
-                                           int g = -1) {
+// (W form: the accumulator is four independent quads - pinned one by one, or the 512-bit constraint makes the compiler gather them
+// into one aligned tuple through 16 v_accvgpr_read / write pairs per tile)
+template <int PL = 2, bool W = true>
+__device__ __forceinline__ void pin_acc_w(f32x16& acc) {
+  if constexpr (W) {
+    if (ASDF16_PIN_ACC) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split_part<PL, G, MIX>(acc, accb, mul, hi0, lo0, hi1, lo1, amax, e, g);
-}
-
-// a deferred tile epilogue is issued in kEpiChunks parts, one behind the MFMAs of each of the first K-blocks of a stage
-constexpr int kEpiChunks = 8;
-// ... starting at this K-block: the accumulator the epilogue reads was finished by the MFMA right in front of the stage,
-// and an AGPR read within ~3 MFMAs of it waits for the matrix pipe (s_nop + dependency stall)
-#ifndef ASDF16_EPI_SHIFT
-#define ASDF16_EPI_SHIFT (ASDF16_STAGE_KB > 8 ? 1 : 0)
-#endif
-constexpr int kEpiShift = ASDF16_EPI_SHIFT;
-static_assert(kEpiShift + kEpiChunks <= ASDF16_STAGE_KB, "epilogue slots");
-struct NoOp16 {
-  __device__ __forceinline__ void operator()(int, int = -1) const {}
-};
-typedef NoOp16 NoEpilogue16;
-
-// make the compiler treat an accumulator as freshly defined here: element reads behind this statement cannot be hoisted
-// in front of it (instruction selection otherwise copies a whole finished accumulator out of the AGPRs right behind its
-// last MFMA - an s_nop 11 plus the wait for that MFMA at every tile boundary)
-// (One-plane kernel with two point groups: the pin does the opposite there - with it the register allocator copies every finished
-// layer-3 accumulator out of the AGPRs and back in, 64 moves and two s_nop 11 per tile; ASDF16_PIN_ACC_P1 = 0.)
-#ifndef ASDF16_PIN_ACC_P1
-#define ASDF16_PIN_ACC_P1 0
-#endif
-template <int PL = 2>
-__device__ __forceinline__ void pin_acc(f32x16& acc) {
+      for (int o = 0; o < 16; o += 4) {
+        f32x4 q;
+        q[0] = acc[o]; q[1] = acc[o + 1]; q[2] = acc[o + 2]; q[3] = acc[o + 3];
+        asm volatile("" : "+a"(q));
+        acc[o] = q[0]; acc[o + 1] = q[1]; acc[o + 2] = q[2]; acc[o + 3] = q[3];
+      }
+    }
+    return;
+  }
   if (PL == 2 ? ASDF16_PIN_ACC : ASDF16_PIN_ACC_P1) asm volatile("" : "+a"(acc));
-}
-
-// One LDS-DMA piece (1 KiB per wave) of the wave's share of a stage; P is the piece index.
-// (Writing M0 once per four pieces instead of save / set / restore around each: -0.5 %, not worth relying on M0 surviving
-// between asm statements.)
-template <int P>
-__device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
-  lds_dma16_off<(P & 3) * 1024>(src + (P >> 2) * 1024, dst + (P >> 2) * 4096);
 }
 
 
@@ -347,8 +93,8 @@ __device__ __forceinline__ void dma_piece(const float* src, unsigned dst) {
 // s_waitcnt for the rest of the LDS latency - 26 % of the wave cycles in the round-1 kernel (SQ_WAIT_ANY).
 // ABL (timing only, tools/k1h_ablate.hip): 1 = no DMA / wait / barrier, 16 = no barrier,
 // 32 = no DMA instructions (waits and barriers kept; the ring keeps the four stages loaded at the head start).
-template <int KB, int Q, int SLOT, int ABL, int PL, int G, bool STEPS, class Pre, class Epi>
-__device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
+template <int KB, int Q, int SLOT, int ABL, int PL, int G, bool STEPS, bool W, class Pre, class Epi>
+__device__ __forceinline__ void stage16w(f32x16& acc, f32x16& accb, const h8 (&xh)[KB], const h8 (&xl)[KB], const float* ring,
                                         const float* next_src, unsigned lds_ring_base, int lane, int wave,
                                         h8 (&ah)[S16<PL, G>::kPrefetch], h8 (&al)[S16<PL, G>::kPrefetch], Pre&& pre, Epi&& epi) {
   constexpr int PF = S16<PL, G>::kPrefetch;
@@ -379,6 +125,51 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
     constexpr int base = Q * kS16Kb;
 #pragma unroll
     for (int j = 0; j < SG::kMfmas; ++j) {
+      if constexpr (W) {
+        // W form: record kb = feature half kb & 1 of K32-block (base + kb) >> 1; (W_hi, x_lo), (W_lo, x_hi), (W_hi, x_hi) for the two
+        // point groups in turn - every MFMA has an independent one between itself and the next on its accumulator
+#if ASDF16_W_ORDER == 3
+        // feature-half OUTER over the tile's records, the groups' three MFMAs back to back, the groups in snake order from record to
+        // record: record i = (fh = i / (KB / 2), K32-block i % (KB / 2)); every MFMA but one per record continues the accumulator of
+        // the MFMA right in front of it (the matrix pipe forwards it: no accumulator read), which the part rewards with a higher
+        // clock - measured against product-sum-outer / group-inner: 71.9 against 73.8 ms per N = 256 sweep, same box
+        // (Layer 2 - 16 records per tile - keeps K32-block outer: the epilogue of layer 1's LAST tile rides in K-blocks 1 .. 8 of layer
+        // 2's first tile and finishes the operands of the last K32-block there; feature half outer would read them at record 7.)
+        const int ri = base + kb;
+        const int xb = KB == 32 ? 2 * (ri % 16) : (ri & ~1), o = (KB == 32 ? ri / 16 : (ri & 1)) * 4;
+        f32x4 s0 = acc_get4(acc, o), s1 = acc_get4(acc, 8 + o);
+        {
+          const bool snake = ri & 1;
+          f32x4& sa = snake ? s1 : s0; f32x4& sb = snake ? s0 : s1;
+          const int xa = xb + (snake ? 1 : 0), xc = xb + (snake ? 0 : 1);
+          if (j == 0) { sa = ASDF_MFMA16W(bufh[kb], xl[xa], sa); sa = ASDF_MFMA16W(bufl[kb], xh[xa], sa); }
+          // (the SAME order of the three products for both groups and every record: a voxel's bits must not depend on the lane it
+          // happens to sit in - the voxel lists of the subset form place it anywhere)
+          if (j == 1) { sa = ASDF_MFMA16W(bufh[kb], xh[xa], sa); sb = ASDF_MFMA16W(bufh[kb], xl[xc], sb); }
+          if (j == 2) { sb = ASDF_MFMA16W(bufl[kb], xh[xc], sb); sb = ASDF_MFMA16W(bufh[kb], xh[xc], sb); }
+        }
+#else
+        const int xb = (base + kb) & ~1, o = (kb & 1) * 4;
+        f32x4 s0 = acc_get4(acc, o), s1 = acc_get4(acc, 8 + o);
+#endif
+#if ASDF16_W_ORDER == 3
+#elif ASDF16_W_ORDER == 0
+        const h8& af = j == 1 ? bufl[kb] : bufh[kb];
+        s0 = ASDF_MFMA16W(af, j == 0 ? xl[xb] : xh[xb], s0);
+        s1 = ASDF_MFMA16W(af, j == 0 ? xl[xb + 1] : xh[xb + 1], s1);
+#elif ASDF16_W_ORDER == 2
+        // (W_hi, x_lo), (W_hi, x_hi), (W_lo, x_hi): four MFMAs in a row on the same A operand (timing experiment)
+        const h8& af = j == 2 ? bufl[kb] : bufh[kb];
+        s0 = ASDF_MFMA16W(af, j == 0 ? xl[xb] : xh[xb], s0);
+        s1 = ASDF_MFMA16W(af, j == 0 ? xl[xb + 1] : xh[xb + 1], s1);
+#else
+        // group-outer (timing experiment): the three MFMAs of a group back to back on its accumulator
+        if (j == 0) { s0 = ASDF_MFMA16W(bufh[kb], xl[xb], s0); s0 = ASDF_MFMA16W(bufl[kb], xh[xb], s0); }
+        if (j == 1) { s0 = ASDF_MFMA16W(bufh[kb], xh[xb], s0); s1 = ASDF_MFMA16W(bufh[kb], xl[xb + 1], s1); }
+        if (j == 2) { s1 = ASDF_MFMA16W(bufl[kb], xh[xb + 1], s1); s1 = ASDF_MFMA16W(bufh[kb], xh[xb + 1], s1); }
+#endif
+        acc_set4(acc, o, s0); acc_set4(acc, 8 + o, s1);
+      } else {
       if (PL == 1 && j == 0) acc = ASDF_MFMA16(bufh[kb], xh[base + kb], acc);
       else if (PL == 1) accb = ASDF_MFMA16(bufh[kb], xl[base + kb], accb);       // the second point group, same A fragment
       else
@@ -392,6 +183,7 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
       // W_lo . x_hi, W_hi . x_hi, W_hi . x_lo
       acc = ASDF_MFMA16(j == 0 ? bufl[kb] : bufh[kb], j == 2 ? xl[base + kb] : xh[base + kb], acc);
 #endif
+      }
       // one DMA piece per MFMA shadow behind the barrier; split-half kernel (round 5): one per K-block, behind its LAST MFMA - the
       // gap that carries the least of a deferred epilogue part
       constexpr bool kDmaPerKb = STEPS && ASDF16_DMA_PER_KB && kS16Kb - BKB >= SG::kPieces;
@@ -434,21 +226,17 @@ __device__ __forceinline__ void stage16(f32x16& acc, f32x16& accb, const h8 (&xh
   for (int i = 0; i < PF; ++i) { ah[i] = bufh[kS16Kb + i]; if (PL == 2) al[i] = bufl[kS16Kb + i]; }
 }
 
-// Timing instrumentation of tools/k1h_ablate.hip (-DASDF16_SEGMENT_TIMES): shader-clock stamps of wave 0 of workgroup 0 at
-// the layer boundaries of its third tile of MLP 0 go to g_seg[] (declared by the tool).  Not compiled into the product.
-#ifdef ASDF16_SEGMENT_TIMES
-#define ASDF16_MARK(k) do { __builtin_amdgcn_sched_barrier(0); seg_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define ASDF16_MARK(k) do { } while (0)
-#endif
 
 // p.stream / p.cst are the split-half images here (pack_decoder_f16).  KP = K-steps of the point features on the fp32
 // MFMA in layers 0 and 2: 2 = affine xyz, 5 / 8 = NeRF encoding of 9 / 15 features (those need 16 KiB stages: their
 // constants block is 40 / 75 KiB).
 // SUB: the kGridSubset form of sdf_mlp_kernel.h - the points are the lattice voxels listed in p.idx (p.count_dev of them, a
 // device word; p.P is the list's capacity), coordinates from the voxel index, outputs scattered in place, no box.
-template <bool TWO_OUT, int ABL = 0, int KP = 2, int PL = 2, int G = 1, bool SUB = false>
-__device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
+template <int ABL = 0, bool SUB = false>
+__device__ __forceinline__ void sdf_mlp_f16w_body(const DecodeParams& p) {
+  constexpr bool TWO_OUT = false, W = true;
+  constexpr int KP = 2, PL = 2, G = 1;
+  static_assert(!W || (PL == 2 && G == 1 && KP == 2 && !TWO_OUT), "W form: split-half, affine point features, SeparateDecoder");
   using CL = CstLayout<KP>;
   using SG = S16<PL, G>;
   static_assert(G == 1 || !TWO_OUT, "two point groups: SeparateDecoder");
@@ -508,7 +296,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int i = tid; i < kA16Floats / 4; i += 256)
         if (i < kA16LayerFloats / 4 || i >= 2 * kA16LayerFloats / 4) reinterpret_cast<f32x4*>(a16s)[i] = src4[i];      // (layer 2's operands are not used: see the tuning log)
     }
-    const float* sbase0 = p.stream + (size_t)head * kS16Head * SG::kFloats;
+    // (W form: its image lies behind the 32x32x16 one in the same allocation)
+    const float* sbase0 = p.stream + (W ? (size_t)kStagesAll * kStageFloats : 0) + (size_t)head * kS16Head * SG::kFloats;
 #pragma unroll
     for (int s = 0; s < ((ABL & 33) ? kRing : kRing - 1); ++s) {
       const float* src = sbase0 + (size_t)s * SG::kFloats + wave * SG::kWaveFloats + lane * 4;
@@ -532,6 +321,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
     // subset mode: list positions from here on are audit picks (see DecodeParams::audit)
     int audit_from = 0x7fffffff;
     if (SUB && p.audit) audit_from = p.audit_from ? *p.audit_from : 0;
+    // a tile's bias row as the accumulator's initial value (W form: gathered for the 16x16 tiles)
+    auto bias_at = [&](int off, int t) -> f32x16 {
+      if constexpr (W) return load_bias16w(hc + off + t * 32, lane);
+      else return load_bias16(hc + off + (t * 2 + half) * 16);
+    };
+    // the fp32 A-fragment word of point-feature step s of tile t (W form: s = the feature half, k = lane >> 4 in ONE K = 4 step)
+    auto pt_word = [&](int off, int t, int s) -> float {
+      if constexpr (W) return hc[off + (t * 2 + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + 16 * s + (lane & 15)];
+      else return hc[off + (t * KP + s) * 64 + lane];
+    };
 
 #pragma unroll 1
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -583,6 +382,31 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #pragma unroll
         for (int s = 0; s < KP; ++s) bp[s] = 2 * s + half < p.pf ? nerf_feature(2 * s + half, x0, x1, x2) : 0.0f;
       }
+      // W form: the point operand of v_mfma_f32_16x16x4_f32 per group - lane l carries component l >> 4 of (x, y, z, 0) of point
+      // 16 g + (l & 15); a lane computed the coordinates of ITS point l & 31, the other group's come from lane l ^ 16
+      float bq[2] = {0.0f, 0.0f};
+      if constexpr (W) {
+        // component q = l >> 4 of point 16 g + (l & 15): the source lane is (l & 15) + 16 g (any lane with that l & 31)
+        const int q = lane >> 4;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int src = (lane & 15) + 16 * g;
+          const float c0 = __shfl(x0, src), c1 = __shfl(x1, src), c2 = __shfl(x2, src);
+          bq[g] = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : 0.0f;
+        }
+      }
+      // point-feature products of one tile into its accumulator: af[s] = pt_word(.., t, s)
+      auto pt_mfma = [&](f32x16& a, const float* af) {
+        if constexpr (W) {
+#pragma unroll
+          for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc_set4(a, 8 * g + 4 * fh, ASDF_MFMA4W(af[fh], bq[g], acc_get4(a, 8 * g + 4 * fh)));
+        } else {
+#pragma unroll
+          for (int s = 0; s < KP; ++s) a = ASDF_MFMA(af[s], bp[s], a);
+        }
+      };
       // one-plane kernels: the points as the fp16 B operand of layers 0 / 2 (sdf_layout.h: kA16Floats) - x T in two planes, T twice
       // (the bias planes' multiplier) on lane half 0; the high planes again on lane half 1 (they meet the weights' low planes)
       auto point_operand = [&](float c0, float c1, float c2, float T) -> h8 {
@@ -633,10 +457,16 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       auto load_pf2 = [&](int t) {
         if (!kPreloadPf) return;
 #pragma unroll
-        for (int s = 0; s < KP; ++s) pf2[s] = hc[CL::kA2 + (t * KP + s) * 64 + lane];
+        for (int s = 0; s < KP; ++s) pf2[s] = pt_word(CL::kA2, t, s);
       };
       auto load_w4 = [&](int t, int c) {        // accumulator registers 2 c, 2 c + 1 of tile t
+        // (W form: register 2 c = group c >> 2, feature half (c >> 1) & 1, r = 2 (c & 1): feature 16 fh + 4 q + r of the tile sits in
+        // register 4 (2 fh + (q >> 1)) + r of lane half q & 1 of the 32x32 D-layout image)
         const float* w4 = hc + CL::kW4 + (t * 2 + half) * 16 + 2 * c;
+        if constexpr (W) {
+          const int wq = lane >> 4;
+          w4 = hc + CL::kW4 + (t * 2 + (wq & 1)) * 16 + 4 * (2 * ((c >> 1) & 1) + (wq >> 1)) + 2 * (c & 1);
+        }
         const float* w4b = hc + CL::kW4b + (t * 2 + half) * 16 + 2 * c;
         w4n[0] = w4[0]; w4n[1] = w4[1];
         if (TWO_OUT) { w4bn[0] = w4b[0]; w4bn[1] = w4b[1]; }
@@ -652,18 +482,21 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       float pf0[2][KP];
       auto l0_load = [&](int t) {
         if (!kPreloadPf) return;
-        acc0[t & 1] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+        acc0[t & 1] = bias_at(CL::kC0, t);
 #pragma unroll
-        for (int s = 0; s < KP; ++s) pf0[t & 1][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
+        for (int s = 0; s < KP; ++s) pf0[t & 1][s] = pt_word(CL::kA0, t, s);
       };
       auto l0_compute = [&](int t, int g = -1) {
-        f32x16 acc = kPreloadPf ? acc0[t & 1] : load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+        f32x16 acc = kPreloadPf ? acc0[t & 1] : bias_at(CL::kC0, t);
         f32x16 accb = acc;
+        if constexpr (W) pt_mfma(acc, pf0[t & 1]);
+        else {
 #pragma unroll
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf0[t & 1][s] : hc[CL::kA0 + (t * KP + s) * 64 + lane];
           if (g != 1) acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2 && g != 0) accb = ASDF_MFMA(af, bpb[s], accb);
+        }
         }
         split_tile<PL, G, kMix>(acc, accb, mul0, h0h[2 * t], h0l[2 * t], h0h[2 * t + 1], h0l[2 * t + 1], amax, g);
       };
@@ -682,8 +515,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         h8 lq[3];
         auto l0p_load = [&](int t) {
           if (kPt16) { lq[t % 3] = a16_frag(0, t); return; }      // bias and point-feature columns in one fp16 operand
-          la[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
-          if (G == 2) lb[t % 3] = load_bias16(hc + CL::kC0 + (t * 2 + half) * 16);
+          la[t % 3] = bias_at(CL::kC0, t);
+          if (G == 2) lb[t % 3] = bias_at(CL::kC0, t);
 #pragma unroll
           for (int s = 0; s < KP; ++s) lf[t % 3][s] = hc[CL::kA0 + (t * KP + s) * 64 + lane];
         };
@@ -701,7 +534,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         };
         l0p_load(0);
         l0p_load(1);
-        acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+        acc1[0] = bias_at(CL::kB1, 0);
         if (G == 2) acc1b[0] = acc1[0];
         __builtin_amdgcn_sched_barrier(0);
         l0p_mfma(0);
@@ -715,7 +548,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         }
       } else {
       l0_load(0);
-      acc1[0] = load_bias16(hc + CL::kB1 + half * 16);
+      acc1[0] = bias_at(CL::kB1, 0);
       if (G == 2) acc1b[0] = acc1[0];
 #pragma unroll
       for (int t = 0; t < kL0Front; ++t) {
@@ -727,7 +560,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       }
 
 #define ASDF_STAGE16(KB, Q, SLOT, ACC, XH, XL, SIDX, PRE, EPI) \
-  stage16<KB, Q, SLOT, ABL, PL, G, kSteps>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
+  stage16w<KB, Q, SLOT, ABL, PL, G, kSteps, W>(ACC, ACC##b, XH, XL, ring, src_of((SIDX) + 3), lds_ring_base, lane, wave, ah, al, PRE, EPI)
 
       ASDF16_MARK(1);
       // (split-half kernel: the second argument of an epilogue callback is the PIECE of the part - stage16 calls it behind each of
@@ -740,7 +573,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesL1; ++t) {
         f32x16& acc = acc1[t & 1];
         f32x16& accb = (G == 2 ? acc1b : acc1)[t & 1];
-        if (!ASDF16_PRELOAD && t > 0) acc = load_bias16(hc + CL::kB1 + (t * 2 + half) * 16);
+        if (!ASDF16_PRELOAD && t > 0) acc = bias_at(CL::kB1, t);
         auto pre = [&](int kb) {       // first stage: the layer-0 tile of the NEXT K-block's epilogue slot
           const int c = kb - kEpiShift;
           if (t == 0 && ASDF16_PRELOAD && kL0Front < kTilesHidden && c >= 0 && c + 1 < kEpiChunks) l0_load(kL0Front + c + 1);
@@ -753,8 +586,11 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
               // a whole layer-0 tile per K-block: its fp32 MFMAs behind the first MFMA, its eight parts over the three gaps (3 + 3 + 2)
               const int T = kL0Front + c;
               if (g == 0) {
+                if constexpr (W) pt_mfma(acc0[T & 1], pf0[T & 1]);
+                else {
 #pragma unroll
-                for (int s = 0; s < KP; ++s) acc0[T & 1] = ASDF_MFMA(pf0[T & 1][s], bp[s], acc0[T & 1]);
+                  for (int s = 0; s < KP; ++s) acc0[T & 1] = ASDF_MFMA(pf0[T & 1][s], bp[s], acc0[T & 1]);
+                }
               }
 #pragma unroll
               for (int e = 0; e < 8; ++e)
@@ -769,15 +605,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             return;
           }
           if (ABL & 4) { asm volatile("" :: "v"(acc1[(t - 1) & 1])); return; }
-          if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(t - 1) & 1]);
-          if (G == 2 && g != 0) pin_acc<PL>(acc1b[(t - 1) & 1]);
+          if (kSteps ? g <= 0 : g != 1) pin_acc_w<PL, W>(acc1[(t - 1) & 1]);
+          if (G == 2 && g != 0) pin_acc_w<PL, W>(acc1b[(t - 1) & 1]);
           split_part<PL, G, kMix>(acc1[(t - 1) & 1], acc1b[(t - 1) & 1], mul1, h1h[2 * (t - 1)], h1l[2 * (t - 1)], h1h[2 * (t - 1) + 1],
                             h1l[2 * (t - 1) + 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);
         };
         auto pre_last = [&](int c) {   // last stage: bias row (and point fragments) of the next tile
           if (!ASDF16_PRELOAD || c != kPreKb) return;
-          if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = load_bias16(hc + CL::kB1 + ((t + 1) * 2 + half) * 16); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
-          else { acc2[0] = load_bias16(hc + CL::kC2 + half * 16); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
+          if (t + 1 < kTilesL1) { acc1[(t + 1) & 1] = bias_at(CL::kB1, (t + 1)); if (G == 2) acc1b[(t + 1) & 1] = acc1[(t + 1) & 1]; }
+          else { acc2[0] = bias_at(CL::kC2, 0); if (G == 2) acc2b[0] = acc2[0]; load_pf2(0); }
         };
 #if ASDF16_STAGE_KB == 8
         ASDF_STAGE16(32, 0, 0, acc, h0h, h0l, t * 4 + 0, pre, epi);
@@ -804,25 +640,28 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         constexpr int SLOT = decltype(slot_tag)::value;
         f32x16& acc = acc2[t & 1];
         f32x16& accb = (G == 2 ? acc2b : acc2)[t & 1];
-        if (!ASDF16_PRELOAD) { acc = load_bias16(hc + CL::kC2 + (t * 2 + half) * 16); load_pf2(t); }
+        if (!ASDF16_PRELOAD) { acc = bias_at(CL::kC2, t); load_pf2(t); }
+        if constexpr (W) pt_mfma(acc, pf2);
+        else {
 #pragma unroll
         for (int s = 0; s < KP; ++s) {
           const float af = kPreloadPf ? pf2[s] : hc[CL::kA2 + (t * KP + s) * 64 + lane];
           acc = ASDF_MFMA(af, bp[s], acc);
           if (G == 2) accb = ASDF_MFMA(af, bpb[s], accb);
         }
+        }
         auto epi = [&](int kb, int g = -1) {
           const int c = kb - kEpiShift;
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc2[(t + 1) & 1]), "v"(acc1[1])); return; }
           if (t > 0) {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc_w<PL, W>(acc2[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc_w<PL, W>(acc2b[(t - 1) & 1]);
             split_part<PL, G, kMix>(acc2[(t - 1) & 1], acc2b[(t - 1) & 1], mul2, h2h[2 * (t - 1)], h2l[2 * (t - 1)], h2h[2 * (t - 1) + 1],
                               h2l[2 * (t - 1) + 1], amax2, c, kSteps ? -1 : g, kSteps ? g : -1, er);
           } else {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc1[(kTilesL1 - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc1b[(kTilesL1 - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc_w<PL, W>(acc1[(kTilesL1 - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc_w<PL, W>(acc1b[(kTilesL1 - 1) & 1]);
             split_part<PL, G, kMix>(acc1[(kTilesL1 - 1) & 1], acc1b[(kTilesL1 - 1) & 1], mul1, h1h[2 * kTilesL1 - 2], h1l[2 * kTilesL1 - 2],
                               h1h[2 * kTilesL1 - 1], h1l[2 * kTilesL1 - 1], amax1, c, kSteps ? -1 : g, kSteps ? g : -1, er);      // K-blocks 14, 15: consumed at the end of this tile, after chunk 7
           }
@@ -830,11 +669,11 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {
           if (!ASDF16_PRELOAD || c != kPreKb) return;
           if (t + 1 < kTilesHidden) {
-            acc2[(t + 1) & 1] = load_bias16(hc + CL::kC2 + ((t + 1) * 2 + half) * 16);
+            acc2[(t + 1) & 1] = bias_at(CL::kC2, (t + 1));
             if (G == 2) acc2b[(t + 1) & 1] = acc2[(t + 1) & 1];
             load_pf2(t + 1);
           } else {
-            acc3[0] = load_bias16(hc + CL::kB3 + half * 16);
+            acc3[0] = bias_at(CL::kB3, 0);
             if (G == 2) acc3b[0] = acc3[0];
           }
         };
@@ -881,6 +720,12 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
             if (G == 2 && g != 0) { const float v = ab[2 * c + r]; partg = fmaf(fabsf(v), w, fmaf(v, w, partg)); }
             continue;
           }
+          if constexpr (W) {        // registers 8 .. 15 are the second point group's: its own dot product
+            const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
+            if (c < 4) part = fmaf(v, w, part);
+            else partg = fmaf(v, w, partg);
+            continue;
+          }
           if (g != 1) {
             const float v = __int_as_float(max(__float_as_int(a[2 * c + r]), 0));
             part = fmaf(v, w, part);
@@ -895,7 +740,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
       for (int t = 0; t < kTilesHidden; ++t) {
         f32x16& acc = acc3[t & 1];
         f32x16& accb = (G == 2 ? acc3b : acc3)[t & 1];
-        if (!ASDF16_PRELOAD) acc = load_bias16(hc + CL::kB3 + (t * 2 + half) * 16);
+        if (!ASDF16_PRELOAD) acc = bias_at(CL::kB3, t);
         auto pre = [&](int kb) {       // first stage: w4 of the next epilogue part
           const int c = kb - kEpiShift;
           if (!kW4Tile && t > 0 && c >= 0 && c + 1 < kEpiChunks) load_w4(t - 1, c + 1);
@@ -905,8 +750,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
           if (c < 0 || c >= kEpiChunks) return;
           if (ABL & 4) { asm volatile("" :: "v"(acc3[(t + 1) & 1]), "v"(acc2[1])); return; }
           if (t > 0) {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc3[(t - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc3b[(t - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc_w<PL, W>(acc3[(t - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc_w<PL, W>(acc3b[(t - 1) & 1]);
             if (kSteps) {        // piece 0 / 1: one register of the pair each; piece 2: the next pair's weights
               if (g < 2) dot_w4_part(acc3[(t - 1) & 1], acc3b[(t - 1) & 1], c, -1, g);
               if (!kW4Tile && (g == 2 || g < 0)) next_w4();
@@ -915,8 +760,8 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
               if (!kW4Tile && g != 0) next_w4();            // (both groups use the same weights: rotate behind the second)
             }
           } else {
-            if (kSteps ? g <= 0 : g != 1) pin_acc<PL>(acc2[(kTilesHidden - 1) & 1]);
-            if (G == 2 && g != 0) pin_acc<PL>(acc2b[(kTilesHidden - 1) & 1]);
+            if (kSteps ? g <= 0 : g != 1) pin_acc_w<PL, W>(acc2[(kTilesHidden - 1) & 1]);
+            if (G == 2 && g != 0) pin_acc_w<PL, W>(acc2b[(kTilesHidden - 1) & 1]);
             split_part<PL, G, kMix>(acc2[(kTilesHidden - 1) & 1], acc2b[(kTilesHidden - 1) & 1], mul2, h2h[2 * kTilesHidden - 2],
                               h2l[2 * kTilesHidden - 2], h2h[2 * kTilesHidden - 1], h2l[2 * kTilesHidden - 1], amax2, c, kSteps ? -1 : g,
                               kSteps ? g : -1, er);  // K-blocks 30, 31: end of this tile
@@ -925,7 +770,7 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
         auto pre_last = [&](int c) {   // last stage: bias row of the next tile, w4 of the first part of this tile's epilogue
           if (c != kPreKb) return;
           if (ASDF16_PRELOAD && t + 1 < kTilesHidden) {
-            acc3[(t + 1) & 1] = load_bias16(hc + CL::kB3 + ((t + 1) * 2 + half) * 16);
+            acc3[(t + 1) & 1] = bias_at(CL::kB3, (t + 1));
             if (G == 2) acc3b[(t + 1) & 1] = acc3[(t + 1) & 1];
           }
           if (kW4Tile) { w4t = load_bias16(hc + CL::kW4 + (t * 2 + half) * 16); return; }
@@ -963,7 +808,15 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
 #endif
         return tanhf(x);
       };
-      part += __shfl_xor(part, 32);
+      if constexpr (W) {
+        // the four lane groups hold the four quarters of every feature half: sum them, then every lane takes the sum of ITS point
+        // l & 31 (group (l >> 4) & 1) - everything below is the 32x32 form's
+        part += __shfl_xor(part, 16); partg += __shfl_xor(partg, 16);
+        part += __shfl_xor(part, 32); partg += __shfl_xor(partg, 32);
+        part = (lane & 16) ? partg : part;
+      } else {
+        part += __shfl_xor(part, 32);
+      }
       const float pre = part + hc[CL::kB4];           // (pre-activations: the strict range report below looks at THESE)
       const float sdf = tanh_out(pre);
       float sdfb = 1.0f, preb = 0.0f, preg = 0.0f;
@@ -1112,6 +965,5 @@ __device__ __forceinline__ void sdf_mlp_f16_body(const DecodeParams& p) {
   if (!SUB && p.status && p.mode != kPointList && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(p.status + 12)[1] = clock64();
 }
 
-// The __global__ instantiations live in k1h_kernels.hip; tools/k1h_ablate.hip instantiates its own.
 
 }  // namespace asdf

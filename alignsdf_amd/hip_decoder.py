@@ -1175,6 +1175,14 @@ class HipSdfDecoder:
                 "switched": len(self.events["modes_switched_off"]), "cert": {k: self.cert[k] for k in self._ADDITIVE_CERT},
                 "math": self.math, "modes": (self.coarse_mode, self.fine_mode)}
 
+    @property
+    def split_half_kernel(self):
+        """Name of the split-half kernel an ordinary sweep of this decoder launches: the W form (v_mfma_f32_16x16x32_f16, round 6)
+        for a SeparateDecoder with affine point features unless the 32-wide instruction is selected (asdf_set_mfma_shape /
+        ASDF_K1H_SHAPE=32), the 32x32x16 form for CombinedDecoder and NeRF-encoded decoders."""
+        wide = not self.combined and not self.nerf_features and int(self._L.asdf_get_mfma_shape()) == 16
+        return "sdf_mlp_f16w_kernel" if wide else "sdf_mlp_f16_kernel"
+
     def sweep_report(self, since=None):
         """Which sweeps produced the volumes behind a run's meshes: one-plane / ordinary / refused-and-repeated counts per pass,
         audits, whole-lattice comparisons, the margins of the statistical certificate, and every mode switch."""

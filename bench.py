@@ -646,7 +646,7 @@ def main():
         kernel_name, peak, launch_ms_all = "sdf_mlp_f16p1_kernel", PEAK_F16_MFMA_TFLOPS, p1_ms
         exec_flop = N ** 3 * meshes_per_sample * EXEC_P1_FLOP_PER_POINT_HEAD
     else:
-        kernel_name = "sdf_mlp_f16_kernel" if split else "sdf_mlp_kernel"
+        kernel_name = dec.split_half_kernel if split else "sdf_mlp_kernel"
         peak, launch_ms_all = (PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS), k1_ms
         exec_flop = N ** 3 * meshes_per_sample * (EXEC_F16_FLOP_PER_POINT_HEAD if split else EXEC_FLOP_PER_POINT_HEAD)
     k_avg_s = float(np.mean(launch_ms_all)) * 1e-3
@@ -833,7 +833,8 @@ def main():
     try:
         import hashlib
         digest = hashlib.sha256()
-        for name in ("sdf_mlp_kernel.h" if kernel_name == "sdf_mlp_kernel" else "sdf_mlp_f16_kernel.h", "sdf_mlp_common.h", "sdf_layout.h"):
+        for name in (("sdf_mlp_f16w_kernel.h",) if kernel_name == "sdf_mlp_f16w_kernel" else ()) + (
+                "sdf_mlp_kernel.h" if kernel_name == "sdf_mlp_kernel" else "sdf_mlp_f16_kernel.h", "sdf_mlp_common.h", "sdf_layout.h"):
             with open(os.path.join(ROOT, "alignsdf_amd", "csrc", name), "rb") as f:
                 digest.update(f.read())
         for cand in sorted([p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith(".json") and "hbm_traffic" in p], reverse=True):

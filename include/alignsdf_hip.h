@@ -257,6 +257,15 @@ int asdf_decoder_set_cluster_list(asdf_decoder_t* dec, int32_t max_points);
  * every member gives up at its first wait without looking at the counter. */
 int asdf_decoder_set_cluster_timeout(asdf_decoder_t* dec, uint64_t ticks);
 
+/* Round 6: the matrix instruction of the split-half kernels of a SeparateDecoder with affine point features (every sweep and every
+ * voxel list of the default arithmetic).  16 (the default) = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16 - the same GEMMs,
+ * both within 1e-5 of the reference (their bits differ: the order of the partial sums does); under the part's power management the
+ * 16-wide form is ~5 % faster per sweep.  Process-wide (a launch-time choice, not decoder state); 0 = back to the environment's choice
+ * (ASDF_K1H_SHAPE=32 selects 32).  Returns the shape in force BEFORE the call, or ASDF_EINVAL.  CombinedDecoder and NeRF-encoded
+ * decoders always run the 32-wide form.  Kept for A/B measurements and as the fallback of a maintainer who distrusts the new kernels. */
+int asdf_set_mfma_shape(int shape);
+int asdf_get_mfma_shape(void);
+
 /* Measurement hook: the next asdf_decode_grid / asdf_decode_points call of this decoder records the two hipEvent_t (passed
  * as void*, created by the caller with timing enabled) immediately before and after the launch of its dominant kernel
  * (sdf_mlp_f16_kernel or sdf_mlp_kernel) on the call's stream - not around the small kernels next to it (bbox

@@ -257,3 +257,56 @@ def test_fallback_decision_rests_on_the_record_alone():
     _, _, clean = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
     assert hip.fall_back_if_overflowed(clean.cpu().numpy()) is False
     hip.close()
+
+
+# ---- round 6: the matrix instruction of the split-half SeparateDecoder kernels (asdf_set_mfma_shape) ------------------------------
+@pytest.fixture
+def mfma_shape():
+    """Sets the process-wide shape for a test and puts the previous one back."""
+    L = _native.lib()
+    before = L.asdf_get_mfma_shape()
+    yield lambda shape: L.asdf_set_mfma_shape(int(shape))
+    L.asdf_set_mfma_shape(before)
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9", "hand6", "obj6"])
+def test_both_mfma_shapes_match_the_reference_and_each_other(tag, golden_dir, mfma_shape):
+    """The W form (v_mfma_f32_16x16x32_f16, the default since round 6) and the 32x32x16 form of the split-half kernel evaluate the
+    same GEMMs: both within 1e-5 of the REFERENCE's own run on the probes, identical boxes, and within 2e-6 of each other on every
+    voxel - yet different bits (other partial-sum order), i.e. the switch really selects another kernel.  (That a voxel's bits do
+    not depend on the lane it sits in - the W form's two point groups take a record's MFMAs in snake order, the voxel lists of the
+    subset form place a voxel anywhere - is pinned by tests/test_gpu_default_sweeps.py: the --fast sweeps' meshes, whose values come
+    from the subset form, are the ordinary sweeps' vertex for vertex; a group-dependent product order failed exactly there.)"""
+    g = np.load("%s/ref_decoder_%s.npz" % (golden_dir, tag))
+    hip = _decoder(tag)
+    assert _native.lib().asdf_get_mfma_shape() == 16 and hip.split_half_kernel == "sdf_mlp_f16w_kernel"
+    vols = {}
+    for shape in (16, 32):
+        assert mfma_shape(shape) in (16, 32) and _native.lib().asdf_get_mfma_shape() == shape
+        assert hip.split_half_kernel == ("sdf_mlp_f16w_kernel" if shape == 16 else "sdf_mlp_f16_kernel")
+        for N in (32, 64):
+            vh, vo, bbox = hip.decode_grid(N, [-1.0, -1.0, -1.0], 2.0 / (N - 1))
+            sel = g["probe_sel_%d" % N]
+            assert np.abs(vh.cpu().numpy().reshape(-1)[sel] - g["p1_hand_%d" % N]).max() <= TOL
+            assert np.abs(vo.cpu().numpy().reshape(-1)[sel] - g["p1_obj_%d" % N]).max() <= TOL
+            b = bbox.cpu().numpy()
+            assert np.array_equal(np.stack([b[0:6], b[8:14]]), g["bbox_%d" % N]) and b[7] == 0 and b[15] == 0
+            vols[(shape, N)] = (vh, vo)
+    for N in (32, 64):
+        for k in (0, 1):
+            d = (vols[(16, N)][k] - vols[(32, N)][k]).abs().max().item()
+            assert 0.0 < d <= 2e-6, (N, k, d)
+    assert _native.lib().asdf_set_mfma_shape(7) == _native.lib().asdf_set_mfma_shape(7) < 0        # EINVAL, nothing changed
+    hip.close()
+
+
+def test_combined_and_nerf_decoders_keep_the_32_wide_kernels(mfma_shape):
+    for tag in ("comb3", "nerf9"):
+        hip = _decoder(tag)
+        assert hip.split_half_kernel == "sdf_mlp_f16_kernel"
+        mfma_shape(32)
+        a = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
+        mfma_shape(16)
+        b = hip.decode_grid(32, [-1.0, -1.0, -1.0], 2.0 / 31)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])      # the switch does not reach them
+        hip.close()

@@ -15,7 +15,7 @@ def compiled(tmp_path_factory):
     """One device-only compile of every decoder translation unit (side by side): (resource-usage remarks, ISA text)."""
     out_dir = tmp_path_factory.mktemp("isa")
     from alignsdf_amd.build_native import TU_FLAGS          # (the per-unit flags of the shipped build: MFMA accumulators in VGPRs for some)
-    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip"]
+    units = ["decoder.hip", "k1_kernels.hip", "k1_cls_kernels.hip", "k1h_kernels.hip", "k1hw_kernels.hip", "k1h_nerf_kernels.hip", "k1s_kernels.hip", "k1s_nerf_kernels.hip"]
     procs = [(u, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *TU_FLAGS.get(u, []), "-S",
                                    "--cuda-device-only", u, "-o", str(out_dir / (u + ".s")), "-Rpass-analysis=kernel-resource-usage"],
                                   cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for u in units]
@@ -168,3 +168,36 @@ def test_short_list_kernel_cluster_form(compiled):
     assert "s_sleep" in body and "s_memrealtime" in body and "s_trap" not in body
     mfma = set(re.findall(r"v_mfma_\w+", body))
     assert mfma == {"v_mfma_f32_32x32x2_f32"}, mfma
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_split_half_kernel_w_form(compiled):
+    """Round 6, the W form (sdf_mlp_f16w_kernel / _subset_kernel: the same GEMMs on v_mfma_f32_16x16x32_f16), pinned in the ISA:
+    * every loop fully unrolled - 6144 16x16x32 MFMAs + 128 v_mfma_f32_16x16x4_f32 of the point features per tile body, NO indexed
+      registers (at the compiler's default unroll threshold the layer loops came out rolled: 87 instead of 72 ms per sweep - the
+      translation unit's own flag in build_native.TU_FLAGS), no 32x32 MFMA left;
+    * the plane split of the 32-wide form, unchanged (640 + 640 v_fma_mix);
+    * at most 512 registers, one wave per SIMD, and whatever sits in scratch (a few dozen per-thread constants of the tile prologue)
+      is NOT touched between the MFMAs of the three hidden layers: at most 8 scratch accesses inside the MFMA stream of a tile body;
+    * the accumulator quads are pinned one by one: no gather of a finished accumulator through v_accvgpr_read / write pairs (the
+      512-bit pin of the 32-wide form cost 16 + 16 per tile here)."""
+    remarks, text = compiled
+    for frag, mangled in (("19sdf_mlp_f16w_kernelE", "_ZN4asdf19sdf_mlp_f16w_kernelENS_12DecodeParamsE"),
+                          ("26sdf_mlp_f16w_subset_kernelE", "_ZN4asdf26sdf_mlp_f16w_subset_kernelENS_12DecodeParamsE")):
+        block = [b for b in re.split(r"remark: Function Name: ", remarks)[1:] if frag in b.split()[0]]
+        assert len(block) == 1, frag
+        get = lambda key: int(re.search(key + r": (\d+)", block[0]).group(1))
+        assert get("VGPRs") + get("AGPRs") <= 512 and get(r"Occupancy \[waves/SIMD\]") == 1 and get(r"ScratchSize \[bytes/lane\]") <= 256, block[0][:400]
+        body = text[text.index(mangled + ":"):]
+        body = [l.strip() for l in body[:body.index("s_endpgm")].splitlines()]
+        ins = [l.split()[0] for l in body if l and not l.startswith((";", ".", "_")) and not l.endswith(":")]
+        count = lambda name: sum(1 for i in ins if i == name)
+        assert count("v_mfma_f32_16x16x32_f16") == 6144 and count("v_mfma_f32_16x16x4_f32") == 128, (count("v_mfma_f32_16x16x32_f16"), count("v_mfma_f32_16x16x4_f32"))
+        assert count("v_mfma_f32_32x32x16_f16") == 0 and count("v_mfma_f32_32x32x2_f32") == 0
+        assert "s_set_gpr_idx_on" not in ins and not [i for i in ins if i.startswith("v_movrel")]
+        assert count("v_fma_mixlo_f16") == 640 and count("v_fma_mixhi_f16") == 640
+        assert not [i for i in ins if i.startswith("ds_max") or i.startswith("ds_add") or i.startswith("ds_min")]
+        mfma = [k for k, i in enumerate(ins) if i.startswith("v_mfma_")]
+        scratch = [k for k, i in enumerate(ins) if i.startswith("scratch_")]
+        assert len([k for k in scratch if mfma[0] < k < mfma[-1]]) <= 8, len([k for k in scratch if mfma[0] < k < mfma[-1]])
+        assert count("v_accvgpr_write_b32") <= 600 and count("v_accvgpr_read_b32") <= 1400, (count("v_accvgpr_write_b32"), count("v_accvgpr_read_b32"))

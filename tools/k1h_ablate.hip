@@ -17,7 +17,7 @@
 #ifdef ASDF16_SEGMENT_TIMES
 __device__ unsigned long long g_seg[8];
 #endif
-#include "sdf_mlp_f16_kernel.h"
+#include "sdf_mlp_f16w_kernel.h"
 using namespace asdf;
 #ifndef ABL_LIST
 #define ABL_LIST X(0) X(32) X(1) X(16) X(4)
@@ -31,10 +31,15 @@ using namespace asdf;
 #ifndef WIDE
 #define WIDE 0          // 1 = the W form (16x16x32 MFMAs; timing only here: it is fed the 32x32x16 image - the same values in another order)
 #endif
+#if WIDE
+#define K1H_BODY(n) sdf_mlp_f16w_body<n, false>(p);
+#else
+#define K1H_BODY(n) sdf_mlp_f16_body<false, n, 2, PLANES, GROUPS>(p);
+#endif
 constexpr int kLds = PLANES == 1 ? kLdsBytesF16P1 : kLdsBytesF16;
 __device__ unsigned long long g_ticks[2];
 #define X(n) __global__ __launch_bounds__(256, 1) void k_abl_##n(const DecodeParams p) { \
-    unsigned long long t0 = __builtin_readcyclecounter(); sdf_mlp_f16_body<false, n, 2, PLANES, GROUPS, false, WIDE != 0>(p); \
+    unsigned long long t0 = __builtin_readcyclecounter(); K1H_BODY(n)  \
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = t0; g_ticks[1] = __builtin_readcyclecounter(); } }
 ABL_LIST
 #undef X
