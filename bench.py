@@ -739,8 +739,8 @@ def main():
             e2, k2_ms, done2, _ = cfg.timed(args.warmup, args.steps, 1, N, keep_meshes=True)
             other_sweeps = {"kind": "ordinary", "coarse": "exact", "fine": "exact", "math": dec.math, "steps": args.steps, "warmup": 1,
                             "ms_per_step": 1e3 * e2 / args.steps, "value": meshes_per_sample * args.steps / e2, "unit": "meshes/s",
-                            "kernel": "sdf_mlp_f16_kernel", "launch_ms": float(np.mean(k2_ms)) if k2_ms else None,
-                            "dtype": "f32 as 2 x f16 planes (3 x v_mfma_f32_32x32x16_f16 per product sum, fp32 accumulate) on every voxel"}
+                            "kernel": dec.split_half_kernel, "launch_ms": float(np.mean(k2_ms)) if k2_ms else None,
+                            "dtype": "f32 as 2 x f16 planes (3 f16 MFMAs per product sum, fp32 accumulate) on every voxel"}
             other_sweeps.update(kernel_clocks(dec, k2_ms, N, meshes_per_sample, EXEC_F16_FLOP_PER_POINT_HEAD, EXEC_F16_SIDE_F32_FLOP_PER_POINT_HEAD))
             if k2_ms:
                 other_sweeps["achieved"] = N ** 3 * meshes_per_sample * EXEC_F16_FLOP_PER_POINT_HEAD / (np.mean(k2_ms) * 1e-3) / 1e12
@@ -875,6 +875,8 @@ def main():
         # same launch's duration; `pipe_busy` = MFMA issue cycles per SIMD / those clocks: frac = pipe_busy x clock / 2.4 GHz.
         roofline = {
             "bound": "mfma", "kernel": kernel_name,
+            "mfma_instruction": {"sdf_mlp_f16w_kernel": "v_mfma_f32_16x16x32_f16", "sdf_mlp_f16_kernel": "v_mfma_f32_32x32x16_f16",
+                                 "sdf_mlp_f16p1_kernel": "v_mfma_f32_32x32x16_f16"}.get(kernel_name, "v_mfma_f32_32x32x2_f32"),
             "achieved": exec_flop / k_avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": exec_flop / k_avg_s / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": 1e3 * k_avg_s, "launches_timed": len(launch_ms_all),

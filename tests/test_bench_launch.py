@@ -89,7 +89,7 @@ def test_bench_line_contract_hand_only_config0():
     assert "every voxel" in line["dtype"] and "2 x f16 planes" in line["dtype"] and "1 plane" not in line["dtype"]
     r = line["roofline"]
     # the kernel that produced `value`: the split-half kernel, 2 launches per sample
-    assert r["kernel"] == "sdf_mlp_f16_kernel" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["launches_timed"] == 6 and r["peak"] == 2516.6
+    assert r["kernel"] == "sdf_mlp_f16w_kernel" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["launches_timed"] == 6 and r["peak"] == 2516.6
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
     assert abs(r["achieved"] - r["executed_flop_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     assert "frac_algorithmic" not in r and r["reference_dense_fp32_tflops_equivalent"] > 0 and 0.5 < r["shader_clock_ghz"] < 2.6 and 0.0 < r["pipe_busy"] < 1.0
@@ -132,7 +132,7 @@ def test_bench_line_under_fast_sweeps():
     assert "1 plane" in line["dtype"] and r["kernel"] == "sdf_mlp_f16p1_kernel" and r["launches_timed"] == 6
     assert 0.5 < r["shader_clock_ghz"] < 2.6 and 0.0 < r["pipe_busy"] < 1.0 and abs(r["frac_from_busy_and_clock"] - r["frac"]) < 0.02 * r["frac"]
     assert cfg["meshes_per_s_every_voxel_f16x3"] > 0 and cfg["meshes_per_s_every_voxel_f16x3"] < line["value"]
-    assert r["every_voxel_kernel"] == "sdf_mlp_f16_kernel" and 0 < r["every_voxel_frac"] < 1
+    assert r["every_voxel_kernel"] == "sdf_mlp_f16w_kernel" and 0 < r["every_voxel_frac"] < 1
     assert cfg["sweeps"]["of"] == "timed region" and cfg["sweeps"]["refused"] == 0
     assert cfg["parity_in_run"]["meshes_bit_identical_to_every_voxel_f16x3"] == 3
 
