@@ -4,6 +4,8 @@
 // One 256-thread workgroup per CU, one wave per SIMD, operands in registers only (no LDS, no memory): the bare instruction.
 //   shape 0: v_mfma_f32_32x32x16_f16, one accumulator chain (K1h's instruction)
 //   shape 1: v_mfma_f32_16x16x32_f16, four accumulator chains (same 16 accumulator registers)
+//   shapes 2 / 3: K1h's operand pattern on 16x16x32 (two chains, alternating) / on 32x32x16; 4: 16x16x32 as ONE fully dependent chain;
+//   5: the W form's shipped order (a group's three MFMAs back to back, the groups in snake order)
 //   data  0: zeros | 1: random fp16 of K1h's plane magnitudes (A: +-[512, 1024) mantissas random; B: half of the values zero = ReLU)
 //         2: as 1 with the B operand's low 5 mantissa bits cleared | 3: as 1 with A AND B low 5 mantissa bits cleared
 // Each launch runs ~60 ms so that the clock settles; prints ms, TFLOP/s and the shader clock held (s_memtime ticks / wall).
@@ -48,6 +50,33 @@ __global__ __launch_bounds__(256, 1) void bench(float* out, const h8* a_in, cons
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m1], c1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1], c1, 0, 0, 0);
+      } else if (SHAPE == 4) {
+        // 16x16x32, ONE fully dependent chain (what does a dependent 4-pass MFMA cost back to back?)
+        const int j = (k % (kA / 2)) * 2, m0 = (2 * k) % kB, m1 = (2 * k + 2) % kB;
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0 + 1], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m0], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1 + 1], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m1], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1], c0, 0, 0, 0);
+      } else if (SHAPE == 5) {
+        // the W form's shipped order: a group's three MFMAs back to back, the groups in snake order (chains of 6 across records)
+        const int j = (k % (kA / 2)) * 2, m0 = (2 * k) % kB, m1 = (2 * k + 2) % kB;
+        if (k & 1) {
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1 + 1], c1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m1], c1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1], c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0 + 1], c0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m0], c0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0], c0, 0, 0, 0);
+        } else {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0 + 1], c0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m0], c0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m0], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1 + 1], c1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j + 1], b[m1], c1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[m1], c1, 0, 0, 0);
+        }
       } else if (SHAPE == 3) {
         // the same on 32x32x16: (W_hi, x_lo), (W_lo, x_hi), (W_hi, x_hi) - exactly K1h's K-block
         const int j = (k % (kA / 2)) * 2, m0 = (2 * k) % kB;
@@ -120,14 +149,16 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(a_d, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(b_d, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep)
-      for (int shape = 0; shape < 4; ++shape) {
+      for (int shape = 0; shape < 6; ++shape) {
         float best = 1e9; double ghz = 0;
         for (int r = 0; r < 3; ++r) {
           (void)hipEventRecord(e0);
           if (shape == 0) hipLaunchKernelGGL(bench<0>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
           else if (shape == 1) hipLaunchKernelGGL(bench<1>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
           else if (shape == 2) hipLaunchKernelGGL(bench<2>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
-          else hipLaunchKernelGGL(bench<3>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
+          else if (shape == 3) hipLaunchKernelGGL(bench<3>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
+          else if (shape == 4) hipLaunchKernelGGL(bench<4>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
+          else hipLaunchKernelGGL(bench<5>, dim3(256), dim3(256), 0, 0, out, a_d, b_d, iters);
           (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
           float ms; (void)hipEventElapsedTime(&ms, e0, e1);
           unsigned long long t[2]; (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), 16);
@@ -135,7 +166,7 @@ int main(int argc, char** argv) {
         }
         const double flop = (double)iters * kB * 3 * 32768.0 * 1024;      // per launch: 1024 SIMDs
         printf("data %d  %-10s  %.2f ms  %.0f TFLOP/s (%.1f %% of 2516.6)  clock %.3f GHz  cycles per 32 K flop %.1f\n", data,
-               shape == 0 ? "32x32x16" : shape == 1 ? "16x16x32" : shape == 2 ? "16x16 K1h" : "32x32 K1h", best, flop / best / 1e9, flop / best / 1e9 / 25.166, ghz, best * 1e6 * ghz / ((double)iters * kB * 3));
+               shape == 0 ? "32x32x16" : shape == 1 ? "16x16x32" : shape == 2 ? "16x16 K1h" : shape == 3 ? "32x32 K1h" : shape == 4 ? "16x16 chain" : "16x16 ord3", best, flop / best / 1e9, flop / best / 1e9 / 25.166, ghz, best * 1e6 * ghz / ((double)iters * kB * 3));
       }
   }
   return 0;
