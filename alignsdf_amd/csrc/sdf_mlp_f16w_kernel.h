@@ -83,6 +83,39 @@ __device__ __forceinline__ void pin_acc_w(f32x16& acc) {
 }
 
 
+// One LDS-DMA piece with M0 declared CLOBBERED instead of saved and restored around the instruction (5 -> 3 instructions per piece).
+// The 32-wide form hides a piece in the 32 clocks of an MFMA; under the W form's 16-clock MFMAs the two extra scalar moves of every
+// piece showed (without its LDS-DMA instructions the W form ran 10-11 % faster, the 32-wide form 6 %).
+#ifndef ASDF16_W_M0_CLOBBER
+#define ASDF16_W_M0_CLOBBER 1
+#endif
+template <int P>
+__device__ __forceinline__ void dma_piece_w(const float* src, unsigned dst) {
+#if ASDF16_W_M0_CLOBBER == 2
+  // (timing experiment: M0 written once per four pieces - it would have to survive between asm statements)
+  if ((P & 3) == 0)
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off offset:%c2"
+        :
+        : "v"(src + (P >> 2) * 1024), "s"(dst + (P >> 2) * 4096), "i"((P & 3) * 1024)
+        : "memory", "m0");
+  else
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%c1" : : "v"(src + (P >> 2) * 1024), "i"((P & 3) * 1024) : "memory");
+#elif ASDF16_W_M0_CLOBBER
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off offset:%c2"
+      :
+      : "v"(src + (P >> 2) * 1024), "s"(dst + (P >> 2) * 4096), "i"((P & 3) * 1024)
+      : "memory", "m0");
+#else
+  dma_piece<P>(src, dst);
+#endif
+}
+
 // One stage = kS16Kb K-blocks of one 32-row output tile: [kblock][plane hi / lo][lane][8 halves].
 // On entry (ah[i], al[i]) hold the A fragments of K-blocks 0 .. PREFETCH-1 of THIS stage; on exit those of the next
 // stage in stream order.  Every K-block is one scheduling region
@@ -189,14 +222,14 @@ __device__ __forceinline__ void stage16w(f32x16& acc, f32x16& accb, const h8 (&x
       constexpr bool kDmaPerKb = STEPS && ASDF16_DMA_PER_KB && kS16Kb - BKB >= SG::kPieces;
       const int m = kDmaPerKb ? (j == 2 ? kb - BKB : -1) : (kb - BKB) * SG::kMfmas + j;
       if (!(ABL & 1) && !(ABL & 32) && m >= 0 && m < SG::kPieces) {
-        if (m == 0) dma_piece<0>(src, dst);
-        else if (m == 1) dma_piece<1>(src, dst);
-        else if (m == 2) dma_piece<2>(src, dst);
-        else if (m == 3) dma_piece<3>(src, dst);
-        else if (m == 4) dma_piece<4>(src, dst);
-        else if (m == 5) dma_piece<5>(src, dst);
-        else if (m == 6) dma_piece<6>(src, dst);
-        else dma_piece<7>(src, dst);
+        if (m == 0) dma_piece_w<0>(src, dst);
+        else if (m == 1) dma_piece_w<1>(src, dst);
+        else if (m == 2) dma_piece_w<2>(src, dst);
+        else if (m == 3) dma_piece_w<3>(src, dst);
+        else if (m == 4) dma_piece_w<4>(src, dst);
+        else if (m == 5) dma_piece_w<5>(src, dst);
+        else if (m == 6) dma_piece_w<6>(src, dst);
+        else dma_piece_w<7>(src, dst);
         __builtin_amdgcn_sched_barrier(0);
       }
 #ifdef ASDF16_FENCE_EVERY_MFMA
