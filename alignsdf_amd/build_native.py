@@ -20,7 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # the W form's K-blocks carry more IR (sub-accumulator extracts / inserts around six MFMAs): at the default threshold the layer loops of
 # k1hw_kernels.hip come out ROLLED, with indexed registers (s_set_gpr_idx_on) - 87 instead of 72 ms per sweep
-UNROLL_ALL = ["-mllvm", "-pragma-unroll-threshold=200000"]
+# (-Wno-inline-asm: its LDS-DMA pieces name the reserved register M0 as clobbered - sdf_mlp_f16w_kernel.h: dma_piece_w - which the
+# compiler reports once per instantiation)
+UNROLL_ALL = ["-mllvm", "-pragma-unroll-threshold=200000", "-Wno-inline-asm"]
 TU_FLAGS = {"k1hw_kernels.hip": UNROLL_ALL, "k1s_kernels.hip": VGPR_FORM, "k1s_nerf_kernels.hip": VGPR_FORM, "k1_kernels.hip": VGPR_FORM, "k1_cls_kernels.hip": VGPR_FORM}
 
 
