@@ -17,7 +17,7 @@ FEATURES_NERF = 1
 
 ERANGE = -6
 ENOSURF = -7
-ABI_VERSION = 128        # asdf_version() of the library these bindings were written for
+ABI_VERSION = 129        # asdf_version() of the library these bindings were written for
 
 # every symbol include/alignsdf_hip.h declares
 EXPORTS = (
@@ -31,6 +31,7 @@ EXPORTS = (
     "asdf_zoom_cube", "asdf_decode_grid_band_dev", "asdf_decode_grid_dev", "asdf_mc_emit_bounded",
     "asdf_sample_surface_workspace_bytes", "asdf_sample_surface", "asdf_icp_normalise",
     "asdf_decoder_set_sample_host", "asdf_decoder_set_cluster_timeout", "asdf_set_mfma_shape", "asdf_get_mfma_shape",
+    "asdf_debug_pack_host_f16w",
 )
 MATH_F32, MATH_F16X3 = 0, 1
 MAX_CLASSES = 8
@@ -135,6 +136,7 @@ def lib():
     L.asdf_sample_surface.argtypes = [vp, vp, i32, vp, i32, f32, ctypes.POINTER(f32), vp, vp, i32, vp, vp, ctypes.c_size_t, vp]
     L.asdf_icp_normalise.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.asdf_debug_pack_host_f16.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams), vp, vp, vp]
+    L.asdf_debug_pack_host_f16w.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams), vp]
     L.asdf_debug_pack_host.argtypes = [ctypes.POINTER(DecoderSpec), ctypes.POINTER(HeadParams)] + [vp] * 6
     _lib = L
     return L

@@ -789,7 +789,7 @@ static bool spec_supported(const asdf_decoder_spec_t* s) {
 
 extern "C" {
 
-int asdf_version(void) { return 128; }
+int asdf_version(void) { return 129; }
 
 int asdf_set_mfma_shape(int shape) {
   if (shape != 0 && shape != 16 && shape != 32) return ASDF_EINVAL;
@@ -984,6 +984,15 @@ int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params
   if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
   auto cp = [](float* dst, const std::vector<float>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(float)); };
   cp(stream, hp.stream); cp(wlat, hp.wlat); cp(wpt, hp.wpt); cp(bias02, hp.b02); cp(cst, hp.cst); cp(embed, hp.emb);
+  return ASDF_OK;
+}
+
+int asdf_debug_pack_host_f16w(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16w) {
+  if (!spec || !heads || !stream16w || !spec_supported(spec)) return ASDF_EINVAL;
+  HostPack hp;
+  if (!pack_decoder(*spec, heads, hp)) return ASDF_ENOMEM;
+  if (!pack_decoder_f16(*spec, heads, hp)) return ASDF_ENOMEM;
+  std::memcpy(stream16w, hp.stream16w.data(), hp.stream16w.size() * sizeof(uint16_t));
   return ASDF_OK;
 }
 

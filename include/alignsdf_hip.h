@@ -423,6 +423,11 @@ int asdf_debug_pack_host(const asdf_decoder_spec_t* spec, const asdf_head_params
  * s2[2] = the layer-2 accumulator scale per head that K0 applies to the per-sample constants. */
 int asdf_debug_pack_host_f16(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16,
                              float* cst16, float* s2);
+/* The same weights in the record order of the W form (v_mfma_f32_16x16x32_f16; sdf_mlp_f16w_kernel.h): stream16w 2*128*8192 fp16 bit
+ * patterns, 2 KiB records [plane hi/lo][lane 64][8] = (tile, feature half, K32-block) - lane l: output row 32 t + 16 fh + (l & 15),
+ * slot (l >> 4, e): input feature 32 j + 16 (e >> 2) + 4 (l >> 4) + (e & 3); layers 1 / 3: record i = (fh i / 16, j i % 16), layer 2:
+ * (fh i % 2, j i / 2). */
+int asdf_debug_pack_host_f16w(const asdf_decoder_spec_t* spec, const asdf_head_params_t* heads, uint16_t* stream16w);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,9 @@ def pack_host(sd, point_feat_size, encode_style):
         out["s2"] = np.zeros(2, np.float32)
         _native.check(L.asdf_debug_pack_host_f16(ctypes.byref(spec), heads, ptr(out["stream16"]), ptr(out["cst16"]), ptr(out["s2"])),
                       "asdf_debug_pack_host_f16")
+        # ... and the W form's image of the same weights (sdf_mlp_f16w_kernel.h)
+        out["stream16w"] = np.zeros(256 * STAGE * 2, np.uint16)
+        _native.check(L.asdf_debug_pack_host_f16w(ctypes.byref(spec), heads, ptr(out["stream16w"])), "asdf_debug_pack_host_f16w")
     return out
 
 

@@ -83,3 +83,40 @@ def test_library_exports_every_declared_symbol(native_lib):
         assert hasattr(native_lib, name), name
     assert native_lib.asdf_version() == _native.ABI_VERSION
     assert native_lib.asdf_strerror(-6).decode().startswith("Surface level")
+
+
+@pytest.mark.parametrize("tag", ["nerf3", "both9"])
+def test_w_form_image_is_the_same_weights_in_its_slot_order(tag, native_lib):
+    """Round 6: the weight stream of the W form (v_mfma_f32_16x16x32_f16; pack.h: pack_decoder_f16, second image) holds exactly the fp16
+    planes of the 32-wide form's image - same scales, same hi / lo values per (output row, input feature) - in the record and slot order
+    sdf_mlp_f16w_kernel.h documents: record (tile t, feature half fh, K32-block j), lane l = row 32 t + 16 fh + (l & 15), slot
+    (q = l >> 4, e) = input feature 32 j + 16 (e >> 2) + 4 q + (e & 3); layers 1 / 3 feature half outer (i = 16 fh + j), layer 2
+    K32-block outer (i = 2 j + fh).  Both images are unpacked into dense [row][feature] matrices here and compared bit for bit."""
+    specs = syn.specs_for(tag)
+    pk = emu.pack_host(syn.full_state_dict(tag), specs["PointFeatSize"], specs["EncodeStyle"])
+    old = pk["stream16"].reshape(2, 1024, 2, 64, 8)          # [head][record = (tile, K16-block)][plane][lane][e]
+    new = pk["stream16w"].reshape(2, 1024, 2, 64, 8)
+    lane = np.arange(64)[:, None]
+    e = np.arange(8)[None, :]
+    tile_row = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+    layers = ((8, 32, 0), (16, 16, 256), (16, 32, 512))      # (tiles, records per tile, first record) of layers 1, 2, 3
+    for head in range(2):
+        for tiles, per, first in layers:
+            K = per * 16
+            dense_old = np.zeros((2, tiles * 32, K), np.uint16)
+            dense_new = np.zeros((2, tiles * 32, K), np.uint16)
+            for t in range(tiles):
+                for i in range(per):
+                    rec = first + t * per + i
+                    # 32-wide form: record i = K16-block i; lane l: row 32 t + (l & 31), element e: feature 32 (i >> 1) + tile_row(8 (i & 1) + e, l >> 5)
+                    rows = 32 * t + (lane & 31) + 0 * e
+                    feats = 32 * (i >> 1) + tile_row(8 * (i & 1) + e, lane >> 5)
+                    for plane in range(2):
+                        dense_old[plane, rows, feats] = old[head, rec, plane]
+                    fh, j = (i // 16, i % 16) if per == 32 else (i & 1, i >> 1)
+                    rows = 32 * t + 16 * fh + (lane & 15) + 0 * e
+                    feats = 32 * j + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3)
+                    for plane in range(2):
+                        dense_new[plane, rows, feats] = new[head, rec, plane]
+            assert np.array_equal(dense_old, dense_new), (tag, head, tiles, per)
+            assert dense_old[0].any()

@@ -25,7 +25,14 @@ __global__ __launch_bounds__(256, 1) void bench(float* out, const h8* a_in, cons
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 192; ++k) {      // 192 MFMAs per iteration
+#ifdef K1H_PATTERN
+      // K1h's operand pattern: per (record, group) three MFMAs (W_hi, x_lo), (W_lo, x_hi), (W_hi, x_hi); a[2 r] / a[2 r + 1] = the planes
+      // of record r's A fragment, b[2 m] / b[2 m + 1] = x_hi / x_lo of operand m
+      const int rec = k / 3, ph = k % 3;
+      const int ai = (rec % (kA / 2)) * 2 + (ph == 1 ? 1 : 0), bi = ((rec * 2) % kB) + (ph == 0 ? 1 : 0);
+#else
       const int ai = (k / 3) % kA, bi = (k * 5) % kB;
+#endif
       if ((k / L) & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ai], b[bi], c1, 0, 0, 0);
       else c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ai], b[bi], c0, 0, 0, 0);
     }
